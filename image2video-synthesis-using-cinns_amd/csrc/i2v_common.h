@@ -1,0 +1,87 @@
+// Shared host-side helpers of libi2v_hip.so (error plumbing, state_dict lookup, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/i2v_hip.h"
+
+namespace i2v {
+
+void set_error(const char* fmt, ...);
+
+#define I2V_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            i2v::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return I2V_E_HIP;                                                                \
+        }                                                                                    \
+    } while (0)
+
+#define I2V_REQUIRE(cond, code, ...)  \
+    do {                              \
+        if (!(cond)) {                \
+            i2v::set_error(__VA_ARGS__); \
+            return (code);            \
+        }                             \
+    } while (0)
+
+// state_dict view: name -> host tensor
+struct StateDict {
+    std::unordered_map<std::string, const i2v_tensor*> map;
+    StateDict(const i2v_tensor* t, int n) {
+        for (int i = 0; i < n; ++i) map.emplace(t[i].name, &t[i]);
+    }
+    // returns nullptr (and sets the error) when missing / wrong size / wrong dtype
+    const float* f32(const std::string& key, int64_t numel) const {
+        auto it = map.find(key);
+        if (it == map.end()) { set_error("state_dict key '%s' missing", key.c_str()); return nullptr; }
+        if (it->second->dtype != I2V_F32 || it->second->numel != numel || !it->second->data) {
+            set_error("state_dict key '%s': expected %lld float32 elements, got %lld (dtype %d)", key.c_str(),
+                      (long long)numel, (long long)it->second->numel, it->second->dtype);
+            return nullptr;
+        }
+        return static_cast<const float*>(it->second->data);
+    }
+    const int64_t* i64(const std::string& key, int64_t numel) const {
+        auto it = map.find(key);
+        if (it == map.end()) { set_error("state_dict key '%s' missing", key.c_str()); return nullptr; }
+        if (it->second->dtype != I2V_I64 || it->second->numel != numel || !it->second->data) {
+            set_error("state_dict key '%s': expected %lld int64 elements", key.c_str(), (long long)numel);
+            return nullptr;
+        }
+        return static_cast<const int64_t*>(it->second->data);
+    }
+    bool has(const std::string& key) const { return map.find(key) != map.end(); }
+};
+
+// Owning device allocation.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int upload(const void* host, size_t n) {
+        release();
+        if (n == 0) return I2V_OK;
+        I2V_HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+        I2V_HIP_CHECK(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
+        return I2V_OK;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace i2v

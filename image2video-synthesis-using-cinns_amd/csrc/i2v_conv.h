@@ -1,0 +1,48 @@
+// Implicit-GEMM convolution on gfx950 matrix cores (shared declarations).
+#pragma once
+#include "i2v_common.h"
+
+namespace i2v {
+
+constexpr int CONV_BM = 128;   // output positions per workgroup
+constexpr int CONV_KC = 16;    // input channels per K chunk
+constexpr int CONV_LDS_STRIDE = 20;  // floats per staged row of 16 channels (+4 pad: conflict-free ds_read_b128)
+
+enum ConvEpilogue : int {
+    EPI_NONE = 0,
+    EPI_LRELU = 1,   // leaky_relu(0.2) on the result (decoder.py:51-52,117)
+    EPI_FRAMES = 2,  // tanh + store as [B][T][3][H][W] (decoder.py:118-120)
+};
+
+// Weights packed for the kernel: [tap][chunk][CoutPad][16] floats (zero padded).
+struct ConvWeights {
+    DevBuf w;
+    DevBuf bias;      // [Cout] (empty = no bias)
+    int Cin = 0, Cout = 0, CoutPad = 0, nchunk = 0;
+    int KT = 1, KH = 1, KW = 1;
+    // w_src: torch layout [Cout][Cin][KT][KH][KW]; scale multiplies every weight (1/sigma); cin_pad_to: the
+    // activation tensor's channel count when it is wider than Cin (zero channels appended).
+    int pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, int kh, int kw, double scale);
+};
+
+struct ConvArgs {
+    const float* in;    // channels-last [B][T][H][W][CinAct]
+    const float* wp;
+    const float* bias;
+    const float* res;   // channels-last [B][T/rt][H/rs][W/rs][Cout] or null
+    float* out;
+    int B, T, H, W;
+    int CinAct;         // channel stride of `in` (>= Cin of the weights)
+    int Cout, CoutPad, nchunk;
+    int KT, KH, KW;
+    int TB, TT, TH, TW;       // output brick handled by one workgroup (TB*TT*TH*TW == CONV_BM)
+    int nbB, nbT, nbH, nbW;   // bricks per dimension
+    int rt, rs;               // nearest-upsample factors applied when reading `res`
+    int epi;
+};
+
+// Chooses the brick and the tile variant and enqueues the kernel.
+int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
+                 int B, int T, int H, int W, int epi, hipStream_t st);
+
+}  // namespace i2v

@@ -1,0 +1,289 @@
+// Implicit-GEMM Conv3d / Conv2d / Linear on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the ATen/cuDNN convolutions reached by the reference through nn.Conv3d (decoder.py:14-18,81),
+// nn.Conv2d (normalization_layer.py:13-15) and nn.Linear (decoder.py:72, normalization_layer.py:44).
+//
+// GEMM view: Out[M = output positions (b,t,h,w)][N = Cout] = sum_{tap, c} In[pos + tap][c] * W[tap][c][n].
+// Activations are channels-last ([B][T][H][W][C]) so the K dimension (channels of one tap) is contiguous.
+//
+// One 256-thread workgroup (4 wavefronts, one per SIMD) computes a brick of 128 output positions
+// (TB x TT x TH x TW, chosen per layer so the halo stays small) times BN output channels:
+//   * per 16-channel K chunk the input halo brick is staged ONCE into LDS (rows of 16 floats padded to 20 so the
+//     ds_read_b128 fragment reads of 16 consecutive positions fall on distinct bank groups) and reused by all
+//     27 taps and all BN output channels;
+//   * the [BN][16] weight slab of each tap is double-buffered in LDS (next tap's global loads are issued before
+//     the current tap's MFMAs, written after them: one barrier per tap);
+//   * each wavefront owns WM x WN accumulator tiles of 32x32 (16 VGPRs each).  MFMA k-slot (s, half) of group g
+//     maps to channel 8g + 4*half + s, so one ds_read_b128 per operand feeds four MFMAs;
+//   * taps that can only see zero padding for the whole brick (T == 1 layers) are skipped;
+//   * epilogue: + bias, + residual read through the nearest-upsample index map (decoder.py:102-114 folded into
+//     the index math), optional leaky_relu(0.2), or tanh + [B][T][3][H][W] store for conv_img.
+#include "i2v_conv.h"
+
+namespace i2v {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
+    constexpr int BN = 32 * WN * WAVES_N;
+    constexpr int LS = CONV_LDS_STRIDE;
+    static_assert(32 * WM * WAVES_M == CONV_BM, "tile");
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int pt = a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
+    const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.TW + a.KW - 1;
+    const int NPOS = a.TB * HT * HH * HW;
+    const int ntaps = a.KT * a.KH * a.KW;
+
+    float* in_lds = smem;
+    float* w_lds = smem + NPOS * LS;
+    int* rowpos = reinterpret_cast<int*>(w_lds + 2 * BN * LS);
+    int* rowres = rowpos + CONV_BM;
+    int* taplist = rowres + CONV_BM;  // [0] = count, [1..] = valid taps
+
+    const int nNt = a.CoutPad / BN;
+    const int ntile = blockIdx.x % nNt;
+    int brick = blockIdx.x / nNt;
+    const int bw = brick % a.nbW; brick /= a.nbW;
+    const int bh = brick % a.nbH; brick /= a.nbH;
+    const int bt = brick % a.nbT; brick /= a.nbT;
+    const int bb = brick;
+    const int b0 = bb * a.TB, t0 = bt * a.TT, h0 = bh * a.TH, w0 = bw * a.TW;
+    const int n0 = ntile * BN;
+
+    if (tid < CONV_BM) {
+        int m = tid;
+        const int iw = m % a.TW; m /= a.TW;
+        const int ih = m % a.TH; m /= a.TH;
+        const int it = m % a.TT; m /= a.TT;
+        const int b = b0 + m, t = t0 + it, h = h0 + ih, w = w0 + iw;
+        const bool ok = b < a.B;
+        rowpos[tid] = ok ? ((b * a.T + t) * a.H + h) * a.W + w : -1;
+        rowres[tid] = ok ? ((b * (a.T / a.rt) + t / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs) + w / a.rs : 0;
+    }
+    if (tid == 0) {
+        int cnt = 0;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int dt = tap / (a.KH * a.KW);
+            const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
+            if (hi < 0 || lo >= a.T) continue;  // the whole brick reads zero padding for this tap
+            taplist[1 + cnt++] = tap;
+        }
+        taplist[0] = cnt;
+    }
+
+    // LDS float offset (tap (0,0,0), channel 4*half) of this lane's A rows
+    int aoff[WM];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm) {
+        int m = wave_m * (32 * WM) + 32 * wm + l31;
+        const int iw = m % a.TW; m /= a.TW;
+        const int ih = m % a.TH; m /= a.TH;
+        const int it = m % a.TT; m /= a.TT;
+        aoff[wm] = (((m * HT + it) * HH + ih) * HW + iw) * LS + 4 * half;
+    }
+    int boff[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) boff[wn] = (wave_n * (32 * WN) + 32 * wn + l31) * LS + 4 * half;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+
+    constexpr int WF4 = BN * 4;                  // float4 per weight slab
+    constexpr int WLD = (WF4 + 255) / 256;       // float4 per thread
+    const long slab = (long)a.CoutPad * CONV_KC;  // floats per (tap, chunk)
+    __syncthreads();
+    const int ntv = taplist[0];
+
+    for (int ch = 0; ch < a.nchunk; ++ch) {
+        __syncthreads();
+        // ---- stage the input halo brick for channels [16 ch, 16 ch + 16)
+        const int c0 = ch * CONV_KC;
+        for (int idx = tid; idx < NPOS * 4; idx += 256) {
+            const int q = idx & 3;
+            int p = idx >> 2;
+            const int iw = p % HW; p /= HW;
+            const int ih = p % HH; p /= HH;
+            const int it = p % HT; p /= HT;
+            const int b = b0 + p, t = t0 + it - pt, h = h0 + ih - ph, w = w0 + iw - pw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = c0 + 4 * q;
+            if (b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W &&
+                c < a.CinAct) {
+                v = *reinterpret_cast<const float4*>(a.in + ((((long)b * a.T + t) * a.H + h) * a.W + w) * a.CinAct + c);
+            }
+            *reinterpret_cast<float4*>(in_lds + (idx >> 2) * LS + 4 * q) = v;
+        }
+        if (ntv > 0) {
+            const float* src = a.wp + ((long)taplist[1] * a.nchunk + ch) * slab + (long)n0 * CONV_KC;
+#pragma unroll
+            for (int u = 0; u < WLD; ++u) {
+                const int f = tid + u * 256;
+                if (f < WF4) *reinterpret_cast<float4*>(w_lds + (f >> 2) * LS + 4 * (f & 3)) =
+                    *reinterpret_cast<const float4*>(src + f * 4);
+            }
+        }
+        __syncthreads();
+        for (int ti = 0; ti < ntv; ++ti) {
+            const int tap = taplist[1 + ti];
+            float4 wreg[WLD];
+            const bool more = ti + 1 < ntv;
+            if (more) {
+                const float* src = a.wp + ((long)taplist[2 + ti] * a.nchunk + ch) * slab + (long)n0 * CONV_KC;
+#pragma unroll
+                for (int u = 0; u < WLD; ++u) {
+                    const int f = tid + u * 256;
+                    if (f < WF4) wreg[u] = *reinterpret_cast<const float4*>(src + f * 4);
+                }
+            }
+            const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KW * a.KH);
+            const int tapoff = ((dt * HH + dh) * HW + dw) * LS;
+            const float* wb = w_lds + (ti & 1) * (BN * LS);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float4 av[WM], bv[WN];
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm) av[wm] = *reinterpret_cast<const float4*>(in_lds + aoff[wm] + tapoff + 8 * g);
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) bv[wn] = *reinterpret_cast<const float4*>(wb + boff[wn] + 8 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int wm = 0; wm < WM; ++wm) {
+                        const float as = s == 0 ? av[wm].x : s == 1 ? av[wm].y : s == 2 ? av[wm].z : av[wm].w;
+#pragma unroll
+                        for (int wn = 0; wn < WN; ++wn) {
+                            const float bs = s == 0 ? bv[wn].x : s == 1 ? bv[wn].y : s == 2 ? bv[wn].z : bv[wn].w;
+                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs, acc[wm][wn], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (more) {
+                float* wd = w_lds + ((ti + 1) & 1) * (BN * LS);
+#pragma unroll
+                for (int u = 0; u < WLD; ++u) {
+                    const int f = tid + u * 256;
+                    if (f < WF4) *reinterpret_cast<float4*>(wd + (f >> 2) * LS + 4 * (f & 3)) = wreg[u];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int HWo = a.H * a.W;
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const int n = n0 + wave_n * (32 * WN) + 32 * wn + l31;
+        if (n >= a.Cout) continue;
+        const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wave_m * (32 * WM) + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int p = rowpos[m];
+                if (p < 0) continue;
+                float v = acc[wm][wn][r] + bias;
+                if (a.res) v += a.res[(long)rowres[m] * a.Cout + n];
+                if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
+                if (a.epi & EPI_FRAMES) {
+                    const int bt_ = p / HWo, hw = p - bt_ * HWo;
+                    a.out[((long)bt_ * a.Cout + n) * HWo + hw] = tanhf(v);
+                } else {
+                    a.out[(long)p * a.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+int ConvWeights::pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, int kh, int kw, double scale) {
+    Cin = cin; Cout = cout; KT = kt; KH = kh; KW = kw;
+    CoutPad = (cout + 31) / 32 * 32;
+    if (CoutPad > 64 && CoutPad % 128) CoutPad = (CoutPad + 127) / 128 * 128;
+    nchunk = (cin + CONV_KC - 1) / CONV_KC;
+    const int ntaps = kt * kh * kw;
+    std::vector<float> p((size_t)ntaps * nchunk * CoutPad * CONV_KC, 0.f);
+    for (int n = 0; n < cout; ++n)
+        for (int c = 0; c < cin; ++c)
+            for (int tap = 0; tap < ntaps; ++tap) {
+                const double v = (double)w_src[((size_t)n * cin + c) * ntaps + tap] * scale;
+                p[(((size_t)tap * nchunk + c / CONV_KC) * CoutPad + n) * CONV_KC + c % CONV_KC] = (float)v;
+            }
+    int rc = w.upload(p.data(), p.size() * 4);
+    if (rc) return rc;
+    if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
+    bias.release();
+    return I2V_OK;
+}
+
+namespace {
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+int launch(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
+    auto kern = conv_mfma_f32_kernel<WAVES_M, WAVES_N, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    constexpr int BN = 32 * WN * WAVES_N;
+    const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
+    I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv: grid of %ld workgroups", nblk);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, a);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+}  // namespace
+
+int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
+                 int B, int T, int H, int W, int epi, hipStream_t st) {
+    I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv: weights not packed");
+    I2V_REQUIRE(cin_act % 4 == 0 && cin_act >= wts.Cin, I2V_E_INVALID, "conv: activation channels %d (weights %d)",
+                cin_act, wts.Cin);
+    ConvArgs a{};
+    a.in = in; a.wp = wts.w.as<float>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
+    a.B = B; a.T = T; a.H = H; a.W = W; a.CinAct = cin_act;
+    a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
+    a.KT = wts.KT; a.KH = wts.KH; a.KW = wts.KW;
+    a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
+    // brick: as cubic as the layer allows (small halo), remaining factor goes to the batch
+    int TW = W < 8 ? W : 8, TH = H < 8 ? H : 8;
+    int rem = CONV_BM / (TW * TH);
+    int TT = T < rem ? T : rem;
+    rem /= TT;
+    while (rem > 1 && W >= TW * 2) { TW *= 2; rem /= 2; }
+    while (rem > 1 && H >= TH * 2) { TH *= 2; rem /= 2; }
+    const int TB = rem;
+    I2V_REQUIRE(TB * TT * TH * TW == CONV_BM && T % TT == 0 && H % TH == 0 && W % TW == 0, I2V_E_INVALID,
+                "conv: cannot tile [T=%d,H=%d,W=%d] into bricks of %d positions (dims must be powers of two)", T, H, W,
+                CONV_BM);
+    a.TB = TB; a.TT = TT; a.TH = TH; a.TW = TW;
+    a.nbB = (B + TB - 1) / TB; a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;
+    const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * (TW + a.KW - 1);
+    const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
+    const size_t lds = ((size_t)npos * CONV_LDS_STRIDE + 2 * (size_t)BN * CONV_LDS_STRIDE) * 4 + (2 * CONV_BM + 32) * 4;
+    I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv: LDS %zu bytes exceeds 160 KiB", lds);
+    if (BN == 128) return launch<2, 2, 2, 2>(a, lds, st);
+    if (BN == 64) return launch<2, 2, 2, 1>(a, lds, st);
+    return launch<4, 1, 1, 1>(a, lds, st);
+}
+
+}  // namespace i2v

@@ -1,0 +1,567 @@
+// Stage-1 VAE decoder on gfx950: Generator.forward (reference: stage1_VAE/modules/decoder.py:97-120).
+//
+// All activations live channels-last ([B][T][H][W][C] fp32) in the caller's workspace.  Per GeneratorBlock
+// (decoder.py:33-52) the launch sequence is
+//   stats(x)                       per-(b,c) sum / sum-of-squares (fp64 accumulation, coalesced float4 rows)
+//   coef                           GroupNorm / InstanceNorm statistics folded with the ADAIN / affine parameters
+//                                  into one (A, B) pair per (b,c): norm(x)*g + beta == x*A + B
+//   resize + conv2d + conv2d       SPADE branch on the start frame (normalization_layer.py:20-23); gamma and beta
+//                                  come out of ONE 128 -> 2C implicit-GEMM conv, "+1" folded into the gamma bias
+//   modulate                       a0 = lrelu((x_up*A+B)*gamma' + beta): nearest upsample folded into the read index,
+//                                  gamma/beta broadcast over T instead of repeat_interleave'd (:22-23)
+//   conv3d 3x3x3 (MFMA)            dx = conv_0(a0)
+//   stats + coef + modulate        a1 = lrelu(ADAIN(dx, z))
+//   [coef + modulate + conv 1x1x1] learned shortcut, evaluated at the LOW resolution (1x1x1 conv and GroupNorm
+//                                  statistics commute with nearest upsampling)
+//   conv3d 3x3x3 (MFMA)            out = conv_1(a1) + shortcut (residual read through the upsample index map)
+// Spectral norm (W / sigma, signed sigma) is folded once at load time (decoder.py:20-25 recomputes it per call).
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "i2v_conv.h"
+
+namespace i2v {
+
+// ------------------------------------------------------------------------------------------------ statistics
+// x [B][P][C] -> sums[b][c] = (sum, sumsq) in fp64.  grid (chunks, B), block 256 = R rows x C4 float4 columns.
+__global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int P, int C,
+                                                    int rows_per_block) {
+    __shared__ double red[256][8];
+    const int C4 = C >> 2;
+    const int tid = threadIdx.x;
+    const int R = 256 / C4;            // rows handled concurrently (C4 <= 256)
+    const int col = tid % C4, r = tid / C4;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * rows_per_block;
+    const int p1 = min(P, p0 + rows_per_block);
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (r < R) {
+        const float* base = x + (long)b * P * C + 4 * col;
+        for (int p = p0 + r; p < p1; p += R) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)p * C);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[tid][j] = s[j]; red[tid][4 + j] = q[j]; }
+    __syncthreads();
+    if (r == 0) {
+        for (int rr = 1; rr < R; ++rr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += red[rr * C4 + col][j]; q[j] += red[rr * C4 + col][4 + j]; }
+        }
+        double* dst = sums + ((long)b * C + 4 * col) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(dst + 2 * j, s[j]);
+            atomicAdd(dst + 2 * j + 1, q[j]);
+        }
+    }
+}
+
+// (sum, sumsq) -> per-(b,c) affine (A, B) with norm(x)*gamma + beta == x*A + B.
+//   groups: number of normalisation groups (C for instance norm); count = elements per channel (T*H*W)
+//   gamma/beta sources: zl != null: ADAIN, gamma = zl[b][zoff + c], beta = zl[b][zoff + C + c] (normalization_layer.py:49-50)
+//                       gw != null: GroupNorm affine weight/bias per channel (normalization_layer.py:31)
+//                       neither: plain normalisation (Spade's GroupNorm(affine=False), :11)
+__global__ void coef_kernel(const double* __restrict__ sums, float2* __restrict__ coef, int C, int groups, double count,
+                            const float* __restrict__ zl, int zstride, int zoff, const float* __restrict__ gw,
+                            const float* __restrict__ gb) {
+    const int b = blockIdx.x;
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g0 = (c / cpg) * cpg;
+        double s = 0, q = 0;
+        for (int j = 0; j < cpg; ++j) {
+            s += sums[((long)b * C + g0 + j) * 2];
+            q += sums[((long)b * C + g0 + j) * 2 + 1];
+        }
+        const double n = count * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;  // biased variance, as F.group_norm / F.instance_norm
+        var = var > 0 ? var : 0;
+        const double rstd = 1.0 / sqrt(var + 1e-5);
+        double gamma = 1.0, beta = 0.0;
+        if (zl) { gamma = zl[(long)b * zstride + zoff + c]; beta = zl[(long)b * zstride + zoff + C + c]; }
+        else if (gw) { gamma = gw[c]; beta = gb[c]; }
+        coef[(long)b * C + c] = make_float2((float)(gamma * rstd), (float)(beta - gamma * mean * rstd));
+    }
+}
+
+// out[b][t][h][w][c] = act( (x[b][t/ut][h/us][w/us][c] * A + B) * gamma'[b][h][w][c] + beta[b][h][w][c] )
+//   gb: [B][H][W][2C] (gamma' = 1 + gamma in [0,C), beta in [C,2C)) or null
+__global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
+                                                       const float* __restrict__ gb, float* __restrict__ out, int B, int T,
+                                                       int H, int W, int C, int ut, int us, int lrelu) {
+    const int C4 = C >> 2;
+    const long total = (long)B * T * H * W * C4;
+    const int Tl = T / ut, Hl = H / us, Wl = W / us;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long p = i / C4;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H); p /= H;
+        const int t = (int)(p % T);
+        const int b = (int)(p / T);
+        const float4 v = *reinterpret_cast<const float4*>(
+            x + ((((long)b * Tl + t / ut) * Hl + h / us) * Wl + w / us) * C + 4 * c4);
+        const float4 ab0 = *reinterpret_cast<const float4*>(coef + (long)b * C + 4 * c4);      // (A0,B0,A1,B1)
+        const float4 ab1 = *reinterpret_cast<const float4*>(coef + (long)b * C + 4 * c4 + 2);  // (A2,B2,A3,B3)
+        float4 r;
+        r.x = fmaf(v.x, ab0.x, ab0.y); r.y = fmaf(v.y, ab0.z, ab0.w);
+        r.z = fmaf(v.z, ab1.x, ab1.y); r.w = fmaf(v.w, ab1.z, ab1.w);
+        if (gb) {
+            const float* g = gb + (((long)b * H + h) * W + w) * (2 * C) + 4 * c4;
+            const float4 ga = *reinterpret_cast<const float4*>(g);
+            const float4 be = *reinterpret_cast<const float4*>(g + C);
+            r.x = fmaf(r.x, ga.x, be.x); r.y = fmaf(r.y, ga.y, be.y);
+            r.z = fmaf(r.z, ga.z, be.z); r.w = fmaf(r.w, ga.w, be.w);
+        }
+        if (lrelu) {
+            r.x = r.x >= 0.f ? r.x : 0.2f * r.x; r.y = r.y >= 0.f ? r.y : 0.2f * r.y;
+            r.z = r.z >= 0.f ? r.z : 0.2f * r.z; r.w = r.w >= 0.f ? r.w : 0.2f * r.w;
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = r;
+    }
+}
+
+// F.interpolate(img, size=(h,w), mode='bilinear', align_corners=True) (normalization_layer.py:20), written
+// channels-last with the 3 colour channels zero-padded to 16 (the conv kernel's K chunk).
+__global__ void resize_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo) {
+    const long total = (long)B * Ho * Wo;
+    const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % Wo);
+        const int h = (int)((i / Wo) % Ho);
+        const int b = (int)(i / ((long)Wo * Ho));
+        const float fh = sh * h, fw = sw * w;
+        const int h0 = (int)fh, w0 = (int)fw;
+        const int h1 = h0 + (h0 < Hi - 1 ? 1 : 0), w1 = w0 + (w0 < Wi - 1 ? 1 : 0);
+        const float lh1 = fh - h0, lh0 = 1.f - lh1, lw1 = fw - w0, lw0 = 1.f - lw1;
+        float* o = out + i * 16;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* pl = img + ((long)b * 3 + c) * Hi * Wi;
+            o[c] = lh0 * (lw0 * pl[h0 * Wi + w0] + lw1 * pl[h0 * Wi + w1]) +
+                   lh1 * (lw0 * pl[h1 * Wi + w0] + lw1 * pl[h1 * Wi + w1]);
+        }
+#pragma unroll
+        for (int c = 3; c < 16; ++c) o[c] = 0.f;
+    }
+}
+
+}  // namespace i2v
+
+using namespace i2v;
+
+namespace {
+
+struct Block {
+    std::string name;
+    int n_in = 0, n_out = 0, n_mid = 0;
+    bool learned = false;
+    int groups_spade = 16;
+    ConvWeights conv0, conv1, convs, sp_conv, sp_gb;
+    DevBuf gn_w, gn_b;
+    int zoff = 0;  // offset of this block's ADAIN (gamma|beta) in the z-GEMM output
+};
+
+struct Level { int T, H, W, ut, us; };  // resolution a block runs at and the upsample factors in front of it
+
+}  // namespace
+
+struct i2v_dec {
+    i2v_dec_cfg cfg;
+    bool loaded = false;
+    int nf = 0;
+    Block blk[6];
+    Level lvl[6];
+    ConvWeights fc, zlin, conv_img;
+    int Nz = 0;
+    int profile = 0;
+    double prof_conv3_ms = 0, prof_conv3_flops = 0, prof_total_ms = 0;
+    // debug tap: copy one intermediate (channels-last) of one block out of the workspace during forward
+    int tap_block = -1, tap_which = -1;
+    float* tap_dst = nullptr;
+    size_t tap_max = 0;
+};
+
+namespace {
+
+struct DecWs {
+    size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, total;
+};
+
+DecWs dec_ws(const i2v_dec* d, int B) {
+    size_t mx_x = (size_t)16 * d->blk[0].n_in, mx_a = 0, mx_dx = 0, mx_xsin = 0, mx_xslow = 0, mx_y = 0, mx_gb = 0;
+    int cmax = 0;
+    for (int k = 0; k < 6; ++k) {
+        const Block& b = d->blk[k];
+        const Level& l = d->lvl[k];
+        const size_t P = (size_t)l.T * l.H * l.W, Pl = P / ((size_t)l.ut * l.us * l.us);
+        mx_x = std::max(mx_x, P * b.n_out);
+        mx_a = std::max(mx_a, P * std::max(b.n_in, b.n_mid));
+        mx_dx = std::max(mx_dx, P * b.n_mid);
+        if (b.learned) { mx_xsin = std::max(mx_xsin, Pl * b.n_in); mx_xslow = std::max(mx_xslow, Pl * b.n_out); }
+        mx_y = std::max(mx_y, (size_t)l.H * l.W);
+        mx_gb = std::max(mx_gb, (size_t)l.H * l.W * 2 * b.n_in);
+        cmax = std::max(cmax, std::max(b.n_in, b.n_mid));
+    }
+    DecWs L;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o = align_up(o + floats * 4, 256); return r; };
+    L.xA = take(B * mx_x); L.xB = take(B * mx_x);
+    L.a = take(B * mx_a); L.dx = take(B * mx_dx);
+    L.xs_in = take(B * mx_xsin); L.xs_low = take(B * mx_xslow);
+    L.y0 = take(B * mx_y * 16); L.y1 = take(B * mx_y * 128); L.gb = take(B * mx_gb);
+    L.zl = take((size_t)B * d->Nz);
+    L.sums1 = take((size_t)B * cmax * 4); L.sums2 = take((size_t)B * cmax * 4);  // doubles: 2 per channel
+    L.coef = take((size_t)B * cmax * 2);
+    L.total = o;
+    return L;
+}
+
+int run_stats(const float* x, double* sums, int B, long P, int C, hipStream_t st) {
+    I2V_REQUIRE(C % 4 == 0 && C / 4 <= 256, I2V_E_INVALID, "stats: unsupported channel count %d", C);
+    I2V_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)B * C * 16, st));
+    const int R = 256 / (C / 4);
+    long rows = R * 16;                       // at least 16 rows per thread-row
+    const long want = (P + 1023) / 1024;      // at most ~1024 chunks per sample
+    if (rows < want) rows = (want + R - 1) / R * R;
+    const int chunks = (int)((P + rows - 1) / rows);
+    hipLaunchKernelGGL(stats_kernel, dim3(chunks, B), dim3(256), 0, st, x, sums, (int)P, C, (int)rows);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+int run_coef(const double* sums, float* coef, int B, int C, int groups, double count, const float* zl, int zstride,
+             int zoff, const float* gw, const float* gb, hipStream_t st) {
+    hipLaunchKernelGGL(coef_kernel, dim3(B), dim3(256), 0, st, sums, reinterpret_cast<float2*>(coef), C, groups, count, zl,
+                       zstride, zoff, gw, gb);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+int run_modulate(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
+                 int us, int lrelu, hipStream_t st) {
+    const long total = (long)B * T * H * W * (C / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
+                       out, B, T, H, W, C, ut, us, lrelu);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+struct ProfScope {
+    i2v_dec* d;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double flops;
+    ProfScope(i2v_dec* d_, hipStream_t st_, double flops_) : d(d_), st(st_), flops(flops_) {
+        if (d->profile) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+    }
+    ~ProfScope() {
+        if (d->profile) {
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            d->prof_conv3_ms += ms;
+            d->prof_conv3_flops += flops;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+    }
+};
+
+int conv3(i2v_dec* d, const ConvWeights& w, const float* in, float* out, const float* res, int rt, int rs, int B,
+          const Level& l, int epi, hipStream_t st) {
+    ProfScope ps(d, st, 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0);
+    return conv_forward(w, in, w.Cin, out, res, rt, rs, B, l.T, l.H, l.W, epi, st);
+}
+
+int sn_pack(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, int k, bool has_bias,
+            ConvWeights& out) {
+    const int64_t numel = (int64_t)cout * cin * k * k * k;
+    const float* bias = nullptr;
+    if (has_bias) { bias = sd.f32(name + ".bias", cout); if (!bias) return I2V_E_MISSING; }
+    if (!spectral) {
+        const float* w = sd.f32(name + ".weight", numel);
+        if (!w) return I2V_E_MISSING;
+        return out.pack(w, bias, cout, cin, k, k, k, 1.0);
+    }
+    const int64_t kk = (int64_t)cin * k * k * k;
+    const float* w = sd.f32(name + ".weight_orig", numel);
+    const float* u = sd.f32(name + ".weight_u", cout);
+    const float* v = sd.f32(name + ".weight_v", kk);
+    if (!w || !u || !v) return I2V_E_MISSING;
+    // sigma = u . (W_mat v), W_mat = weight_orig.reshape(Cout, -1); signed, no abs (torch spectral_norm, eval mode)
+    double sigma = 0.0;
+    for (int n = 0; n < cout; ++n) {
+        double r = 0.0;
+        const float* row = w + (size_t)n * kk;
+        for (int64_t j = 0; j < kk; ++j) r += (double)row[j] * v[j];
+        sigma += r * u[n];
+    }
+    I2V_REQUIRE(sigma != 0.0 && std::isfinite(sigma), I2V_E_INVALID, "spectral norm sigma of %s is %g", name.c_str(), sigma);
+    return out.pack(w, bias, cout, cin, k, k, k, 1.0 / sigma);
+}
+
+}  // namespace
+
+extern "C" {
+
+int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
+    I2V_REQUIRE(cfg && out, I2V_E_INVALID, "i2v_dec_create: null argument");
+    I2V_REQUIRE(cfg->channel_factor > 0 && cfg->channel_factor % 8 == 0, I2V_E_INVALID,
+                "i2v_dec_create: channel_factor must be a multiple of 8 (Norm3D uses 16 groups), got %d", cfg->channel_factor);
+    I2V_REQUIRE(cfg->channel_factor * 16 <= 1024, I2V_E_INVALID, "i2v_dec_create: channel_factor %d too large", cfg->channel_factor);
+    I2V_REQUIRE(cfg->z_dim > 0 && cfg->z_dim % 4 == 0, I2V_E_INVALID, "i2v_dec_create: z_dim must be a multiple of 4");
+    for (int i = 0; i < 2; ++i) {
+        const int s = cfg->upsample_s[i], t = cfg->upsample_t[i];
+        I2V_REQUIRE((s == 1 || s == 2 || s == 4) && (t == 1 || t == 2 || t == 4), I2V_E_INVALID,
+                    "i2v_dec_create: upsample factors must be 1, 2 or 4");
+    }
+    I2V_REQUIRE(cfg->mma == 0, I2V_E_INVALID, "i2v_dec_create: mma mode %d not available in this build", cfg->mma);
+    int ndev = 0;
+    I2V_HIP_CHECK(hipGetDeviceCount(&ndev));
+    I2V_REQUIRE(ndev > 0, I2V_E_HIP, "i2v_dec_create: no HIP device");
+    auto d = std::make_unique<i2v_dec>();
+    d->cfg = *cfg;
+    const int nf = d->nf = cfg->channel_factor;
+    const char* names[6] = {"head_0", "g_0", "g_1", "g_2", "g_3", "g_4"};
+    const int cin[6] = {16, 16, 16, 8, 4, 2}, cout[6] = {16, 16, 8, 4, 2, 1};
+    int T = 1, S = 4, zoff = 0;
+    for (int k = 0; k < 6; ++k) {
+        Block& b = d->blk[k];
+        b.name = names[k];
+        b.n_in = cin[k] * nf; b.n_out = cout[k] * nf; b.n_mid = std::min(b.n_in, b.n_out);
+        b.learned = b.n_in != b.n_out;
+        int g = 16;
+        while (b.n_in % g) --g;  // normalization_layer.py:9-10
+        b.groups_spade = g;
+        b.zoff = zoff;
+        zoff += 2 * b.n_mid;
+        int ut = 1, us = 1;
+        if (k >= 1 && k <= 3) { ut = 2; us = 2; }                                  // decoder.py:102-108
+        if (k == 4) { ut = cfg->upsample_t[0]; us = cfg->upsample_s[0]; }          // :111
+        if (k == 5) { ut = cfg->upsample_t[1]; us = cfg->upsample_s[1]; }          // :114
+        T *= ut; S *= us;
+        d->lvl[k] = Level{T, S, S, ut, us};
+    }
+    d->Nz = zoff;
+    *out = d.release();
+    return I2V_OK;
+}
+
+void i2v_dec_destroy(i2v_dec* d) { delete d; }
+
+int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
+    I2V_REQUIRE(d && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_dec_load: null argument");
+    StateDict sd(tensors, n_tensors);
+    const int nf = d->nf, zd = d->cfg.z_dim;
+    const bool sn = d->cfg.spectral_norm != 0;
+    int rc;
+    {   // fc: Linear(z_dim, 4*4*16nf) (decoder.py:72); rows permuted so the output is channels-last [h][w][c]
+        const int C = 16 * nf;
+        const float* w = sd.f32("fc.weight", (int64_t)16 * C * zd);
+        const float* b = sd.f32("fc.bias", (int64_t)16 * C);
+        if (!w || !b) return I2V_E_MISSING;
+        std::vector<float> wp((size_t)16 * C * zd), bp((size_t)16 * C);
+        for (int c = 0; c < C; ++c)
+            for (int hw = 0; hw < 16; ++hw) {
+                std::memcpy(&wp[((size_t)hw * C + c) * zd], w + ((size_t)c * 16 + hw) * zd, (size_t)zd * 4);
+                bp[(size_t)hw * C + c] = b[(size_t)c * 16 + hw];
+            }
+        if ((rc = d->fc.pack(wp.data(), bp.data(), 16 * C, zd, 1, 1, 1, 1.0))) return rc;
+    }
+    std::vector<float> zw((size_t)d->Nz * zd), zb((size_t)d->Nz);
+    for (int k = 0; k < 6; ++k) {
+        Block& b = d->blk[k];
+        const std::string p = b.name + ".";
+        if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
+        if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
+        if (b.learned) {
+            if ((rc = sn_pack(sd, p + "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs))) return rc;
+            const float* gw = sd.f32(p + "norm_s.bn.weight", b.n_in);
+            const float* gb = sd.f32(p + "norm_s.bn.bias", b.n_in);
+            if (!gw || !gb) return I2V_E_MISSING;
+            if ((rc = b.gn_w.upload(gw, (size_t)b.n_in * 4))) return rc;
+            if ((rc = b.gn_b.upload(gb, (size_t)b.n_in * 4))) return rc;
+        }
+        // Spade: Conv2d(3,128,3) then conv_gamma | conv_beta fused as one Conv2d(128, 2C, 3)
+        const float* w1 = sd.f32(p + "norm_0.conv.weight", 128 * 3 * 9);
+        const float* b1 = sd.f32(p + "norm_0.conv.bias", 128);
+        const float* wg = sd.f32(p + "norm_0.conv_gamma.weight", (int64_t)b.n_in * 128 * 9);
+        const float* bg = sd.f32(p + "norm_0.conv_gamma.bias", b.n_in);
+        const float* wb = sd.f32(p + "norm_0.conv_beta.weight", (int64_t)b.n_in * 128 * 9);
+        const float* bb = sd.f32(p + "norm_0.conv_beta.bias", b.n_in);
+        if (!w1 || !b1 || !wg || !bg || !wb || !bb) return I2V_E_MISSING;
+        if ((rc = b.sp_conv.pack(w1, b1, 128, 3, 1, 3, 3, 1.0))) return rc;
+        std::vector<float> wgb((size_t)2 * b.n_in * 128 * 9), bgb((size_t)2 * b.n_in);
+        std::memcpy(wgb.data(), wg, (size_t)b.n_in * 128 * 9 * 4);
+        std::memcpy(wgb.data() + (size_t)b.n_in * 128 * 9, wb, (size_t)b.n_in * 128 * 9 * 4);
+        for (int c = 0; c < b.n_in; ++c) { bgb[c] = bg[c] + 1.0f; bgb[b.n_in + c] = bb[c]; }  // normalized*(1+gamma)+beta
+        if ((rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0))) return rc;
+        // ADAIN linear rows into the shared z-GEMM
+        const float* lw = sd.f32(p + "norm_1.linear.weight", (int64_t)2 * b.n_mid * zd);
+        const float* lb = sd.f32(p + "norm_1.linear.bias", (int64_t)2 * b.n_mid);
+        if (!lw || !lb) return I2V_E_MISSING;
+        std::memcpy(&zw[(size_t)b.zoff * zd], lw, (size_t)2 * b.n_mid * zd * 4);
+        std::memcpy(&zb[b.zoff], lb, (size_t)2 * b.n_mid * 4);
+    }
+    if ((rc = d->zlin.pack(zw.data(), zb.data(), d->Nz, zd, 1, 1, 1, 1.0))) return rc;
+    {
+        const float* w = sd.f32("conv_img.weight", (int64_t)3 * nf * 27);
+        const float* b = sd.f32("conv_img.bias", 3);
+        if (!w || !b) return I2V_E_MISSING;
+        if ((rc = d->conv_img.pack(w, b, 3, nf, 3, 3, 3, 1.0))) return rc;
+    }
+    d->loaded = true;
+    return I2V_OK;
+}
+
+int i2v_dec_out_shape(const i2v_dec* d, int32_t* t, int32_t* h, int32_t* w) {
+    I2V_REQUIRE(d && t && h && w, I2V_E_INVALID, "i2v_dec_out_shape: null argument");
+    *t = d->lvl[5].T; *h = d->lvl[5].H; *w = d->lvl[5].W;
+    return I2V_OK;
+}
+
+size_t i2v_dec_workspace_bytes(const i2v_dec* d, int32_t batch, int32_t img_h, int32_t img_w) {
+    (void)img_h; (void)img_w;
+    if (!d || batch <= 0) return 0;
+    return dec_ws(d, batch).total;
+}
+
+double i2v_dec_flops_per_sample(const i2v_dec* d, int32_t img_h, int32_t img_w) {
+    (void)img_h; (void)img_w;
+    if (!d) return 0.0;
+    double f = 2.0 * d->cfg.z_dim * (16.0 * 16 * d->nf + d->Nz);
+    for (int k = 0; k < 6; ++k) {
+        const Block& b = d->blk[k];
+        const Level& l = d->lvl[k];
+        const double P = (double)l.T * l.H * l.W, HW = (double)l.H * l.W;
+        f += 2.0 * P * 27.0 * ((double)b.n_in * b.n_mid + (double)b.n_mid * b.n_out);
+        if (b.learned) f += 2.0 * P * (double)b.n_in * b.n_out;  // counted at output resolution, as the reference runs it
+        f += 2.0 * HW * 9.0 * (3.0 * 128 + 128.0 * 2 * b.n_in);
+    }
+    const Level& l = d->lvl[5];
+    f += 2.0 * l.T * l.H * l.W * 27.0 * d->nf * 3;
+    return f;
+}
+
+int i2v_dec_set_profile(i2v_dec* d, int32_t on) {
+    I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_set_profile: null");
+    d->profile = on;
+    return I2V_OK;
+}
+
+int i2v_dec_debug_tap(i2v_dec* d, int32_t block, int32_t which, float* dst, size_t max_floats) {
+    I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_debug_tap: null");
+    d->tap_block = block; d->tap_which = which; d->tap_dst = dst; d->tap_max = max_floats;
+    return I2V_OK;
+}
+
+int i2v_dec_get_profile(const i2v_dec* d, double* conv3_ms, double* conv3_flops, double* total_ms) {
+    I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_get_profile: null");
+    if (conv3_ms) *conv3_ms = d->prof_conv3_ms;
+    if (conv3_flops) *conv3_flops = d->prof_conv3_flops;
+    if (total_ms) *total_ms = d->prof_total_ms;
+    return I2V_OK;
+}
+
+int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, const float* motion, float* out,
+                    void* workspace, size_t workspace_bytes, int32_t batch, void* stream) {
+    I2V_REQUIRE(d && d->loaded, I2V_E_STATE, "i2v_dec_forward: weights not loaded");
+    I2V_REQUIRE(img && motion && out && workspace && batch > 0 && img_h > 0 && img_w > 0, I2V_E_INVALID,
+                "i2v_dec_forward: null argument or bad size");
+    const int B = batch;
+    const DecWs L = dec_ws(d, B);
+    I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_dec_forward: workspace %zu < required %zu", workspace_bytes,
+                L.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    float *xA = F(L.xA), *xB = F(L.xB), *a = F(L.a), *dx = F(L.dx), *xs_in = F(L.xs_in), *xs_low = F(L.xs_low);
+    float *y0 = F(L.y0), *y1 = F(L.y1), *gb = F(L.gb), *zl = F(L.zl), *coef = F(L.coef);
+    double* sums1 = reinterpret_cast<double*>(ws + L.sums1);
+    double* sums2 = reinterpret_cast<double*>(ws + L.sums2);
+    int rc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (d->profile) {
+        d->prof_conv3_ms = d->prof_conv3_flops = d->prof_total_ms = 0;
+        I2V_HIP_CHECK(hipEventCreate(&ev0));
+        I2V_HIP_CHECK(hipEventCreate(&ev1));
+        I2V_HIP_CHECK(hipEventRecord(ev0, st));
+    }
+    // x = fc(motion).reshape(B, 16nf, 1, 4, 4) (decoder.py:99) -- written channels-last [B][1][4][4][16nf]
+    if ((rc = conv_forward(d->fc, motion, d->cfg.z_dim, xA, nullptr, 1, 1, B, 1, 1, 1, EPI_NONE, st))) return rc;
+    // all six ADAIN Linear(z_dim, 2C) in one GEMM (they depend only on z)
+    if ((rc = conv_forward(d->zlin, motion, d->cfg.z_dim, zl, nullptr, 1, 1, B, 1, 1, 1, EPI_NONE, st))) return rc;
+    float* x = xA;
+    float* xn = xB;
+    auto tap = [&](int k, int which, const float* src, size_t count) -> int {
+        if (d->tap_dst && d->tap_block == k && d->tap_which == which)
+            I2V_HIP_CHECK(hipMemcpyAsync(d->tap_dst, src, std::min(count, d->tap_max) * 4, hipMemcpyDeviceToDevice, st));
+        return I2V_OK;
+    };
+    for (int k = 0; k < 6; ++k) {
+        Block& b = d->blk[k];
+        const Level& l = d->lvl[k];
+        const int Tl = l.T / l.ut, Hl = l.H / l.us, Wl = l.W / l.us;
+        const long Pl = (long)Tl * Hl * Wl, P = (long)l.T * l.H * l.W;
+        // GroupNorm statistics of the (virtually upsampled) block input == statistics of the low-res tensor
+        if ((rc = run_stats(x, sums1, B, Pl, b.n_in, st))) return rc;
+        if ((rc = run_coef(sums1, coef, B, b.n_in, b.groups_spade, (double)Pl, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
+        // SPADE branch (normalization_layer.py:20-23)
+        {
+            const long tot = (long)B * l.H * l.W;
+            hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, y0,
+                               B, img_h, img_w, l.H, l.W);
+            I2V_HIP_CHECK(hipGetLastError());
+        }
+        if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
+        if ((rc = conv_forward(b.sp_gb, y1, 128, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
+        if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
+        if ((rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st))) return rc;
+        if ((rc = tap(k, 1, a, (size_t)B * P * b.n_in))) return rc;
+        if ((rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st))) return rc;
+        if ((rc = tap(k, 2, dx, (size_t)B * P * b.n_mid))) return rc;
+        // ADAIN (normalization_layer.py:47-51) + leaky_relu
+        if ((rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
+        if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, d->Nz, b.zoff, nullptr, nullptr, st))) return rc;
+        if ((rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st))) return rc;
+        if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
+        // shortcut (decoder.py:44-49) at low resolution
+        const float* res = x;
+        if (b.learned) {
+            if ((rc = run_coef(sums1, coef, B, b.n_in, 16, (double)Pl, nullptr, 0, 0, b.gn_w.as<float>(), b.gn_b.as<float>(), st)))
+                return rc;
+            if ((rc = run_modulate(x, coef, nullptr, xs_in, B, Tl, Hl, Wl, b.n_in, 1, 1, 0, st))) return rc;
+            if ((rc = conv_forward(b.convs, xs_in, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, st))) return rc;
+            res = xs_low;
+            if ((rc = tap(k, 4, xs_low, (size_t)B * Pl * b.n_out))) return rc;
+        }
+        // g_4's output only feeds conv_img(leaky_relu(x)) (decoder.py:117): fuse the activation here
+        if ((rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st))) return rc;
+        if ((rc = tap(k, 5, xn, (size_t)B * P * b.n_out))) return rc;
+        std::swap(x, xn);
+    }
+    if ((rc = conv3(d, d->conv_img, x, out, nullptr, 1, 1, B, d->lvl[5], EPI_FRAMES, st))) return rc;
+    if (d->profile) {
+        I2V_HIP_CHECK(hipEventRecord(ev1, st));
+        I2V_HIP_CHECK(hipEventSynchronize(ev1));
+        float ms = 0;
+        I2V_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        d->prof_total_ms = ms;
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+    return I2V_OK;
+}
+
+}  // extern "C"

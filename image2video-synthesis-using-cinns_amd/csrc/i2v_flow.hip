@@ -1,0 +1,448 @@
+// cINN flow on gfx950: ConditionalFlow forward / inverse (reference: stage2_cINN/modules/flow_blocks.py).
+//
+// The flow is a FLAT vector flow on z in R^{B x 64}: 20 blocks x 2 coupling half-steps, each half-step
+// evaluating an s-net and a t-net (4 Linear layers each, hidden 512).  Per pass all 47-50 M parameters are
+// read exactly once (189-200 MB fp32): the pass is bound by weight streaming and by the 160-deep chain of
+// dependent layers, not by arithmetic (DESIGN.md "cINN pass").
+//
+// Data layout in HBM
+//   x state      [B][64]      one wavefront (64 lanes) owns one sample: lane == channel
+//   activations  [2H][B]      row n = net*H + j (net 0 = s, 1 = t), batch contiguous -> lane == sample,
+//                             every load/store of the N-split layer kernels is a coalesced 256-B row segment
+//   weights      torch layout [N][K] rows (K contiguous): a workgroup's rows are wave-uniform -> scalar loads;
+//                the s- and t-net of a half-step are stored back to back so one launch covers both.
+//   W3T          [H][64]      last layer transposed: lane == (net, channel), coalesced
+//
+// Kernels
+//   flow_linear_kernel : out[n][b] = act(bias + sum_k W[n][k] * in[k][b]); N split over workgroups, K over the
+//                        waves of a workgroup (LDS reduce).  Used for the embedding pre-GEMM of all 80 first
+//                        layers (one launch, off the dependent chain), and for layers 0..2 of every half-step.
+//   flow_tail_kernel   : one workgroup per sample: last Linear (H -> 32, s and t), affine coupling
+//                        x*exp(s)+t / (x-t)*exp(-s) (flow_blocks.py:91,103), log-det = sum_c s by a wavefront
+//                        shuffle reduction (:93), then the elementwise ops between two half-steps (Shuffle gather
+//                        as a lane permute :152-154, ActNorm modules.py:80/100, InvLeakyRelu :180-187, half swap).
+#include "i2v_common.h"
+#include "i2v_linear.h"
+
+#include <cmath>
+#include <memory>
+
+namespace i2v {
+
+struct TailArgs {
+    const float* h;    // [2H][B] output of the last hidden layer, or null (no coupling in this launch)
+    const float* W3T;  // [H][64]
+    const float* b3;   // [64]
+    float* x;          // [B][64] state, updated in place
+    float* logdet;     // [B] or null
+    int H, B;
+    int reverse;
+    // elementwise ops applied after the coupling, before the next half-step's first layer
+    const int* shuf;       // [64] gather indices or null
+    const float* an_loc;   // [64] or null
+    const float* an_scale; // [64]
+    float an_logdet;       // sum log|scale| of that ActNorm (forward only)
+    int do_lrelu;
+    int do_swap;
+};
+
+__global__ __launch_bounds__(256) void flow_tail_kernel(TailArgs a) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    if (a.h) {
+        // last Linear: lane = (net, c); 4 waves split K = H
+        const int net = lane >> 5;
+        const int kc = a.H / 4;
+        const float* hp = a.h + ((long)net * a.H + (long)w * kc) * a.B + b;
+        const float* wp = a.W3T + (long)w * kc * 64 + lane;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < kc; ++k) acc = fmaf(hp[(long)k * a.B], wp[k * 64], acc);
+        part[w][lane] = acc;
+    }
+    __syncthreads();
+    if (w != 0) return;
+    float x = a.x[(long)b * 64 + lane];
+    if (a.h) {
+        const float st = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] + a.b3[lane];
+        // lanes 0..31 hold s[c], lanes 32..63 hold t[c]; the transformed half is x[32..63]
+        const float s = __shfl(st, lane & 31);
+        if (lane >= 32) x = a.reverse ? (x - st) * expf(-s) : fmaf(x, expf(s), st);
+        if (a.logdet && !a.reverse) {
+            float r = lane < 32 ? st : 0.f;  // log-det of the coupling: sum over the 32 channels of s
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off);
+            if (lane == 0) a.logdet[b] += r;
+        }
+    }
+    if (!a.reverse) {
+        if (a.shuf) x = __shfl(x, a.shuf[lane]);            // Shuffle.forward: x[:, idx]
+        if (a.an_loc) {                                     // ActNorm.forward: scale * (x + loc)
+            x = a.an_scale[lane] * (x + a.an_loc[lane]);
+            if (a.logdet && lane == 0) a.logdet[b] += a.an_logdet;
+        }
+        if (a.do_lrelu) x = x * (x >= 0.f ? 1.0f : 0.9f);   // InvLeakyRelu.forward (log-det reported as 0, quirk Q2)
+    } else {
+        if (a.do_lrelu) x = x / (x >= 0.f ? 1.0f : 0.9f);   // InvLeakyRelu.reverse
+        if (a.an_loc) x = x / a.an_scale[lane] - a.an_loc[lane];  // ActNorm.reverse
+        if (a.shuf) x = __shfl(x, a.shuf[lane]);            // Shuffle.reverse: x[:, argsort(idx)]
+    }
+    if (a.do_swap) x = __shfl(x, lane ^ 32);                // chunk / cat[::-1], flow_blocks.py:86,99
+    a.x[(long)b * 64 + lane] = x;
+}
+
+}  // namespace i2v
+
+using namespace i2v;
+
+struct i2v_flow {
+    i2v_flow_cfg cfg;
+    int device = 0;
+    bool loaded = false;
+    int S = 0;      // half-steps = 2 * n_flows
+    int H = 0, E = 0, ld0 = 0, depth = 0;
+    DevBuf W0, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;
+    std::vector<float> an_logdet;
+    std::vector<int> step_cond;  // 1: first layer sees only the embedding (mode 'cond')
+    size_t param_bytes = 0;
+    // graph cache
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int g_reverse = -1, g_B = -1;
+    void* g_ws = nullptr;
+
+    ~i2v_flow() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    }
+};
+
+namespace {
+
+struct WsLayout {
+    size_t x, embed, logdet, pre, hA, hB, total;
+};
+
+WsLayout ws_layout(const i2v_flow* f, int B) {
+    WsLayout L;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, 256); return r; };
+    L.x = take((size_t)B * 64 * 4);
+    L.embed = take((size_t)B * f->E * 4);
+    L.logdet = take((size_t)B * 4);
+    L.pre = take((size_t)f->S * 2 * f->H * B * 4);
+    L.hA = take((size_t)2 * f->H * B * 4);
+    L.hB = take((size_t)2 * f->H * B * 4);
+    L.total = o;
+    return L;
+}
+
+// The launch chain of one pass on `st`, reading/writing only workspace memory.
+int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
+    const WsLayout L = ws_layout(f, B);
+    float* x = reinterpret_cast<float*>(ws + L.x);
+    const float* embed = reinterpret_cast<const float*>(ws + L.embed);
+    float* logdet = reinterpret_cast<float*>(ws + L.logdet);
+    float* pre = reinterpret_cast<float*>(ws + L.pre);
+    float* hA = reinterpret_cast<float*>(ws + L.hA);
+    float* hB = reinterpret_cast<float*>(ws + L.hB);
+    const int H = f->H, N2 = 2 * f->H, S = f->S;
+    const bool act = f->cfg.activation != 0, an = !f->cfg.skip_actnorm, sh = !f->cfg.skip_shuffle;
+
+    if (!reverse) I2V_HIP_CHECK(hipMemsetAsync(logdet, 0, (size_t)B * 4, st));
+    {   // embedding part of every first layer, all half-steps at once: pre[s][n][b] = b0 + W0[:, 32:] . embed
+        LinArgs a{};
+        a.W = f->W0.as<float>() + 32;
+        a.ldw = f->ld0;
+        a.K = f->E;
+        a.in = embed;
+        a.in_sk = 1;
+        a.in_sb = f->E;
+        a.in_group_stride = 0;
+        a.group_rows = S * N2;
+        a.bias_vec = f->b0.as<float>();
+        a.bias_mat = nullptr;
+        a.out = pre;
+        a.out_sn = B;
+        a.out_sb = 1;
+        a.N = S * N2;
+        a.B = B;
+        a.slope = 1.0f;
+        int rc = launch_linear<8, 4>(a, st);
+        if (rc) return rc;
+    }
+    auto tail = [&](const float* h, int step, int shuf_block, int an_block, bool lrelu, bool swap) -> int {
+        TailArgs t{};
+        t.h = h;
+        t.W3T = h ? f->W3T.as<float>() + (size_t)step * H * 64 : nullptr;
+        t.b3 = h ? f->b3.as<float>() + (size_t)step * 64 : nullptr;
+        t.x = x;
+        t.logdet = reverse ? nullptr : logdet;
+        t.H = H;
+        t.B = B;
+        t.reverse = reverse ? 1 : 0;
+        t.shuf = shuf_block >= 0 ? (reverse ? f->shuf_b.as<int>() : f->shuf_f.as<int>()) + shuf_block * 64 : nullptr;
+        t.an_loc = an_block >= 0 ? f->an_loc.as<float>() + an_block * 64 : nullptr;
+        t.an_scale = an_block >= 0 ? f->an_scale.as<float>() + an_block * 64 : nullptr;
+        t.an_logdet = an_block >= 0 ? f->an_logdet[an_block] : 0.f;
+        t.do_lrelu = lrelu ? 1 : 0;
+        t.do_swap = swap ? 1 : 0;
+        hipLaunchKernelGGL(flow_tail_kernel, dim3(B), dim3(256), 0, st, t);
+        I2V_HIP_CHECK(hipGetLastError());
+        return I2V_OK;
+    };
+    const int nf = f->cfg.n_flows;
+    // ops in front of the first half-step
+    int rc;
+    if (!reverse) rc = tail(nullptr, 0, -1, an ? 0 : -1, act, false);
+    else rc = tail(nullptr, 0, sh ? nf - 1 : -1, -1, false, false);
+    if (rc) return rc;
+
+    for (int it = 0; it < S; ++it) {
+        // forward visits (fl, i) = (0,0),(0,1),(1,0)...; reverse visits (nf-1,1),(nf-1,0),(nf-2,1)...
+        const int fl = reverse ? nf - 1 - it / 2 : it / 2;
+        const int i = reverse ? 1 - it % 2 : it % 2;
+        const int step = fl * 2 + i;
+        // layer 0: K = 32 state channels (+ the precomputed embedding part as a per-(n,b) bias)
+        LinArgs a{};
+        a.W = f->W0.as<float>() + (size_t)step * N2 * f->ld0;
+        a.ldw = f->ld0;
+        a.K = f->step_cond[step] ? 0 : 32;
+        a.in = x;
+        a.in_sk = 1;
+        a.in_sb = 64;
+        a.in_group_stride = 0;
+        a.group_rows = N2;
+        a.bias_vec = nullptr;
+        a.bias_mat = pre + (size_t)step * N2 * B;
+        a.out = hA;
+        a.out_sn = B;
+        a.out_sb = 1;
+        a.N = N2;
+        a.B = B;
+        a.slope = 0.01f;  // nn.LeakyReLU() default, modules.py:17
+        if ((rc = launch_linear<4, 4>(a, st))) return rc;
+        float* cur = hA;
+        float* nxt = hB;
+        for (int d = 0; d < f->depth; ++d) {
+            LinArgs m{};
+            m.W = f->Wmid.as<float>() + ((size_t)step * f->depth + d) * N2 * H;
+            m.ldw = H;
+            m.K = H;
+            m.in = cur;
+            m.in_sk = B;
+            m.in_sb = 1;
+            m.in_group_stride = (long)H * B;
+            m.group_rows = H;
+            m.bias_vec = f->bmid.as<float>() + ((size_t)step * f->depth + d) * N2;
+            m.bias_mat = nullptr;
+            m.out = nxt;
+            m.out_sn = B;
+            m.out_sb = 1;
+            m.N = N2;
+            m.B = B;
+            m.slope = 0.01f;
+            if ((rc = launch_linear<4, 4>(m, st))) return rc;
+            std::swap(cur, nxt);
+        }
+        // last layer + coupling + the ops up to the next half-step's first layer
+        int shuf_block = -1, an_block = -1;
+        bool lrelu = false, swap = false;
+        if (!reverse) {
+            if (i == 0) swap = true;  // before half-step 1: cat(chunk[::-1])
+            else {
+                if (sh) shuf_block = fl;
+                if (fl + 1 < nf) { if (an) an_block = fl + 1; lrelu = act; }
+            }
+        } else {
+            if (i == 1) swap = true;  // before half-step 0 (flow_blocks.py:98-99)
+            else {
+                lrelu = act;
+                if (an) an_block = fl;
+                if (fl - 1 >= 0 && sh) shuf_block = fl - 1;
+            }
+        }
+        if ((rc = tail(cur, step, shuf_block, an_block, lrelu, swap))) return rc;
+    }
+    return I2V_OK;
+}
+
+int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, float* xout, float* logdet,
+             void* workspace, size_t workspace_bytes, int B, hipStream_t st) {
+    I2V_REQUIRE(f && f->loaded, I2V_E_STATE, "i2v_flow: weights not loaded");
+    I2V_REQUIRE(B > 0 && xin && embed && xout && workspace, I2V_E_INVALID, "i2v_flow: null argument or batch <= 0");
+    const WsLayout L = ws_layout(f, B);
+    I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_flow: workspace %zu < required %zu",
+                workspace_bytes, L.total);
+    char* ws = static_cast<char*>(workspace);
+    I2V_HIP_CHECK(hipMemcpyAsync(ws + L.x, xin, (size_t)B * 64 * 4, hipMemcpyDeviceToDevice, st));
+    I2V_HIP_CHECK(hipMemcpyAsync(ws + L.embed, embed, (size_t)B * f->E * 4, hipMemcpyDeviceToDevice, st));
+    if (f->cfg.use_graph) {
+        if (!(f->gexec && f->g_reverse == (int)reverse && f->g_B == B && f->g_ws == workspace)) {
+            if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
+            if (!f->cap_stream) I2V_HIP_CHECK(hipStreamCreateWithFlags(&f->cap_stream, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            I2V_HIP_CHECK(hipStreamBeginCapture(f->cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_chain(f, reverse, ws, B, f->cap_stream);
+            hipError_t e = hipStreamEndCapture(f->cap_stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            I2V_HIP_CHECK(e);
+            e = hipGraphInstantiate(&f->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            I2V_HIP_CHECK(e);
+            f->g_reverse = reverse;
+            f->g_B = B;
+            f->g_ws = workspace;
+        }
+        I2V_HIP_CHECK(hipGraphLaunch(f->gexec, st));
+    } else {
+        int rc = enqueue_chain(f, reverse, ws, B, st);
+        if (rc) return rc;
+    }
+    I2V_HIP_CHECK(hipMemcpyAsync(xout, ws + L.x, (size_t)B * 64 * 4, hipMemcpyDeviceToDevice, st));
+    if (logdet) I2V_HIP_CHECK(hipMemcpyAsync(logdet, ws + L.logdet, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    return I2V_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out) {
+    I2V_REQUIRE(cfg && out, I2V_E_INVALID, "i2v_flow_create: null argument");
+    I2V_REQUIRE(cfg->in_channels == 64, I2V_E_INVALID,
+                "i2v_flow_create: in_channels must be 64 (lane <-> channel mapping), got %d", cfg->in_channels);
+    I2V_REQUIRE(cfg->hidden_dim >= 64 && cfg->hidden_dim % 64 == 0, I2V_E_INVALID,
+                "i2v_flow_create: hidden_dim must be a positive multiple of 64, got %d", cfg->hidden_dim);
+    I2V_REQUIRE(cfg->embedding_dim > 0 && cfg->hidden_depth >= 0 && cfg->n_flows > 0, I2V_E_INVALID,
+                "i2v_flow_create: bad embedding_dim/hidden_depth/n_flows");
+    int ndev = 0;
+    I2V_HIP_CHECK(hipGetDeviceCount(&ndev));
+    I2V_REQUIRE(ndev > 0, I2V_E_HIP, "i2v_flow_create: no HIP device");
+    auto f = std::make_unique<i2v_flow>();
+    f->cfg = *cfg;
+    I2V_HIP_CHECK(hipGetDevice(&f->device));
+    f->S = 2 * cfg->n_flows;
+    f->H = cfg->hidden_dim;
+    f->E = cfg->embedding_dim;
+    f->ld0 = 32 + cfg->embedding_dim;
+    f->depth = cfg->hidden_depth;
+    *out = f.release();
+    return I2V_OK;
+}
+
+void i2v_flow_destroy(i2v_flow* f) { delete f; }
+
+int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
+    I2V_REQUIRE(f && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_flow_load: null argument");
+    StateDict sd(tensors, n_tensors);
+    const int nf = f->cfg.n_flows, H = f->H, E = f->E, ld0 = f->ld0, D = f->depth, S = f->S, N2 = 2 * H;
+    std::vector<float> W0((size_t)S * N2 * ld0, 0.f), b0((size_t)S * N2), Wmid((size_t)S * D * N2 * H),
+        bmid((size_t)S * D * N2), W3T((size_t)S * H * 64), b3((size_t)S * 64), loc((size_t)nf * 64, 0.f),
+        scale((size_t)nf * 64, 1.f);
+    std::vector<int> sf((size_t)nf * 64), sb((size_t)nf * 64);
+    f->an_logdet.assign(nf, 0.f);
+    f->step_cond.assign(S, 0);
+    size_t pbytes = 0;
+    for (int fl = 0; fl < nf; ++fl) {
+        const std::string p = "sub_layers." + std::to_string(fl) + ".";
+        const bool cond = f->cfg.control == 2 || (f->cfg.control == 1 && fl % 4 != 0);  // flow_blocks.py:24
+        const int dim = cond ? E : 32 + E;
+        if (!f->cfg.skip_actnorm) {
+            const float* l = sd.f32(p + "norm_layer.loc", 64);
+            const float* s = sd.f32(p + "norm_layer.scale", 64);
+            if (!l || !s) return I2V_E_MISSING;
+            double ld = 0.0;
+            for (int c = 0; c < 64; ++c) {
+                loc[fl * 64 + c] = l[c];
+                scale[fl * 64 + c] = s[c];
+                ld += std::log(std::fabs((double)s[c]));  // modules.py:86-87 with H = W = 1
+            }
+            f->an_logdet[fl] = (float)ld;
+            pbytes += 2 * 64 * 4;
+        }
+        if (!f->cfg.skip_shuffle) {
+            const int64_t* a = sd.i64(p + "shuffle.forward_shuffle_idx", 64);
+            const int64_t* b = sd.i64(p + "shuffle.backward_shuffle_idx", 64);
+            if (!a || !b) return I2V_E_MISSING;
+            for (int c = 0; c < 64; ++c) {
+                I2V_REQUIRE(a[c] >= 0 && a[c] < 64 && b[c] >= 0 && b[c] < 64, I2V_E_INVALID,
+                            "i2v_flow_load: shuffle index out of range in block %d", fl);
+                sf[fl * 64 + c] = (int)a[c];
+                sb[fl * 64 + c] = (int)b[c];
+            }
+            pbytes += 2 * 64 * 8;
+        }
+        for (int i = 0; i < 2; ++i) {
+            const int step = fl * 2 + i;
+            f->step_cond[step] = cond ? 1 : 0;
+            for (int net = 0; net < 2; ++net) {
+                const std::string q = p + "coupling." + (net == 0 ? "s." : "t.") + std::to_string(i) + ".main.";
+                const float* w = sd.f32(q + "0.weight", (int64_t)H * dim);
+                const float* bb = sd.f32(q + "0.bias", H);
+                if (!w || !bb) return I2V_E_MISSING;
+                for (int n = 0; n < H; ++n) {
+                    float* dst = &W0[((size_t)step * N2 + (size_t)net * H + n) * ld0];
+                    if (cond) std::memcpy(dst + 32, w + (size_t)n * dim, (size_t)E * 4);
+                    else std::memcpy(dst, w + (size_t)n * dim, (size_t)dim * 4);
+                    b0[(size_t)step * N2 + net * H + n] = bb[n];
+                }
+                for (int d = 0; d < D; ++d) {
+                    const std::string li = std::to_string(2 * (d + 1));
+                    const float* wm = sd.f32(q + li + ".weight", (int64_t)H * H);
+                    const float* bm = sd.f32(q + li + ".bias", H);
+                    if (!wm || !bm) return I2V_E_MISSING;
+                    std::memcpy(&Wmid[(((size_t)step * D + d) * N2 + (size_t)net * H) * H], wm, (size_t)H * H * 4);
+                    std::memcpy(&bmid[((size_t)step * D + d) * N2 + (size_t)net * H], bm, (size_t)H * 4);
+                }
+                const std::string ll = std::to_string(2 * (D + 1));
+                const float* w3 = sd.f32(q + ll + ".weight", (int64_t)32 * H);
+                const float* bb3 = sd.f32(q + ll + ".bias", 32);
+                if (!w3 || !bb3) return I2V_E_MISSING;
+                for (int c = 0; c < 32; ++c) {
+                    for (int k = 0; k < H; ++k) W3T[((size_t)step * H + k) * 64 + net * 32 + c] = w3[(size_t)c * H + k];
+                    b3[(size_t)step * 64 + net * 32 + c] = bb3[c];
+                }
+                pbytes += ((size_t)H * dim + H + (size_t)D * ((size_t)H * H + H) + (size_t)32 * H + 32) * 4;
+            }
+        }
+    }
+    int rc;
+    if ((rc = f->W0.upload(W0.data(), W0.size() * 4))) return rc;
+    if ((rc = f->b0.upload(b0.data(), b0.size() * 4))) return rc;
+    if ((rc = f->Wmid.upload(Wmid.data(), Wmid.size() * 4))) return rc;
+    if ((rc = f->bmid.upload(bmid.data(), bmid.size() * 4))) return rc;
+    if ((rc = f->W3T.upload(W3T.data(), W3T.size() * 4))) return rc;
+    if ((rc = f->b3.upload(b3.data(), b3.size() * 4))) return rc;
+    if ((rc = f->an_loc.upload(loc.data(), loc.size() * 4))) return rc;
+    if ((rc = f->an_scale.upload(scale.data(), scale.size() * 4))) return rc;
+    if ((rc = f->shuf_f.upload(sf.data(), sf.size() * 4))) return rc;
+    if ((rc = f->shuf_b.upload(sb.data(), sb.size() * 4))) return rc;
+    f->param_bytes = pbytes;
+    f->loaded = true;
+    if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
+    return I2V_OK;
+}
+
+size_t i2v_flow_workspace_bytes(const i2v_flow* f, int32_t batch) {
+    if (!f || batch <= 0) return 0;
+    return ws_layout(f, batch).total;
+}
+
+size_t i2v_flow_param_bytes(const i2v_flow* f) { return f ? f->param_bytes : 0; }
+
+int i2v_flow_forward(i2v_flow* f, const float* x, const float* embed, float* zt, float* logdet, void* workspace,
+                     size_t workspace_bytes, int32_t batch, void* stream) {
+    I2V_REQUIRE(logdet, I2V_E_INVALID, "i2v_flow_forward: logdet is null");
+    return run_pass(f, false, x, embed, zt, logdet, workspace, workspace_bytes, batch, static_cast<hipStream_t>(stream));
+}
+
+int i2v_flow_inverse(i2v_flow* f, const float* residual, const float* embed, float* z, void* workspace,
+                     size_t workspace_bytes, int32_t batch, void* stream) {
+    return run_pass(f, true, residual, embed, z, nullptr, workspace, workspace_bytes, batch,
+                    static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+// Leaf modules of the cINN, individually callable: BasicFullyConnectedNet, ActNorm, InvLeakyRelu, Shuffle and the
+// ActNorm data-dependent initialisation statistics (reference: stage2_cINN/modules/modules.py, flow_blocks.py:142-187).
+#include <algorithm>
+#include <memory>
+
+#include "i2v_linear.h"
+
+namespace i2v {
+
+__global__ void channel_op_kernel(int op, const float* __restrict__ x, float* __restrict__ out, long total, int C, int inner,
+                                  const float* __restrict__ p0, const float* __restrict__ p1,
+                                  const long long* __restrict__ idx, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / inner) % C);
+        float v = x[i];
+        switch (op) {
+            case I2V_OP_ACTNORM_FWD: v = p1[c] * (v + p0[c]); break;
+            case I2V_OP_ACTNORM_REV: v = v / p1[c] - p0[c]; break;
+            case I2V_OP_INVLRELU_FWD: v = v * (v >= 0.f ? 1.0f : alpha); break;
+            case I2V_OP_INVLRELU_REV: v = v / (v >= 0.f ? 1.0f : alpha); break;
+            case I2V_OP_GATHER: {
+                const long b = i / ((long)inner * C);
+                v = x[(b * C + idx[c]) * inner + i % inner];
+                break;
+            }
+        }
+        out[i] = v;
+    }
+}
+
+// one workgroup per row: mean and unbiased std, two-pass in fp64
+__global__ __launch_bounds__(256) void row_mean_std_kernel(const float* __restrict__ x, int n, float* __restrict__ mean,
+                                                           float* __restrict__ stdv) {
+    __shared__ double red[256];
+    const float* r = x + (long)blockIdx.x * n;
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += r[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const double m = red[0] / n;
+    __syncthreads();
+    double q = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { const double d = r[i] - m; q += d * d; }
+    red[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        mean[blockIdx.x] = (float)m;
+        stdv[blockIdx.x] = (float)sqrt(red[0] / (n > 1 ? n - 1 : 1));  // torch.std default: unbiased
+    }
+}
+
+__global__ __launch_bounds__(64) void actnorm_logdet_kernel(const float* __restrict__ scale, int C, float hw,
+                                                            float* __restrict__ out, int B) {
+    float r = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) r += logf(fabsf(scale[c]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off);  // wavefront reduction over the channels
+    const float ld = hw * r;
+    for (int b = threadIdx.x; b < B; b += 64) out[b] = ld;
+}
+
+}  // namespace i2v
+
+using namespace i2v;
+
+struct i2v_mlp {
+    int dim, hidden, depth, out_dim;
+    bool loaded = false;
+    std::vector<DevBuf> W, b;  // depth + 2 layers, torch layout [out][in]
+};
+
+extern "C" {
+
+int i2v_mlp_create(int32_t dim, int32_t hidden_dim, int32_t depth, int32_t out_dim, i2v_mlp** out) {
+    I2V_REQUIRE(out && dim > 0 && hidden_dim > 0 && depth >= 0 && out_dim > 0, I2V_E_INVALID, "i2v_mlp_create: bad argument");
+    int ndev = 0;
+    I2V_HIP_CHECK(hipGetDeviceCount(&ndev));
+    I2V_REQUIRE(ndev > 0, I2V_E_HIP, "i2v_mlp_create: no HIP device");
+    auto m = std::make_unique<i2v_mlp>();
+    m->dim = dim; m->hidden = hidden_dim; m->depth = depth; m->out_dim = out_dim;
+    m->W.resize(depth + 2);
+    m->b.resize(depth + 2);
+    *out = m.release();
+    return I2V_OK;
+}
+
+void i2v_mlp_destroy(i2v_mlp* m) { delete m; }
+
+int i2v_mlp_load(i2v_mlp* m, const i2v_tensor* tensors, int32_t n_tensors) {
+    I2V_REQUIRE(m && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_mlp_load: null argument");
+    StateDict sd(tensors, n_tensors);
+    for (int li = 0; li < m->depth + 2; ++li) {
+        const int in = li == 0 ? m->dim : m->hidden, outd = li == m->depth + 1 ? m->out_dim : m->hidden;
+        const std::string key = "main." + std::to_string(2 * li);
+        const float* w = sd.f32(key + ".weight", (int64_t)in * outd);
+        const float* b = sd.f32(key + ".bias", outd);
+        if (!w || !b) return I2V_E_MISSING;
+        int rc;
+        if ((rc = m->W[li].upload(w, (size_t)in * outd * 4))) return rc;
+        if ((rc = m->b[li].upload(b, (size_t)outd * 4))) return rc;
+    }
+    m->loaded = true;
+    return I2V_OK;
+}
+
+size_t i2v_mlp_workspace_bytes(const i2v_mlp* m, int32_t batch) {
+    if (!m || batch <= 0) return 0;
+    return 2 * align_up((size_t)m->hidden * batch * 4, 256);
+}
+
+int i2v_mlp_forward(i2v_mlp* m, const float* x, float* y, void* workspace, size_t workspace_bytes, int32_t batch,
+                    void* stream) {
+    I2V_REQUIRE(m && m->loaded, I2V_E_STATE, "i2v_mlp_forward: weights not loaded");
+    I2V_REQUIRE(x && y && workspace && batch > 0, I2V_E_INVALID, "i2v_mlp_forward: null argument");
+    I2V_REQUIRE(workspace_bytes >= i2v_mlp_workspace_bytes(m, batch), I2V_E_WORKSPACE, "i2v_mlp_forward: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int B = batch, H = m->hidden;
+    float* hA = static_cast<float*>(workspace);
+    float* hB = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)H * B * 4, 256));
+    const float* in = x;
+    long in_sk = 1, in_sb = m->dim;
+    int K = m->dim;
+    for (int li = 0; li < m->depth + 2; ++li) {
+        const bool last = li == m->depth + 1;
+        LinArgs a{};
+        a.W = m->W[li].as<float>(); a.ldw = K; a.K = K;
+        a.in = in; a.in_sk = in_sk; a.in_sb = in_sb; a.in_group_stride = 0;
+        a.N = last ? m->out_dim : H;
+        a.group_rows = a.N;
+        a.bias_vec = m->b[li].as<float>(); a.bias_mat = nullptr;
+        a.B = B;
+        if (last) { a.out = y; a.out_sn = 1; a.out_sb = m->out_dim; a.slope = 1.0f; }
+        else { a.out = (li & 1) ? hB : hA; a.out_sn = B; a.out_sb = 1; a.slope = 0.01f; }  // nn.LeakyReLU(), modules.py:17
+        int rc = launch_linear<4, 4>(a, st);
+        if (rc) return rc;
+        in = a.out; in_sk = B; in_sb = 1; K = H;
+    }
+    return I2V_OK;
+}
+
+int i2v_channel_op(int32_t op, const float* x, float* out, int32_t batch, int32_t channels, int32_t inner, const float* p0,
+                   const float* p1, const int64_t* idx, float alpha, void* stream) {
+    I2V_REQUIRE(x && out && batch > 0 && channels > 0 && inner > 0, I2V_E_INVALID, "i2v_channel_op: bad argument");
+    I2V_REQUIRE(op >= 0 && op <= I2V_OP_GATHER, I2V_E_INVALID, "i2v_channel_op: unknown op %d", op);
+    if (op <= I2V_OP_ACTNORM_REV) I2V_REQUIRE(p0 && p1, I2V_E_INVALID, "i2v_channel_op: actnorm needs loc and scale");
+    if (op == I2V_OP_GATHER) I2V_REQUIRE(idx && x != out, I2V_E_INVALID, "i2v_channel_op: gather needs idx and out != x");
+    const long total = (long)batch * channels * inner;
+    const long blocks = std::min<long>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(channel_op_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), op, x, out,
+                       total, channels, inner, p0, p1, reinterpret_cast<const long long*>(idx), alpha);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+int i2v_row_mean_std(const float* x, int32_t rows, int32_t n, float* mean, float* stdv, void* stream) {
+    I2V_REQUIRE(x && mean && stdv && rows > 0 && n > 0, I2V_E_INVALID, "i2v_row_mean_std: bad argument");
+    hipLaunchKernelGGL(row_mean_std_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, mean, stdv);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+int i2v_actnorm_logdet(const float* scale, int32_t channels, float hw, float* out, int32_t batch, void* stream) {
+    I2V_REQUIRE(scale && out && channels > 0 && batch > 0, I2V_E_INVALID, "i2v_actnorm_logdet: bad argument");
+    hipLaunchKernelGGL(actnorm_logdet_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), scale, channels, hw, out,
+                       batch);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+}  // extern "C"

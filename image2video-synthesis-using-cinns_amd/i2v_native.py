@@ -1,0 +1,347 @@
+"""ctypes binding of ``libi2v_hip.so`` (C ABI declared in ``include/i2v_hip.h``).
+
+PyTorch-ROCm tensors are used only as containers: every call passes raw device pointers
+(``tensor.data_ptr()``) and the current HIP stream.  There is NO CPU fallback: if the shared
+library is missing, or a tensor does not live on a GPU, the call raises.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import numpy as np
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libi2v_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+I2V_F32, I2V_I64, I2V_U8 = 0, 1, 2
+
+
+class I2VError(RuntimeError):
+    pass
+
+
+class _Tensor(ctypes.Structure):
+    _fields_ = [("name", c_char_p), ("data", c_void_p), ("numel", c_int64), ("dtype", c_int32)]
+
+
+class FlowCfg(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("in_channels", "embedding_dim", "hidden_dim", "hidden_depth", "n_flows",
+                                      "control", "activation", "skip_actnorm", "skip_shuffle", "use_graph")]
+
+
+class DecCfg(ctypes.Structure):
+    _fields_ = [("channel_factor", c_int32), ("z_dim", c_int32), ("upsample_s", c_int32 * 2),
+                ("upsample_t", c_int32 * 2), ("spectral_norm", c_int32), ("mma", c_int32)]
+
+
+_lib = None
+
+# symbol -> (restype, argtypes); also the list the CPU test-suite checks the .so exports
+SYMBOLS = {
+    "i2v_last_error": (c_char_p, []),
+    "i2v_version": (c_int32, []),
+    "i2v_device_count": (c_int32, []),
+    "i2v_flow_create": (c_int32, [POINTER(FlowCfg), POINTER(c_void_p)]),
+    "i2v_flow_destroy": (None, [c_void_p]),
+    "i2v_flow_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
+    "i2v_flow_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "i2v_flow_param_bytes": (c_size_t, [c_void_p]),
+    "i2v_flow_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "i2v_flow_inverse": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "i2v_mlp_create": (c_int32, [c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "i2v_mlp_destroy": (None, [c_void_p]),
+    "i2v_mlp_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
+    "i2v_mlp_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "i2v_mlp_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "i2v_channel_op": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                 c_float, c_void_p]),
+    "i2v_row_mean_std": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "i2v_actnorm_logdet": (c_int32, [c_void_p, c_int32, c_float, c_void_p, c_int32, c_void_p]),
+    "i2v_dec_create": (c_int32, [POINTER(DecCfg), POINTER(c_void_p)]),
+    "i2v_dec_destroy": (None, [c_void_p]),
+    "i2v_dec_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
+    "i2v_dec_out_shape": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "i2v_dec_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32, c_int32]),
+    "i2v_dec_flops_per_sample": (c_double, [c_void_p, c_int32, c_int32]),
+    "i2v_dec_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "i2v_dec_set_profile": (c_int32, [c_void_p, c_int32]),
+    "i2v_dec_debug_tap": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t]),
+    "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+}
+
+
+def build(force=False):
+    """Compile ``libi2v_hip.so`` for gfx950 in-tree (``make`` in csrc/; hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC, "-j4"], check=True)
+    if not os.path.exists(LIB_PATH):
+        raise I2VError(f"build did not produce {LIB_PATH}")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded shared library.  Fails loudly when it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise I2VError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"or `make -C {CSRC}`; this package has no CPU/eager fallback")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise I2VError(f"{what} failed ({rc}): {lib().i2v_last_error().decode(errors='replace')}")
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise I2VError("libi2v_hip kernels need tensors on a HIP device (got a CPU tensor); "
+                           "this package has no CPU fallback -- move the module and its inputs to 'cuda'")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise I2VError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pack_state_dict(sd):
+    """{key: tensor/ndarray} -> (ctypes array of i2v_tensor, keep-alive list)."""
+    keep, items = [], []
+    for k, v in sd.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().contiguous().numpy()
+        a = np.ascontiguousarray(v)
+        if a.dtype == np.float32:
+            dt = I2V_F32
+        elif a.dtype == np.int64:
+            dt = I2V_I64
+        elif a.dtype == np.uint8:
+            dt = I2V_U8
+        else:
+            raise I2VError(f"state_dict entry {k}: unsupported dtype {a.dtype}")
+        kb = k.encode()
+        keep.append((kb, a))
+        items.append(_Tensor(kb, a.ctypes.data_as(c_void_p), a.size, dt))
+    arr = (_Tensor * len(items))(*items)
+    return arr, keep
+
+
+class _Workspace:
+    """Caller-owned device scratch, cached per (device, size class) so its address is stable across calls."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class NativeFlow:
+    """Handle for ``i2v_flow_*`` (ConditionalFlow, flow_blocks.py:8-60)."""
+
+    def __init__(self, in_channels, embedding_dim, hidden_dim, hidden_depth, n_flows, control=False,
+                 activation="lrelu", skip_actnorm=False, skip_shuffle=False, use_graph=True):
+        cfg = FlowCfg(in_channels, embedding_dim, hidden_dim, hidden_depth, n_flows, int(control),
+                      1 if activation == "lrelu" else 0, int(skip_actnorm), int(skip_shuffle), int(use_graph))
+        h = c_void_p()
+        _check(lib().i2v_flow_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_flow_create")
+        self._h = h
+        self.embedding_dim = embedding_dim
+        self._ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.i2v_flow_destroy(self._h)
+            self._h = None
+
+    def load(self, state_dict):
+        arr, keep = _pack_state_dict(state_dict)
+        _check(lib().i2v_flow_load(self._h, arr, len(arr)), "i2v_flow_load")
+        del keep
+
+    @property
+    def param_bytes(self):
+        return int(lib().i2v_flow_param_bytes(self._h))
+
+    def _run(self, x, embed, reverse):
+        _require_gpu(x, embed)
+        B = x.shape[0]
+        if x.shape != (B, 64) or embed.shape != (B, self.embedding_dim):
+            raise I2VError(f"flow: expected x [B,64] and embed [B,{self.embedding_dim}], got {tuple(x.shape)}, {tuple(embed.shape)}")
+        nbytes = lib().i2v_flow_workspace_bytes(self._h, B)
+        ws = self._ws.get(nbytes, x.device)
+        out = torch.empty_like(x)
+        if reverse:
+            _check(lib().i2v_flow_inverse(self._h, x.data_ptr(), embed.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), B, _stream()), "i2v_flow_inverse")
+            return out
+        logdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        _check(lib().i2v_flow_forward(self._h, x.data_ptr(), embed.data_ptr(), out.data_ptr(), logdet.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), B, _stream()), "i2v_flow_forward")
+        return out, logdet
+
+    def forward(self, x, embed):
+        return self._run(x, embed, False)
+
+    def inverse(self, x, embed):
+        return self._run(x, embed, True)
+
+
+class NativeDecoder:
+    """Handle for ``i2v_dec_*`` (Generator, decoder.py:55-120)."""
+
+    def __init__(self, channel_factor, z_dim, upsample_s, upsample_t, spectral_norm=True, mma=0):
+        cfg = DecCfg(channel_factor, z_dim, (c_int32 * 2)(*upsample_s), (c_int32 * 2)(*upsample_t),
+                     int(bool(spectral_norm)), mma)
+        h = c_void_p()
+        _check(lib().i2v_dec_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_dec_create")
+        self._h = h
+        self.z_dim = z_dim
+        self._ws = _Workspace()
+        t, hh, w = c_int32(), c_int32(), c_int32()
+        _check(lib().i2v_dec_out_shape(self._h, ctypes.byref(t), ctypes.byref(hh), ctypes.byref(w)), "i2v_dec_out_shape")
+        self.out_shape = (t.value, hh.value, w.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.i2v_dec_destroy(self._h)
+            self._h = None
+
+    def load(self, state_dict):
+        arr, keep = _pack_state_dict(state_dict)
+        _check(lib().i2v_dec_load(self._h, arr, len(arr)), "i2v_dec_load")
+        del keep
+
+    def flops_per_sample(self, img_h, img_w):
+        return float(lib().i2v_dec_flops_per_sample(self._h, img_h, img_w))
+
+    def set_profile(self, on):
+        _check(lib().i2v_dec_set_profile(self._h, int(on)), "i2v_dec_set_profile")
+
+    def get_profile(self):
+        a, b, c = c_double(), c_double(), c_double()
+        _check(lib().i2v_dec_get_profile(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "i2v_dec_get_profile")
+        return {"conv3_ms": a.value, "conv3_flops": b.value, "total_ms": c.value}
+
+    def debug_tap(self, block, which, dst):
+        """Test hook (i2v_dec_debug_tap): dst = float32 CUDA tensor or None."""
+        if dst is None:
+            _check(lib().i2v_dec_debug_tap(self._h, -1, -1, None, 0), "i2v_dec_debug_tap")
+        else:
+            _check(lib().i2v_dec_debug_tap(self._h, block, which, dst.data_ptr(), dst.numel()), "i2v_dec_debug_tap")
+
+    def forward(self, img, motion):
+        _require_gpu(img, motion)
+        B = img.shape[0]
+        if img.dim() != 4 or img.shape[1] != 3 or motion.shape != (B, self.z_dim):
+            raise I2VError(f"decoder: expected img [B,3,H,W] and motion [B,{self.z_dim}], got {tuple(img.shape)}, {tuple(motion.shape)}")
+        nbytes = lib().i2v_dec_workspace_bytes(self._h, B, img.shape[2], img.shape[3])
+        ws = self._ws.get(nbytes, img.device)
+        T, H, W = self.out_shape
+        out = torch.empty(B, T, 3, H, W, dtype=torch.float32, device=img.device)
+        _check(lib().i2v_dec_forward(self._h, img.data_ptr(), img.shape[2], img.shape[3], motion.data_ptr(),
+                                     out.data_ptr(), ws.data_ptr(), ws.numel(), B, _stream()), "i2v_dec_forward")
+        return out
+
+
+class NativeMLP:
+    """Handle for ``i2v_mlp_*`` (BasicFullyConnectedNet, modules.py:9-30)."""
+
+    def __init__(self, dim, hidden_dim, depth, out_dim):
+        h = c_void_p()
+        _check(lib().i2v_mlp_create(dim, hidden_dim, depth, out_dim, ctypes.byref(h)), "i2v_mlp_create")
+        self._h = h
+        self.dim, self.out_dim = dim, out_dim
+        self._ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.i2v_mlp_destroy(self._h)
+            self._h = None
+
+    def load(self, state_dict):
+        arr, keep = _pack_state_dict(state_dict)
+        _check(lib().i2v_mlp_load(self._h, arr, len(arr)), "i2v_mlp_load")
+        del keep
+
+    def forward(self, x):
+        _require_gpu(x)
+        if x.dim() != 2 or x.shape[1] != self.dim:
+            raise I2VError(f"mlp: expected x [B,{self.dim}], got {tuple(x.shape)}")
+        B = x.shape[0]
+        ws = self._ws.get(lib().i2v_mlp_workspace_bytes(self._h, B), x.device)
+        y = torch.empty(B, self.out_dim, dtype=torch.float32, device=x.device)
+        _check(lib().i2v_mlp_forward(self._h, x.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), B, _stream()),
+               "i2v_mlp_forward")
+        return y
+
+
+OP_ACTNORM_FWD, OP_ACTNORM_REV, OP_INVLRELU_FWD, OP_INVLRELU_REV, OP_GATHER = range(5)
+
+
+def _channel_op(op, x, p0=None, p1=None, idx=None, alpha=0.0):
+    _require_gpu(x)
+    if x.dim() < 2:
+        raise I2VError("channel op: need a [B, C, ...] tensor")
+    B, C = x.shape[0], x.shape[1]
+    inner = x.numel() // (B * C)
+    out = torch.empty_like(x)
+    _check(lib().i2v_channel_op(op, x.data_ptr(), out.data_ptr(), B, C, inner,
+                                p0.data_ptr() if p0 is not None else None, p1.data_ptr() if p1 is not None else None,
+                                idx.data_ptr() if idx is not None else None, float(alpha), _stream()), "i2v_channel_op")
+    return out
+
+
+def actnorm(x, loc, scale, reverse):
+    """ActNorm.forward / reverse arithmetic (modules.py:80,100) on [B,C,H,W]."""
+    loc = loc.detach().reshape(-1).contiguous()
+    scale = scale.detach().reshape(-1).contiguous()
+    _require_gpu(loc, scale)
+    return _channel_op(OP_ACTNORM_REV if reverse else OP_ACTNORM_FWD, x, loc, scale)
+
+
+def actnorm_logdet(scale, hw, batch):
+    scale = scale.detach().reshape(-1).contiguous()
+    _require_gpu(scale)
+    out = torch.empty(batch, dtype=torch.float32, device=scale.device)
+    _check(lib().i2v_actnorm_logdet(scale.data_ptr(), scale.numel(), float(hw), out.data_ptr(), batch, _stream()),
+           "i2v_actnorm_logdet")
+    return out
+
+
+def inv_lrelu(x, alpha, reverse):
+    return _channel_op(OP_INVLRELU_REV if reverse else OP_INVLRELU_FWD, x, alpha=alpha)
+
+
+def gather_channels(x, idx):
+    idx = idx.detach().contiguous()
+    if not idx.is_cuda or idx.dtype != torch.int64:
+        raise I2VError("gather_channels: idx must be an int64 tensor on the GPU")
+    return _channel_op(OP_GATHER, x, idx=idx)
+
+
+def channel_mean_std(flat):
+    """flat [C, N] -> (mean [C], unbiased std [C])."""
+    _require_gpu(flat)
+    C, N = flat.shape
+    mean = torch.empty(C, dtype=torch.float32, device=flat.device)
+    std = torch.empty(C, dtype=torch.float32, device=flat.device)
+    _check(lib().i2v_row_mean_std(flat.data_ptr(), C, N, mean.data_ptr(), std.data_ptr(), _stream()), "i2v_row_mean_std")
+    return mean, std

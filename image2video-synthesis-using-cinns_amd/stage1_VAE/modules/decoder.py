@@ -1,0 +1,73 @@
+"""Mirror of the reference's ``stage1_VAE/modules/decoder.py`` class surface (GeneratorBlock, Generator).
+
+``Generator.forward(img, motion)`` is ONE call into libi2v_hip.so (``i2v_dec_forward``, csrc/i2v_dec.hip): all
+activations stay channels-last in HBM, spectral-norm is folded at load time, the 3x3x3 convolutions run on the
+gfx950 matrix cores.  The sub-modules carry the reference's state_dict keys (``g_k.conv_0.weight_orig`` ...) so
+released ``.pth`` files load unchanged."""
+import torch
+import torch.nn as nn
+
+import i2v_native as native
+from i2v_params import ConvParams, LinearParams, NativeBacked
+from stage1_VAE.modules.normalization_layer import ADAIN, Norm3D, Spade
+
+
+class GeneratorBlock(NativeBacked):
+    """out = shortcut(x) + conv_1(lrelu(ADAIN(conv_0(lrelu(Spade(x, img))), z)))   (reference decoder.py:7-52)."""
+
+    def __init__(self, n_in, n_out, use_spectral, z_dim):
+        super().__init__()
+        self.learned_shortcut = (n_in != n_out)
+        n_middle = min(n_in, n_out)
+        self.n_in, self.n_out, self.z_dim, self.use_spectral = n_in, n_out, z_dim, bool(use_spectral)
+        self.conv_0 = ConvParams(n_in, n_middle, 3, 3, bias=True, spectral=use_spectral)
+        self.conv_1 = ConvParams(n_middle, n_out, 3, 3, bias=True, spectral=use_spectral)
+        if self.learned_shortcut:
+            self.conv_s = ConvParams(n_in, n_out, 1, 3, bias=False, spectral=use_spectral)
+        self.norm_0 = Spade(n_in)
+        self.norm_1 = ADAIN(n_middle, z_dim)
+        if self.learned_shortcut:
+            self.norm_s = Norm3D(n_in)
+
+    def _build_native(self):
+        h = native.NativeGBlock(self.n_in, self.n_out, self.z_dim, self.use_spectral)
+        h.load(self.state_dict())
+        return h
+
+    def forward(self, x, cond1, cond2):
+        return self.native().forward(x.contiguous(), cond1.contiguous(), cond2.contiguous())
+
+
+class Generator(NativeBacked):
+    """fc -> head_0 -> (x2, g_0) -> (x2, g_1) -> (x2, g_2) -> (up, g_3) -> (up, g_4) -> lrelu -> conv_img -> tanh
+    (reference decoder.py:55-120).  Returns ``[B, 16, 3, H, W]`` (contiguous; the reference returns a transposed
+    view of a [B,3,16,H,W] buffer)."""
+
+    def __init__(self, dic):
+        super().__init__()
+        nf = dic["channel_factor"]
+        self.z_dim = dic["z_dim"]
+        self.fmap_start = 16 * nf
+        use_spectral = dic["spectral_norm"]
+        self.upsample_s = list(dic["upsample_s"])
+        self.upsample_t = list(dic["upsample_t"])
+        self.channel_factor = nf
+        self.use_spectral = bool(use_spectral)
+        self.fc = LinearParams(self.z_dim, 4 * 4 * 16 * nf)
+        self.head_0 = GeneratorBlock(16 * nf, 16 * nf, use_spectral, self.z_dim)
+        self.g_0 = GeneratorBlock(16 * nf, 16 * nf, use_spectral, self.z_dim)
+        self.g_1 = GeneratorBlock(16 * nf, 8 * nf, use_spectral, self.z_dim)
+        self.g_2 = GeneratorBlock(8 * nf, 4 * nf, use_spectral, self.z_dim)
+        self.g_3 = GeneratorBlock(4 * nf, 2 * nf, use_spectral, self.z_dim)
+        self.g_4 = GeneratorBlock(2 * nf, 1 * nf, use_spectral, self.z_dim)
+        self.conv_img = ConvParams(nf, 3, 3, 3, bias=True, spectral=False)
+        self.mma = int(dic.get("mma", 0)) if hasattr(dic, "get") else 0
+
+    def _build_native(self):
+        h = native.NativeDecoder(self.channel_factor, self.z_dim, self.upsample_s, self.upsample_t, self.use_spectral,
+                                 mma=self.mma)
+        h.load(self.state_dict())
+        return h
+
+    def forward(self, img, motion):
+        return self.native().forward(img.contiguous(), motion.contiguous())

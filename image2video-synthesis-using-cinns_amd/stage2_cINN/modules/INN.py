@@ -1,0 +1,67 @@
+"""Mirror of the reference's ``stage2_cINN/modules/INN.py``: ``SupervisedTransformer`` owns the conditional flow
+and the frozen conditioning embedder and dispatches forward / reverse (reference INN.py:8-73).
+
+The ResNet-50 conditioning embedder (stage2_cINN/AE/modules/AE.py:91-166) sits in FRONT of the hot path and is the
+first "next" row of the coverage contract.  Until it is built, the embedding is supplied by the
+caller (``embed=``) or by a user-provided ``embedder`` object exposing ``encode(x).mode()``."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from stage2_cINN.modules.flow_blocks import ConditionalFlow
+
+
+class SupervisedTransformer(nn.Module):
+    def __init__(self, **kwargs):
+        super().__init__()
+        in_channels = kwargs["flow_in_channels"]
+        mid_channels = kwargs["flow_mid_channels"]
+        hidden_depth = kwargs["flow_hidden_depth"]
+        n_flows = kwargs["n_flows"]
+        conditioning_option = kwargs["flow_conditioning_option"]
+        embedding_channels = kwargs["flow_embedding_channels"] if "flow_embedding_channels" in kwargs \
+            else kwargs["flow_in_channels"]
+        self.control = bool(kwargs["control"])
+        self.cond_size = 10 if self.control else 0
+        self.flow = ConditionalFlow(in_channels=in_channels, embedding_dim=embedding_channels + self.cond_size * 3,
+                                    hidden_dim=mid_channels, hidden_depth=hidden_depth, n_flows=n_flows,
+                                    conditioning_option=conditioning_option, control=self.control)
+        # reference INN.py:36-41 builds ResnetEncoder(config.AE) from dic['model_path'] + dic['model_name'];
+        # here an embedder object can be injected instead (row N1)
+        self.embedder = kwargs.get("embedder", None)
+
+    def embed_pos(self, pos):
+        """Three one-hots of 10 bins at index floor(pos*10 - 1e-4) (reference INN.py:49-57)."""
+        pos = pos.detach().float().cpu() * self.cond_size - 1e-4
+        out = torch.zeros(pos.size(0), 3 * self.cond_size)
+        rows = np.arange(pos.size(0))
+        for j in range(3):
+            out[rows, j * self.cond_size + pos[:, j].long()] = 1
+        return out
+
+    def _embed(self, input, cond, embed):
+        if embed is None:
+            if self.embedder is None:
+                raise RuntimeError("SupervisedTransformer: no conditioning embedder is attached (ResNet-50 embedder is "
+                                   "row N1 of the coverage contract); pass embed=[B,E] explicitly")
+            with torch.no_grad():
+                embed = self.embedder.encode(cond[0]).mode().reshape(input.size(0), -1).detach()
+        if self.control:
+            embed = torch.cat((embed, self.embed_pos(cond[1]).to(embed)), dim=1)
+        return embed.contiguous()
+
+    def forward(self, input, cond, reverse=False, train=False, embed=None):
+        embed = self._embed(input, cond, embed)
+        if reverse:
+            return self.reverse(input, embed)
+        out, logdet = self.flow(input, embed)
+        return out, logdet
+
+    def reverse(self, out, cond):
+        return self.flow(out, cond, reverse=True)
+
+    def sample(self, shape, cond):
+        """reference INN.py:43-47 (calls reverse with the raw cond, i.e. cond must already be an embedding)."""
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        z_tilde = torch.randn(shape).to(device)
+        return self.reverse(z_tilde, cond)

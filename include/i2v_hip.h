@@ -1,0 +1,159 @@
+/* libi2v_hip.so -- C ABI of the MI355X-native (gfx950) cINN-sampling + VAE-decoder hot path.
+ *
+ * The reference (CompVis/image2video-synthesis-using-cINNs) is pure PyTorch and has no FFI of
+ * its own: the boundary it offers is the Python class surface.  This header is
+ * the NEW native boundary underneath that surface; each entry point names the reference
+ * method (file:line relative to the reference repo) whose arithmetic it replaces.  The Python
+ * mirror of the reference classes (image2video-synthesis-using-cinns_amd/...) calls these via
+ * ctypes, see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.
+ *   - "host tensors" (i2v_tensor) are read during *_load only and are not retained.
+ *   - all pointers passed to the compute calls are DEVICE pointers owned by the caller (PyTorch
+ *     allocates inputs, outputs and the workspace); the library owns only its packed weights.
+ *   - compute calls only ENQUEUE on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and never synchronise.  A handle is bound to the device current at create time,
+ *     is not re-entrant, and must be used from one stream at a time.
+ *   - return value: 0 = ok, negative = error (I2V_E_*); i2v_last_error() gives the message of
+ *     the last failure on the calling thread.
+ */
+#ifndef I2V_HIP_H
+#define I2V_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2V_OK 0
+#define I2V_E_INVALID (-1)   /* bad argument / unsupported configuration */
+#define I2V_E_MISSING (-2)   /* a state_dict key is missing or has the wrong size */
+#define I2V_E_HIP (-3)       /* a HIP runtime call failed */
+#define I2V_E_WORKSPACE (-4) /* workspace too small */
+#define I2V_E_STATE (-5)     /* weights not loaded */
+
+#define I2V_F32 0
+#define I2V_I64 1
+#define I2V_U8 2
+
+/* One named host tensor of a PyTorch state_dict (contiguous). */
+typedef struct {
+    const char* name;  /* state_dict key, e.g. "sub_layers.3.coupling.s.0.main.2.weight" */
+    const void* data;  /* HOST pointer */
+    int64_t numel;
+    int32_t dtype;     /* I2V_F32 / I2V_I64 / I2V_U8 */
+} i2v_tensor;
+
+const char* i2v_last_error(void);
+int i2v_version(void);
+/* Number of HIP devices visible; <0 on error.  Used by the Python side to fail loudly. */
+int i2v_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * cINN flow: ConditionalFlow (stage2_cINN/modules/flow_blocks.py:8-60)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct i2v_flow i2v_flow;
+
+typedef struct {
+    int32_t in_channels;   /* 64 (flow_blocks.py:13); the kernels map channel <-> wavefront lane */
+    int32_t embedding_dim; /* E (+30 with control), flow_blocks.py:14 */
+    int32_t hidden_dim;    /* 512 = z_dim * flow_mid_channels_factor, get_model.py:34 */
+    int32_t hidden_depth;  /* 2, flow_blocks.py:16 */
+    int32_t n_flows;       /* 20 */
+    int32_t control;       /* 1: blocks fl%4 != 0 run in mode 'cond' (flow_blocks.py:24); 2: every block does */
+    int32_t activation;    /* 1 = InvLeakyRelu(0.9) (default), 0 = IgnoreLeakyRelu */
+    int32_t skip_actnorm;  /* 1: no ActNorm  (used to expose the bare coupling block, :63-105) */
+    int32_t skip_shuffle;  /* 1: no Shuffle */
+    int32_t use_graph;     /* 1: replay the launch chain from a captured hipGraph */
+} i2v_flow_cfg;
+
+int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out);
+void i2v_flow_destroy(i2v_flow* f);
+/* Packs the 80 MLPs, ActNorm and Shuffle parameters of ConditionalFlow.state_dict() into the
+ * streaming layout and uploads them.  Keys: sub_layers.{i}.{norm_layer.{loc,scale},
+ * coupling.{s,t}.{0,1}.main.{0,2,4,6}.{weight,bias}, shuffle.{forward,backward}_shuffle_idx}. */
+int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors);
+size_t i2v_flow_workspace_bytes(const i2v_flow* f, int32_t batch);
+/* Bytes of parameters streamed per pass (the algorithmic HBM traffic of SURVEY §8d). */
+size_t i2v_flow_param_bytes(const i2v_flow* f);
+/* ConditionalFlow.forward(x, embedding, reverse=False), flow_blocks.py:42-51.
+ * x [B,64], embed [B,E] -> zt [B,64], logdet [B]. */
+int i2v_flow_forward(i2v_flow* f, const float* x, const float* embed, float* zt, float* logdet,
+                     void* workspace, size_t workspace_bytes, int32_t batch, void* stream);
+/* ConditionalFlow.forward(x, embedding, reverse=True), flow_blocks.py:53-57. */
+int i2v_flow_inverse(i2v_flow* f, const float* residual, const float* embed, float* z,
+                     void* workspace, size_t workspace_bytes, int32_t batch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Leaf modules of the flow, individually callable (sub-module classes stay usable)
+ * ---------------------------------------------------------------------------------------- */
+/* BasicFullyConnectedNet (stage2_cINN/modules/modules.py:9-30): Linear(dim,hidden) -> LeakyReLU(0.01) ->
+ * depth x [Linear(hidden,hidden) -> LeakyReLU(0.01)] -> Linear(hidden,out_dim).  Keys main.{0,2,...}.{weight,bias}. */
+typedef struct i2v_mlp i2v_mlp;
+int i2v_mlp_create(int32_t dim, int32_t hidden_dim, int32_t depth, int32_t out_dim, i2v_mlp** out);
+void i2v_mlp_destroy(i2v_mlp* m);
+int i2v_mlp_load(i2v_mlp* m, const i2v_tensor* tensors, int32_t n_tensors);
+size_t i2v_mlp_workspace_bytes(const i2v_mlp* m, int32_t batch);
+/* x [B,dim] -> y [B,out_dim] */
+int i2v_mlp_forward(i2v_mlp* m, const float* x, float* y, void* workspace, size_t workspace_bytes, int32_t batch,
+                    void* stream);
+
+/* Per-channel elementwise ops on a contiguous [B][C][inner] tensor. */
+#define I2V_OP_ACTNORM_FWD 0  /* out = p1[c] * (x + p0[c])        ActNorm.forward, modules.py:80 (p0 = loc, p1 = scale) */
+#define I2V_OP_ACTNORM_REV 1  /* out = x / p1[c] - p0[c]          ActNorm.reverse, modules.py:100 */
+#define I2V_OP_INVLRELU_FWD 2 /* out = x * (x >= 0 ? 1 : alpha)   InvLeakyRelu.forward, flow_blocks.py:180-181 */
+#define I2V_OP_INVLRELU_REV 3 /* out = x / (x >= 0 ? 1 : alpha)   InvLeakyRelu.reverse, flow_blocks.py:185-186 */
+#define I2V_OP_GATHER 4       /* out[b,c] = x[b, idx[c]]          Shuffle, flow_blocks.py:152-154 (idx: device int64) */
+int i2v_channel_op(int32_t op, const float* x, float* out, int32_t batch, int32_t channels, int32_t inner,
+                   const float* p0, const float* p1, const int64_t* idx, float alpha, void* stream);
+/* Per-row mean and unbiased std of x [rows][n] (ActNorm.initialize, modules.py:43-63). */
+int i2v_row_mean_std(const float* x, int32_t rows, int32_t n, float* mean, float* std, void* stream);
+/* out[b] = hw * sum_c log|scale[c]| for b < batch (ActNorm log-det, modules.py:86-88). */
+int i2v_actnorm_logdet(const float* scale, int32_t channels, float hw, float* out, int32_t batch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage-1 decoder: Generator (stage1_VAE/modules/decoder.py:55-120)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct i2v_dec i2v_dec;
+
+typedef struct {
+    int32_t channel_factor; /* nf, decoder.py:59 (multiple of 8) */
+    int32_t z_dim;          /* 64 */
+    int32_t upsample_s[2];  /* decoder.py:66 */
+    int32_t upsample_t[2];  /* decoder.py:67 */
+    int32_t spectral_norm;  /* decoder.py:64 */
+    int32_t mma;            /* 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = split-fp16 3-term MFMA */
+} i2v_dec_cfg;
+
+int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out);
+void i2v_dec_destroy(i2v_dec* d);
+/* Folds W/sigma (signed sigma = u.(W_mat v), torch spectral_norm eval semantics, hook at
+ * decoder.py:20-25), re-lays every conv for the implicit-GEMM kernels and uploads.  Keys as in
+ * Generator.state_dict(): fc.*, {head_0,g_0..g_4}.{conv_0,conv_1,conv_s}.{weight_orig,weight_u,
+ * weight_v,bias} (or .weight when spectral_norm = 0), .norm_0.{conv,conv_gamma,conv_beta}.*,
+ * .norm_1.linear.*, .norm_s.bn.*, conv_img.*. */
+int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors);
+/* Output geometry [T, H, W] of one decoder pass (T = 16 for every shipped config). */
+int i2v_dec_out_shape(const i2v_dec* d, int32_t* t, int32_t* h, int32_t* w);
+size_t i2v_dec_workspace_bytes(const i2v_dec* d, int32_t batch, int32_t img_h, int32_t img_w);
+double i2v_dec_flops_per_sample(const i2v_dec* d, int32_t img_h, int32_t img_w);
+/* Generator.forward(img, motion), decoder.py:97-120.
+ * img [B,3,img_h,img_w] (NCHW, [-1,1]), motion [B,z_dim] -> out [B,T,3,H,W] contiguous. */
+int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, const float* motion,
+                    float* out, void* workspace, size_t workspace_bytes, int32_t batch, void* stream);
+/* Last-call per-kernel-class device time in ms (needs i2v_dec_set_profile(d,1), which makes the
+ * forward synchronise; for bench/roofline only).  names: "conv3", "conv_other", "norm", "other". */
+int i2v_dec_set_profile(i2v_dec* d, int32_t on);
+/* Test hook: during the next forwards copy up to max_floats of one channels-last intermediate of GeneratorBlock
+ * `block` (0 = head_0 .. 5 = g_4) into dst (device).  which: 0 = SPADE (1+gamma | beta) [B,H,W,2C], 1 = lrelu(Spade(x)),
+ * 2 = conv_0 output, 3 = lrelu(ADAIN(.)), 4 = shortcut (low resolution), 5 = block output.  dst = NULL disables. */
+int i2v_dec_debug_tap(i2v_dec* d, int32_t block, int32_t which, float* dst, size_t max_floats);
+int i2v_dec_get_profile(const i2v_dec* d, double* conv3_ms, double* conv3_flops, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2V_HIP_H */
