@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: cINN inverse + stage-1 decoder, synthesized frames/sec (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one Model.synthesize-equivalent call on synthetic inputs already resident in HBM: cINN inverse on the
+rank's shard of the globally drawn residual/embedding, one decoder pass (16 frames per sample), and for N > 1 one RCCL
+all-gather collating the [B/N,16,3,H,W] blocks.  Weak scaling: the per-GPU batch is fixed (BASELINE configs[1]:
+BAIR 64x64, seq_len 16, batch 64 per MI355X), the global batch grows with N.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     dominant kernel = the 3x3x3 implicit-GEMM Conv3d on fp32 MFMA: achieved = algorithmic FLOPs of all its
+               launches / their summed duration, measured with HIP events on the launch stream inside the timed region
+  roofline_cinn  the coupling-block pass against the HBM roofline: algorithmic bytes (parameters + I/O) / pass time
+  cpu_baseline the CPU oracle ("port" of the reference op sequence, spectral norm folded once) timed on the host cores
+               on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "image2video-synthesis-using-cinns_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[1]: BAIR 64x64, seq_len 16, batch 64 on one MI355X (full cINN stack + decoder)
+    "bair64": dict(nf=64, emb=64, img=64, ups=[2, 1], upt=[2, 1], batch=64, name="BAIR 64x64x16 nf=64 E=64"),
+    # BASELINE.json configs[2]: Landscape 128x128, seq_len 16, batch 32
+    "land128": dict(nf=32, emb=128, img=128, ups=[2, 2], upt=[2, 1], batch=32, name="Landscape 128x128x16 nf=32 E=128"),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="bair64", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--vid-length", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import i2v_dist
+    import i2v_native
+    import i2v_synth as synth
+    from stage1_VAE.modules.decoder import Generator
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+
+    cfg = CONFIGS[args.config]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.set_grad_enabled(False)
+
+    per_gpu = args.batch or cfg["batch"]
+    total = per_gpu * world
+    # weights: deterministic synthetic (no checkpoints reachable), replicated on every rank
+    fsd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.flow_state_dict(seed=7, embedding_dim=cfg["emb"]).items()}
+    dsd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.decoder_state_dict(seed=7, channel_factor=cfg["nf"]).items()}
+    flow = ConditionalFlow(64, cfg["emb"], 512, 2, 20, conditioning_option="None")
+    flow.load_state_dict(fsd)
+    gen = Generator({"channel_factor": cfg["nf"], "z_dim": 64, "upsample_s": cfg["ups"], "upsample_t": cfg["upt"],
+                     "spectral_norm": True})
+    gen.load_state_dict(dsd)
+    flow, gen = flow.to(dev).eval(), gen.to(dev).eval()
+
+    # inputs drawn for the GLOBAL batch (CPU generators, fixed seeds), then sliced per rank and made resident
+    x0, residual, embed = synth.bench_inputs(total, cfg["img"], cfg["emb"])
+    lo, hi = i2v_dist.shard_bounds(total, world, rank)
+    x0_d, res_d, emb_d = x0[lo:hi].to(dev), residual[lo:hi].to(dev), embed[lo:hi].to(dev)
+
+    def step():
+        z = flow(res_d, emb_d, reverse=True).view(hi - lo, -1)
+        seq = gen(x0_d, z)
+        while seq.shape[1] < args.vid_length:
+            seq = torch.cat((seq, gen(seq[:, -1].contiguous(), z)), dim=1)
+        return i2v_dist.collate(seq, total)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    gen.native().set_profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = gen.native().get_profile()
+    gen.native().set_profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    frames_per_step = out.shape[0] * out.shape[1]
+    assert out.shape[0] == total
+
+    # cINN pass latency (device-timed, median of 50 after 5 warm-ups), rank 0 only
+    cinn = {}
+    if rank == 0:
+        for direction in ("inv", "fwd"):
+            fn = (lambda: flow(res_d, emb_d, reverse=True)) if direction == "inv" else (lambda: flow(res_d, emb_d))
+            for _ in range(5):
+                fn()
+            ts = []
+            for _ in range(50):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            cinn[direction + "_us"] = float(np.median(ts))
+    if rank == 0:
+        nb = hi - lo
+        cinn_bytes = flow.native().param_bytes + 4 * nb * (64 + cfg["emb"] + 64)
+        result = {
+            "metric": "synthesized frames/sec (BxT): cINN inverse + VAE decoder",
+            "value": frames_per_step * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded start frames / latents / embeddings, deterministic synthetic weights)",
+            "config": {"workload": f"{cfg['name']}, batch {per_gpu}/GPU, vid_length {args.vid_length}: "
+                                   "20-block cINN inverse + decoder pass(es)" + (" + RCCL all-gather" if world > 1 else ""),
+                       "global_batch": total, "frames_per_step": frames_per_step, "parallelism": f"batch-shard x{world}"},
+            "roofline": {
+                "kernel": "conv_mfma_f32_kernel (3x3x3 Conv3d implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma",
+                "achieved": prof["conv3_flops"] / (prof["conv3_ms"] * 1e-3) / 1e12 if prof["conv3_ms"] > 0 else None,
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": (prof["conv3_flops"] / (prof["conv3_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if prof["conv3_ms"] > 0 else None,
+                "traffic": None,
+                "launches": prof["conv3_launches"],
+                "avg_launch_ms": prof["conv3_ms"] / max(prof["conv3_launches"], 1),
+                "time_share": prof["conv3_ms"] * 1e-3 / dt,
+            },
+            "roofline_cinn": {
+                "kernel": "cINN inverse pass (flow_linear_kernel + flow_tail_kernel chain)",
+                "bound": "hbm", "bytes_per_pass": cinn_bytes,
+                "achieved": cinn_bytes / (cinn["inv_us"] * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": cinn_bytes / (cinn["inv_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                "inv_latency_us": cinn["inv_us"], "fwd_latency_us": cinn["fwd_us"], "batch": nb,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, fsd, dsd)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, fsd, dsd):
+    """The CPU oracle (torch-CPU port of the reference op sequence; W/sigma folded once, i.e. the "folded" variant of
+    SURVEY §8d -- not inflated by the reference's per-call renormalisation) on a bounded sample of the same workload."""
+    from oracle import decoder_ref, model_ref
+    import i2v_synth as synth
+    # one thread per physical core of one socket is what torch-CPU conv3d scales to; 256 SMT threads ran 4x slower
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    nb = 2
+    x0, residual, embed = synth.bench_inputs(nb, cfg["img"], cfg["emb"])
+    folded = decoder_ref.fold_spectral_norm(dsd)
+    model_ref.synthesize(fsd, folded, x0[:1], residual[:1], embed[:1], 16, cfg["ups"], cfg["upt"], faithful=False)  # warm-up
+    t0 = time.perf_counter()
+    seq = model_ref.synthesize(fsd, folded, x0, residual, embed, 16, cfg["ups"], cfg["upt"], faithful=False)
+    dt = time.perf_counter() - t0
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": seq.shape[0] * seq.shape[1] / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 warm call (after a batch-1 warm-up), batch {nb} x 16 frames, same geometry and weights (oracle/model_ref.synthesize, folded)",
+            "cpu": cpu, "seconds": dt}
+
+
+if __name__ == "__main__":
+    main()

@@ -182,7 +182,10 @@ struct i2v_dec {
     ConvWeights fc, zlin, conv_img;
     int Nz = 0;
     int profile = 0;
-    double prof_conv3_ms = 0, prof_conv3_flops = 0, prof_total_ms = 0;
+    struct ProfEv { hipEvent_t e0, e1; double flops; };
+    std::vector<ProfEv> prof_events;
+    double prof_conv3_ms = 0, prof_conv3_flops = 0;
+    long prof_conv3_launches = 0;
     // debug tap: copy one intermediate (channels-last) of one block out of the workspace during forward
     int tap_block = -1, tap_which = -1;
     float* tap_dst = nullptr;
@@ -256,24 +259,22 @@ int run_modulate(const float* x, const float* coef, const float* gb, float* out,
     return I2V_OK;
 }
 
+// Brackets one 3x3x3 conv launch with HIP events on the launch stream WITHOUT synchronising; the pairs are
+// resolved later by i2v_dec_get_profile (after the caller has synchronised the stream).
 struct ProfScope {
     i2v_dec* d;
     hipStream_t st;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr;
     double flops;
     ProfScope(i2v_dec* d_, hipStream_t st_, double flops_) : d(d_), st(st_), flops(flops_) {
-        if (d->profile) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+        if (d->profile) { (void)hipEventCreate(&e0); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
         if (d->profile) {
+            hipEvent_t e1 = nullptr;
+            (void)hipEventCreate(&e1);
             (void)hipEventRecord(e1, st);
-            (void)hipEventSynchronize(e1);
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            d->prof_conv3_ms += ms;
-            d->prof_conv3_flops += flops;
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
+            d->prof_events.push_back({e0, e1, flops});
         }
     }
 };
@@ -457,6 +458,8 @@ double i2v_dec_flops_per_sample(const i2v_dec* d, int32_t img_h, int32_t img_w) 
 int i2v_dec_set_profile(i2v_dec* d, int32_t on) {
     I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_set_profile: null");
     d->profile = on;
+    d->prof_conv3_ms = d->prof_conv3_flops = 0;
+    d->prof_conv3_launches = 0;
     return I2V_OK;
 }
 
@@ -466,11 +469,22 @@ int i2v_dec_debug_tap(i2v_dec* d, int32_t block, int32_t which, float* dst, size
     return I2V_OK;
 }
 
-int i2v_dec_get_profile(const i2v_dec* d, double* conv3_ms, double* conv3_flops, double* total_ms) {
+int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, int64_t* conv3_launches) {
     I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_get_profile: null");
+    for (auto& ev : d->prof_events) {
+        I2V_HIP_CHECK(hipEventSynchronize(ev.e1));
+        float ms = 0;
+        I2V_HIP_CHECK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+        d->prof_conv3_ms += ms;
+        d->prof_conv3_flops += ev.flops;
+        d->prof_conv3_launches += 1;
+        (void)hipEventDestroy(ev.e0);
+        (void)hipEventDestroy(ev.e1);
+    }
+    d->prof_events.clear();
     if (conv3_ms) *conv3_ms = d->prof_conv3_ms;
     if (conv3_flops) *conv3_flops = d->prof_conv3_flops;
-    if (total_ms) *total_ms = d->prof_total_ms;
+    if (conv3_launches) *conv3_launches = d->prof_conv3_launches;
     return I2V_OK;
 }
 
@@ -491,13 +505,6 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     double* sums1 = reinterpret_cast<double*>(ws + L.sums1);
     double* sums2 = reinterpret_cast<double*>(ws + L.sums2);
     int rc;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (d->profile) {
-        d->prof_conv3_ms = d->prof_conv3_flops = d->prof_total_ms = 0;
-        I2V_HIP_CHECK(hipEventCreate(&ev0));
-        I2V_HIP_CHECK(hipEventCreate(&ev1));
-        I2V_HIP_CHECK(hipEventRecord(ev0, st));
-    }
     // x = fc(motion).reshape(B, 16nf, 1, 4, 4) (decoder.py:99) -- written channels-last [B][1][4][4][16nf]
     if ((rc = conv_forward(d->fc, motion, d->cfg.z_dim, xA, nullptr, 1, 1, B, 1, 1, 1, EPI_NONE, st))) return rc;
     // all six ADAIN Linear(z_dim, 2C) in one GEMM (they depend only on z)
@@ -552,15 +559,6 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
         std::swap(x, xn);
     }
     if ((rc = conv3(d, d->conv_img, x, out, nullptr, 1, 1, B, d->lvl[5], EPI_FRAMES, st))) return rc;
-    if (d->profile) {
-        I2V_HIP_CHECK(hipEventRecord(ev1, st));
-        I2V_HIP_CHECK(hipEventSynchronize(ev1));
-        float ms = 0;
-        I2V_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-        d->prof_total_ms = ms;
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
-    }
     return I2V_OK;
 }
 

@@ -144,14 +144,16 @@ double i2v_dec_flops_per_sample(const i2v_dec* d, int32_t img_h, int32_t img_w);
  * img [B,3,img_h,img_w] (NCHW, [-1,1]), motion [B,z_dim] -> out [B,T,3,H,W] contiguous. */
 int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, const float* motion,
                     float* out, void* workspace, size_t workspace_bytes, int32_t batch, void* stream);
-/* Last-call per-kernel-class device time in ms (needs i2v_dec_set_profile(d,1), which makes the
- * forward synchronise; for bench/roofline only).  names: "conv3", "conv_other", "norm", "other". */
+/* Roofline instrumentation.  With profiling on, every 3x3x3 Conv3d launch (the dominant kernel) is bracketed by HIP
+ * events recorded on the launch stream -- no synchronisation is added to the forward.  After the caller has
+ * synchronised, i2v_dec_get_profile resolves the pending pairs and returns the totals since set_profile(d, 1):
+ * summed kernel time [ms], summed algorithmic FLOPs (2*M*N*K per launch) and the number of launches. */
 int i2v_dec_set_profile(i2v_dec* d, int32_t on);
+int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, int64_t* conv3_launches);
 /* Test hook: during the next forwards copy up to max_floats of one channels-last intermediate of GeneratorBlock
  * `block` (0 = head_0 .. 5 = g_4) into dst (device).  which: 0 = SPADE (1+gamma | beta) [B,H,W,2C], 1 = lrelu(Spade(x)),
  * 2 = conv_0 output, 3 = lrelu(ADAIN(.)), 4 = shortcut (low resolution), 5 = block output.  dst = NULL disables. */
 int i2v_dec_debug_tap(i2v_dec* d, int32_t block, int32_t which, float* dst, size_t max_floats);
-int i2v_dec_get_profile(const i2v_dec* d, double* conv3_ms, double* conv3_flops, double* total_ms);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,254 @@
+"""Parity of the HIP path (through the C ABI / the class-surface mirror) against the golden vectors generated from
+the reference modules and against the CPU oracle.  Run on the GPU box: pytest -m gpu.
+
+Tolerances (BASELINE.json north_star / SURVEY §8d): frames and z within 1e-4 relative L2, logdet within 1e-4
+abs-rel, flow round trip <= 1e-4 max-abs on the synthetic (expansive) flow."""
+import numpy as np
+import pytest
+import torch
+
+import i2v_synth as synth
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def T(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def sub(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    import i2v_native
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    i2v_native.lib()  # fails loudly if libi2v_hip.so is missing
+    torch.set_grad_enabled(False)
+
+
+def test_flow_leaf_modules_vs_golden():
+    from stage2_cINN.modules import flow_blocks as fb, modules as md
+    g, meta = load_golden("flow_units")
+    sd = T(synth.flow_state_dict(**meta["synth"]))
+    an = md.ActNorm(64, logdet=True)
+    an.load_state_dict(sub(sd, "sub_layers.0.norm_layer."))
+    an = an.cuda()
+    h, ld = an(cu(g["an_x"]))
+    assert rel_l2(h.cpu(), g["an_fwd"]) < 1e-6 and np.allclose(ld.cpu(), g["an_logdet"], rtol=1e-5)
+    assert rel_l2(an(cu(g["an_x"]), reverse=True).cpu(), g["an_rev"]) < 1e-6
+    # quirk Q1: data-dependent init on the first forward, in eval mode
+    an0 = md.ActNorm(64, logdet=True).cuda().eval()
+    h0, ld0 = an0(cu(g["an0_x"]))
+    assert int(an0.initialized.item()) == 1
+    assert rel_l2(an0.loc.reshape(-1).cpu(), g["an0_loc"]) < 1e-5 and rel_l2(an0.scale.reshape(-1).cpu(), g["an0_scale"]) < 1e-5
+    assert rel_l2(h0.cpu(), g["an0_fwd"]) < 1e-5 and np.allclose(ld0.cpu(), g["an0_logdet"], rtol=1e-4, atol=1e-4)
+    act = fb.InvLeakyRelu()
+    ha, lda = act(cu(g["act_x"]))
+    assert lda == 0.0 and np.array_equal(ha.cpu().numpy(), g["act_fwd"])  # quirk Q2
+    assert rel_l2(act(cu(g["act_x"]), reverse=True).cpu(), g["act_rev"]) < 1e-6
+    sh = fb.Shuffle(64)
+    sh.load_state_dict(sub(sd, "sub_layers.0.shuffle."))
+    sh = sh.cuda()
+    y, ld = sh(cu(g["sh_x"]))
+    assert ld == 0 and np.array_equal(y.cpu().numpy(), g["sh_fwd"])
+    assert np.array_equal(sh(cu(g["sh_x"]), reverse=True).cpu().numpy(), g["sh_rev"])
+    net = md.BasicFullyConnectedNet(dim=96, depth=2, hidden_dim=512, out_dim=32)
+    net.load_state_dict(sub(sd, "sub_layers.0.coupling.s.0."))
+    assert rel_l2(net.cuda()(cu(g["mlp_x"])).cpu(), g["mlp_y"]) < TOL
+
+
+def test_coupling_and_block_vs_golden():
+    from stage2_cINN.modules import flow_blocks as fb
+    g, meta = load_golden("flow_units")
+    sd = T(synth.flow_state_dict(**meta["synth"]))
+    x4, e4 = cu(g["cpl_x"])[:, :, None, None], cu(g["cpl_e"])[:, :, None, None]
+    cb = fb.ConditionalDoubleVectorCouplingBlock(64, 64, 512, 2, mode="normal")
+    cb.load_state_dict(sub(sd, "sub_layers.1.coupling."))
+    cb = cb.cuda()
+    y, ld = cb(x4, e4)
+    assert y.shape == (6, 64) and rel_l2(y.cpu(), g["cpl_fwd"]) < TOL and np.allclose(ld.cpu(), g["cpl_logdet"], atol=1e-4)
+    r = cb(x4, e4, reverse=True)
+    assert r.shape == (6, 64, 1, 1) and rel_l2(r.reshape(6, 64).cpu(), g["cpl_rev"]) < TOL
+    with pytest.raises(AssertionError):
+        cb(x4.reshape(6, 64), e4)  # flow_blocks.py:78-79 asserts 4-D inputs
+    sdc = T(synth.flow_state_dict(**meta["synth_cond"]))
+    cbc = fb.ConditionalDoubleVectorCouplingBlock(64, 94, 512, 2, mode="cond")
+    cbc.load_state_dict(sub(sdc, "sub_layers.1.coupling."))
+    cbc = cbc.cuda()
+    ec = cu(g["cplc_e"])[:, :, None, None]
+    y, ld = cbc(x4, ec)
+    assert rel_l2(y.cpu(), g["cplc_fwd"]) < TOL and np.allclose(ld.cpu(), g["cplc_logdet"], atol=1e-4)
+    assert rel_l2(cbc(x4, ec, reverse=True).reshape(6, 64).cpu(), g["cplc_rev"]) < TOL
+    blk = fb.ConditionalFlatDoubleCouplingFlowBlock(64, 64, 512, 2)
+    blk.load_state_dict(sub(sd, "sub_layers.1."))
+    blk = blk.cuda()
+    y, ld = blk(x4, e4)
+    assert rel_l2(y.cpu(), g["blk_fwd"]) < TOL and np.allclose(ld.cpu(), g["blk_logdet"], atol=1e-4)
+    assert rel_l2(blk(x4, e4, reverse=True).reshape(6, 64).cpu(), g["blk_rev"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["flow_full_e64", "flow_full_e128", "flow_full_ctrl"])
+def test_full_flow_vs_golden(name):
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    g, meta = load_golden(name)
+    a = meta["synth"]
+    flow = ConditionalFlow(64, a["embedding_dim"], 512, 2, 20, conditioning_option="None", control=a["control"])
+    flow.load_state_dict(T(synth.flow_state_dict(**a)))
+    flow = flow.cuda().eval()
+    x, e = cu(g["x"]), cu(g["e"])
+    zt, ld = flow(x, e)
+    assert list(zt.shape) == list(g["fwd_shape"]) and ld.shape == (8,)
+    assert rel_l2(zt.reshape(8, 64).cpu(), g["fwd"]) < TOL
+    assert np.allclose(ld.cpu(), g["logdet"], rtol=1e-4, atol=1e-4)
+    z = flow(x, e, reverse=True)
+    assert list(z.shape) == list(g["rev_shape"])
+    assert rel_l2(z.reshape(8, 64).cpu(), g["rev"]) < TOL
+    assert rel_l2(flow.reverse(x, e).reshape(8, 64).cpu(), g["rev"]) < TOL
+    rt = flow(zt, e, reverse=True).reshape(8, 64)
+    assert float((rt - x).abs().max()) < 1e-4  # invertibility
+    # second call replays the captured graph; results must be identical
+    assert torch.equal(flow(x, e, reverse=True), z)
+
+
+def test_flow_batch_sizes_and_sharding_property():
+    """Full-width flow at the BASELINE batch (64) vs the oracle, ragged batches, and batch-permutation
+    equivariance (proves shardability)."""
+    from oracle import flow_ref
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    sd = T(synth.flow_state_dict(seed=7, embedding_dim=64))
+    flow = ConditionalFlow(64, 64, 512, 2, 20, conditioning_option="None")
+    flow.load_state_dict(sd)
+    flow = flow.cuda().eval()
+    _, residual, embed = synth.bench_inputs(64, 64, 64)
+    ref = flow_ref.flow_reverse(sd, residual, embed).reshape(64, 64)
+    z = flow(residual.cuda(), embed.cuda(), reverse=True).reshape(64, 64)
+    assert rel_l2(z.cpu(), ref) < TOL
+    for lo, hi in ((0, 1), (3, 10), (0, 37)):  # shards: same rows, any batch size incl. 1 and non-multiples of 64
+        zs = flow(residual[lo:hi].cuda().contiguous(), embed[lo:hi].cuda().contiguous(), reverse=True).reshape(hi - lo, 64)
+        assert rel_l2(zs.cpu(), ref[lo:hi]) < TOL
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(0))
+    zp = flow(residual[perm].cuda(), embed[perm].cuda(), reverse=True).reshape(64, 64)
+    assert torch.equal(zp.cpu(), z.cpu()[perm])
+    zt, ld = flow(residual[:11].cuda().contiguous(), embed[:11].cuda().contiguous())  # forward, ragged B = 11
+    ztr, ldr = flow_ref.flow_forward(sd, residual[:11], embed[:11])
+    assert rel_l2(zt.reshape(11, 64).cpu(), ztr.reshape(11, 64)) < TOL and np.allclose(ld.cpu(), ldr, rtol=1e-4, atol=1e-4)
+
+
+def _gen(meta):
+    from stage1_VAE.modules.decoder import Generator
+    gen = Generator({"channel_factor": meta["synth"]["channel_factor"], "z_dim": 64, "upsample_s": meta["upsample_s"],
+                     "upsample_t": meta["upsample_t"], "spectral_norm": True})
+    gen.load_state_dict(T(synth.decoder_state_dict(**meta["synth"])))
+    return gen.cuda().eval()
+
+
+def test_decoder_nf8_bair_vs_golden():
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    out = gen(cu(g["img"]), cu(g["z"]))
+    assert out.shape == (2, 16, 3, 64, 64) and out.is_contiguous()
+    assert rel_l2(out.cpu(), g["out"]) < TOL
+    assert float(out.abs().max()) < 1.0  # tanh range
+    # batch-permutation equivariance and batch-size independence (B = 1 shard of a B = 2 batch): bit-identical
+    perm = torch.tensor([1, 0])
+    out2 = gen(cu(g["img"])[perm].contiguous(), cu(g["z"])[perm].contiguous())
+    assert torch.equal(out2, out[perm])
+    out1 = gen(cu(g["img"])[1:].contiguous(), cu(g["z"])[1:].contiguous())
+    assert torch.equal(out1, out[1:])
+
+
+def test_decoder_nf8_128_vs_golden():
+    g, meta = load_golden("dec_nf8_128")
+    out = _gen(meta)(cu(g["img"]), cu(g["z"]))
+    assert out.shape == (1, 16, 3, 128, 128)
+    assert rel_l2(out[..., ::2, ::2].cpu(), g["out_s2"]) < TOL
+
+
+def test_decoder_full_width_bair_vs_golden():
+    g, meta = load_golden("dec_nf64_bair")
+    out = _gen(meta)(cu(g["img"]), cu(g["z"]))
+    assert out.shape == (1, 16, 3, 64, 64)
+    assert rel_l2(out[..., ::2, ::2].cpu(), g["out_s2"]) < TOL
+
+
+def test_decoder_full_width_128_vs_golden():
+    g, meta = load_golden("dec_nf32_128")
+    out = _gen(meta)(cu(g["img"]), cu(g["z"]))
+    assert out.shape == (1, 16, 3, 128, 128)
+    assert rel_l2(out[..., ::2, ::2].cpu(), g["out_s2"]) < TOL
+
+
+def test_decoder_negative_sigma_and_resized_start_frame():
+    """Signed sigma (quirk D6) folded exactly, and a start frame whose size differs from the SPADE resolutions
+    (bilinear resize path) -- vs the oracle."""
+    from oracle import decoder_ref
+    from stage1_VAE.modules.decoder import Generator
+    args = dict(seed=3, channel_factor=8, negative_sigma=["g_1.conv_0", "g_1.conv_s", "g_3.conv_1"])
+    sd = T(synth.decoder_state_dict(**args))
+    gen = Generator({"channel_factor": 8, "z_dim": 64, "upsample_s": [2, 1], "upsample_t": [2, 1], "spectral_norm": True})
+    gen.load_state_dict(sd)
+    gen = gen.cuda().eval()
+    img = 2 * torch.rand(3, 3, 48, 80, generator=torch.Generator().manual_seed(5)) - 1
+    z = torch.randn(3, 64, generator=torch.Generator().manual_seed(6))
+    ref = decoder_ref.generator(sd, img, z)
+    out = gen(img.cuda(), z.cuda())
+    assert rel_l2(out.cpu(), ref) < TOL
+
+
+def test_model_forward_semantics_vs_golden(tmp_path):
+    """get_model.Model from YAML + checkpoints on disk: T = 32 autoregressive, quirk Q3 batch slice."""
+    import yaml
+    from get_model import Model
+    g, meta = load_golden("model_nf8")
+    s1 = tmp_path / "stage1" / "run"
+    s2 = tmp_path / "stage2"
+    s1.mkdir(parents=True)
+    s2.mkdir()
+    (s1 / "config_stage1.yaml").write_text(yaml.safe_dump({"Decoder": {
+        "channel_factor": 8, "z_dim": 64, "upsample_s": meta["upsample_s"], "upsample_t": meta["upsample_t"], "spectral_norm": True}}))
+    torch.save({"state_dict": T(synth.decoder_state_dict(**meta["synth_dec"]))}, s1 / "best_PFVD_GEN.pth")
+    (s2 / "config_stage2.yaml").write_text(yaml.safe_dump({
+        "Flow": {"n_flows": 20, "flow_hidden_depth": 2, "flow_mid_channels_factor": 8},
+        "Conditioning_Model": {"z_dim": 64, "checkpoint_name": "Encoder_stage2", "model_name": "ae/", "model_path": str(tmp_path) + "/"},
+        "First_stage_model": {"checkpoint_decoder": "best_PFVD_GEN", "checkpoint_encoder": "best_PFVD_ENC",
+                              "model_name": "run", "model_path": str(tmp_path / "stage1") + "/"},
+        "Training": {"bs": 50}, "Data": {"img_size": 64}}))
+    torch.save({"state_dict": T(synth.flow_state_dict(**meta["synth_flow"]))}, s2 / "cINN.pth")
+    model = Model(str(s2) + "/", 32)
+    y32 = model(cu(g["x1"]), residual=cu(g["r1"]), embed=cu(g["e1"]))
+    assert y32.shape == (1, 32, 3, 64, 64) and rel_l2(y32.cpu(), g["y32"]) < TOL
+    model.vid_length = 2
+    yq3 = model(cu(g["x3"]), residual=cu(g["r3"]), embed=cu(g["e3"]))
+    assert list(yq3.shape) == list(g["yq3_shape"])  # B=3 > vid_length=2: two SAMPLES come back (Q3)
+    assert rel_l2(yq3[:, ::4].cpu(), g["yq3_t4"]) < TOL
+    model.vid_length = 20
+    assert list(model(cu(g["x1"]), residual=cu(g["r1"]), embed=cu(g["e1"])).shape) == list(g["y20_shape"])
+    assert model.synthesize(cu(g["x3"]), residual=cu(g["r3"]), embed=cu(g["e3"])).shape[0] == 3
+
+
+def test_full_size_properties_bair_b8():
+    """BASELINE geometry (nf = 64, 64x64x16) at a batch the oracle cannot finish quickly: size-independent properties.
+    Shards of the batch reproduce the rows of the full batch bit-for-bit; output in (-1, 1); finite."""
+    from stage1_VAE.modules.decoder import Generator
+    gen = Generator({"channel_factor": 64, "z_dim": 64, "upsample_s": [2, 1], "upsample_t": [2, 1], "spectral_norm": True})
+    gen.load_state_dict(T(synth.decoder_state_dict(seed=7, channel_factor=64)))
+    gen = gen.cuda().eval()
+    x0, residual, _ = synth.bench_inputs(8, 64, 64)
+    out = gen(x0.cuda(), residual.cuda())
+    assert out.shape == (8, 16, 3, 64, 64) and bool(torch.isfinite(out).all()) and float(out.abs().max()) <= 1.0
+    lo = gen(x0[:3].cuda().contiguous(), residual[:3].cuda().contiguous())
+    hi = gen(x0[3:].cuda().contiguous(), residual[3:].cuda().contiguous())
+    assert torch.equal(torch.cat((lo, hi)), out)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
