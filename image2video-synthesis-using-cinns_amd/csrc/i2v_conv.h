@@ -45,4 +45,17 @@ struct ConvArgs {
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
                  int B, int T, int H, int W, int epi, hipStream_t st);
 
+// ---- split-fp16 path (i2v_conv16.hip): operands carried as (fp16 hi, fp16 lo * 2^11) pairs, 3 fp16 MFMAs per product
+struct Conv16Weights {
+    DevBuf w;      // [tap][chunk32][CoutPad][4 groups x (8 hi | 8 lo) fp16] = 128 B per (n, chunk)
+    DevBuf bias;
+    int Cin = 0, Cout = 0, CoutPad = 0, nchunk = 0;
+    int KT = 1, KH = 1, KW = 1;
+    int pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, int kh, int kw, double scale);
+};
+
+// in_hl16: channels-last activations in the hl16 format (4 bytes per element, Cin % 8 == 0); out: fp32 channels-last.
+int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
+                   int H, int W, int epi, hipStream_t st);
+
 }  // namespace i2v

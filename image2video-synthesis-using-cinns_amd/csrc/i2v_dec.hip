@@ -127,6 +127,49 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
     }
 }
 
+// Same as modulate_kernel, but writes the result in the split-fp16 operand format of i2v_conv16.hip ("hl16": per 8
+// channels 8 x fp16 hi | 8 x fp16 lo*2^11); one thread = one position x 8 channels (32 bytes in, 32 bytes out).
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void modulate_hl16_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
+                                                            const float* __restrict__ gb, char* __restrict__ out, int B, int T,
+                                                            int H, int W, int C, int ut, int us, int lrelu) {
+    const int C8 = C >> 3;
+    const long total = (long)B * T * H * W * C8;
+    const int Tl = T / ut, Hl = H / us, Wl = W / us;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long p = i / C8;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H); p /= H;
+        const int t = (int)(p % T);
+        const int b = (int)(p / T);
+        const float* xp = x + ((((long)b * Tl + t / ut) * Hl + h / us) * Wl + w / us) * C + 8 * c8;
+        const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 4);
+        float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const float2* cp = coef + (long)b * C + 8 * c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float2 ab = cp[j]; r[j] = fmaf(r[j], ab.x, ab.y); }
+        if (gb) {
+            const float* g = gb + (((long)b * H + h) * W + w) * (2 * C) + 8 * c8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = fmaf(r[j], g[j], g[C + j]);
+        }
+        half8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = r[j];
+            if (lrelu) v = v >= 0.f ? v : 0.2f * v;
+            const _Float16 hh = (_Float16)v;
+            hi[j] = hh;
+            lo[j] = (_Float16)((v - (float)hh) * 2048.0f);
+        }
+        char* o = out + i * 32;
+        *reinterpret_cast<half8_t*>(o) = hi;
+        *reinterpret_cast<half8_t*>(o + 16) = lo;
+    }
+}
+
 // F.interpolate(img, size=(h,w), mode='bilinear', align_corners=True) (normalization_layer.py:20), written
 // channels-last with the 3 colour channels zero-padded to 16 (the conv kernel's K chunk).
 __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo) {
@@ -165,6 +208,7 @@ struct Block {
     bool learned = false;
     int groups_spade = 16;
     ConvWeights conv0, conv1, convs, sp_conv, sp_gb;
+    Conv16Weights conv0_16, conv1_16;  // split-fp16 variants (cfg.mma == 1)
     DevBuf gn_w, gn_b;
     int zoff = 0;  // offset of this block's ADAIN (gamma|beta) in the z-GEMM output
 };
@@ -249,7 +293,15 @@ int run_coef(const double* sums, float* coef, int B, int C, int groups, double c
 }
 
 int run_modulate(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
-                 int us, int lrelu, hipStream_t st) {
+                 int us, int lrelu, hipStream_t st, bool hl16 = false) {
+    if (hl16) {
+        const long tot8 = (long)B * T * H * W * (C / 8);
+        long nb = std::min<long>((tot8 + 255) / 256, 65536);
+        hipLaunchKernelGGL(modulate_hl16_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
+                           reinterpret_cast<char*>(out), B, T, H, W, C, ut, us, lrelu);
+        I2V_HIP_CHECK(hipGetLastError());
+        return I2V_OK;
+    }
     const long total = (long)B * T * H * W * (C / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
@@ -285,8 +337,15 @@ int conv3(i2v_dec* d, const ConvWeights& w, const float* in, float* out, const f
     return conv_forward(w, in, w.Cin, out, res, rt, rs, B, l.T, l.H, l.W, epi, st);
 }
 
+int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* out, const float* res, int rt, int rs, int B,
+             const Level& l, int epi, hipStream_t st) {
+    ProfScope ps(d, st, 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0);
+    return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st);
+}
+
+template <class WT>
 int sn_pack(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, int k, bool has_bias,
-            ConvWeights& out) {
+            WT& out) {
     const int64_t numel = (int64_t)cout * cin * k * k * k;
     const float* bias = nullptr;
     if (has_bias) { bias = sd.f32(name + ".bias", cout); if (!bias) return I2V_E_MISSING; }
@@ -327,7 +386,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
         I2V_REQUIRE((s == 1 || s == 2 || s == 4) && (t == 1 || t == 2 || t == 4), I2V_E_INVALID,
                     "i2v_dec_create: upsample factors must be 1, 2 or 4");
     }
-    I2V_REQUIRE(cfg->mma == 0, I2V_E_INVALID, "i2v_dec_create: mma mode %d not available in this build", cfg->mma);
+    I2V_REQUIRE(cfg->mma == 0 || cfg->mma == 1, I2V_E_INVALID, "i2v_dec_create: unknown mma mode %d", cfg->mma);
     int ndev = 0;
     I2V_HIP_CHECK(hipGetDeviceCount(&ndev));
     I2V_REQUIRE(ndev > 0, I2V_E_HIP, "i2v_dec_create: no HIP device");
@@ -384,8 +443,13 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
     for (int k = 0; k < 6; ++k) {
         Block& b = d->blk[k];
         const std::string p = b.name + ".";
-        if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
-        if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
+        if (d->cfg.mma == 1) {
+            if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0_16))) return rc;
+            if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1_16))) return rc;
+        } else {
+            if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
+            if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
+        }
         if (b.learned) {
             if ((rc = sn_pack(sd, p + "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs))) return rc;
             const float* gw = sd.f32(p + "norm_s.bn.weight", b.n_in);
@@ -534,14 +598,17 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
         if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
         if ((rc = conv_forward(b.sp_gb, y1, 128, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
         if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
-        if ((rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st))) return rc;
+        const bool f16 = d->cfg.mma == 1;
+        if ((rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16))) return rc;
         if ((rc = tap(k, 1, a, (size_t)B * P * b.n_in))) return rc;
-        if ((rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st))) return rc;
+        if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
+        else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
+        if (rc) return rc;
         if ((rc = tap(k, 2, dx, (size_t)B * P * b.n_mid))) return rc;
         // ADAIN (normalization_layer.py:47-51) + leaky_relu
         if ((rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
         if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, d->Nz, b.zoff, nullptr, nullptr, st))) return rc;
-        if ((rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st))) return rc;
+        if ((rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16))) return rc;
         if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
         // shortcut (decoder.py:44-49) at low resolution
         const float* res = x;
@@ -554,7 +621,9 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
             if ((rc = tap(k, 4, xs_low, (size_t)B * Pl * b.n_out))) return rc;
         }
         // g_4's output only feeds conv_img(leaky_relu(x)) (decoder.py:117): fuse the activation here
-        if ((rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st))) return rc;
+        if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st);
+        else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st);
+        if (rc) return rc;
         if ((rc = tap(k, 5, xn, (size_t)B * P * b.n_out))) return rc;
         std::swap(x, xn);
     }

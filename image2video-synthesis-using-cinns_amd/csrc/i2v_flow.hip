@@ -46,19 +46,21 @@ struct TailArgs {
     int do_swap;
 };
 
-__global__ __launch_bounds__(256) void flow_tail_kernel(TailArgs a) {
-    __shared__ float part[4][64];
+constexpr int TAIL_WAVES = 16;
+
+__global__ __launch_bounds__(64 * TAIL_WAVES) void flow_tail_kernel(TailArgs a) {
+    __shared__ float part[TAIL_WAVES][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
     if (a.h) {
-        // last Linear: lane = (net, c); 4 waves split K = H
+        // last Linear: lane = (net, c); the waves split K = H, all of a wave's loads are in flight together
         const int net = lane >> 5;
-        const int kc = a.H / 4;
+        const int kc = a.H / TAIL_WAVES;
         const float* hp = a.h + ((long)net * a.H + (long)w * kc) * a.B + b;
         const float* wp = a.W3T + (long)w * kc * 64 + lane;
         float acc = 0.f;
-#pragma unroll 8
+#pragma unroll 16
         for (int k = 0; k < kc; ++k) acc = fmaf(hp[(long)k * a.B], wp[k * 64], acc);
         part[w][lane] = acc;
     }
@@ -66,7 +68,9 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(TailArgs a) {
     if (w != 0) return;
     float x = a.x[(long)b * 64 + lane];
     if (a.h) {
-        const float st = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] + a.b3[lane];
+        float st = a.b3[lane];
+#pragma unroll
+        for (int q = 0; q < TAIL_WAVES; ++q) st += part[q][lane];
         // lanes 0..31 hold s[c], lanes 32..63 hold t[c]; the transformed half is x[32..63]
         const float s = __shfl(st, lane & 31);
         if (lane >= 32) x = a.reverse ? (x - st) * expf(-s) : fmaf(x, expf(s), st);
@@ -91,6 +95,15 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(TailArgs a) {
     }
     if (a.do_swap) x = __shfl(x, lane ^ 32);                // chunk / cat[::-1], flow_blocks.py:86,99
     a.x[(long)b * 64 + lane] = x;
+}
+
+// ingest / egress between caller tensors and the workspace-resident state (a hipMemcpyAsync costs ~12 us each here)
+__global__ void flow_copy2_kernel(const float* __restrict__ a, float* __restrict__ da, int na, const float* __restrict__ b,
+                                  float* __restrict__ db, int nb) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {
+        if (i < na) da[i] = a[i];
+        else db[i - na] = b[i - na];
+    }
 }
 
 }  // namespace i2v
@@ -189,7 +202,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         t.an_logdet = an_block >= 0 ? f->an_logdet[an_block] : 0.f;
         t.do_lrelu = lrelu ? 1 : 0;
         t.do_swap = swap ? 1 : 0;
-        hipLaunchKernelGGL(flow_tail_kernel, dim3(B), dim3(256), 0, st, t);
+        hipLaunchKernelGGL(flow_tail_kernel, dim3(B), dim3(64 * TAIL_WAVES), 0, st, t);
         I2V_HIP_CHECK(hipGetLastError());
         return I2V_OK;
     };
@@ -277,8 +290,12 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_flow: workspace %zu < required %zu",
                 workspace_bytes, L.total);
     char* ws = static_cast<char*>(workspace);
-    I2V_HIP_CHECK(hipMemcpyAsync(ws + L.x, xin, (size_t)B * 64 * 4, hipMemcpyDeviceToDevice, st));
-    I2V_HIP_CHECK(hipMemcpyAsync(ws + L.embed, embed, (size_t)B * f->E * 4, hipMemcpyDeviceToDevice, st));
+    {
+        const int na = B * 64, nb = B * f->E;
+        hipLaunchKernelGGL(flow_copy2_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, st, xin,
+                           reinterpret_cast<float*>(ws + L.x), na, embed, reinterpret_cast<float*>(ws + L.embed), nb);
+        I2V_HIP_CHECK(hipGetLastError());
+    }
     if (f->cfg.use_graph) {
         if (!(f->gexec && f->g_reverse == (int)reverse && f->g_B == B && f->g_ws == workspace)) {
             if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
@@ -301,8 +318,13 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
         int rc = enqueue_chain(f, reverse, ws, B, st);
         if (rc) return rc;
     }
-    I2V_HIP_CHECK(hipMemcpyAsync(xout, ws + L.x, (size_t)B * 64 * 4, hipMemcpyDeviceToDevice, st));
-    if (logdet) I2V_HIP_CHECK(hipMemcpyAsync(logdet, ws + L.logdet, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    {
+        const int na = B * 64, nb = logdet ? B : 0;
+        hipLaunchKernelGGL(flow_copy2_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(ws + L.x), xout, na, reinterpret_cast<const float*>(ws + L.logdet),
+                           logdet, nb);
+        I2V_HIP_CHECK(hipGetLastError());
+    }
     return I2V_OK;
 }
 
@@ -314,9 +336,9 @@ int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out) {
     I2V_REQUIRE(cfg && out, I2V_E_INVALID, "i2v_flow_create: null argument");
     I2V_REQUIRE(cfg->in_channels == 64, I2V_E_INVALID,
                 "i2v_flow_create: in_channels must be 64 (lane <-> channel mapping), got %d", cfg->in_channels);
-    I2V_REQUIRE(cfg->hidden_dim >= 64 && cfg->hidden_dim % 64 == 0, I2V_E_INVALID,
-                "i2v_flow_create: hidden_dim must be a positive multiple of 64, got %d", cfg->hidden_dim);
-    I2V_REQUIRE(cfg->embedding_dim > 0 && cfg->hidden_depth >= 0 && cfg->n_flows > 0, I2V_E_INVALID,
+    I2V_REQUIRE(cfg->hidden_dim >= 64 && cfg->hidden_dim % 64 == 0 && cfg->hidden_dim <= LIN_MAXK, I2V_E_INVALID,
+                "i2v_flow_create: hidden_dim must be a multiple of 64 in [64, %d], got %d", LIN_MAXK, cfg->hidden_dim);
+    I2V_REQUIRE(cfg->embedding_dim > 0 && cfg->embedding_dim <= LIN_MAXK && cfg->hidden_depth >= 0 && cfg->n_flows > 0, I2V_E_INVALID,
                 "i2v_flow_create: bad embedding_dim/hidden_depth/n_flows");
     int ndev = 0;
     I2V_HIP_CHECK(hipGetDeviceCount(&ndev));

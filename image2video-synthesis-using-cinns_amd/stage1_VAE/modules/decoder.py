@@ -4,6 +4,8 @@
 activations stay channels-last in HBM, spectral-norm is folded at load time, the 3x3x3 convolutions run on the
 gfx950 matrix cores.  The sub-modules carry the reference's state_dict keys (``g_k.conv_0.weight_orig`` ...) so
 released ``.pth`` files load unchanged."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -61,7 +63,10 @@ class Generator(NativeBacked):
         self.g_3 = GeneratorBlock(4 * nf, 2 * nf, use_spectral, self.z_dim)
         self.g_4 = GeneratorBlock(2 * nf, 1 * nf, use_spectral, self.z_dim)
         self.conv_img = ConvParams(nf, 3, 3, 3, bias=True, spectral=False)
-        self.mma = int(dic.get("mma", 0)) if hasattr(dic, "get") else 0
+        # matrix-core mode of the 3x3x3 convolutions: 0 = exact fp32 MFMA, 1 = split-fp16 (3 fp16 MFMAs per product,
+        # fp32-class accuracy, ~5x the rate).  Not a reference key: taken from dic["mma"] or the I2V_DEC_MMA env var.
+        mma = dic.get("mma", None) if hasattr(dic, "get") else None
+        self.mma = int(os.environ.get("I2V_DEC_MMA", "1")) if mma is None else int(mma)
 
     def _build_native(self):
         h = native.NativeDecoder(self.channel_factor, self.z_dim, self.upsample_s, self.upsample_t, self.use_spectral,

@@ -86,25 +86,31 @@ def cl(x):  # NCDHW -> channels-last flat
     return x.permute(0, 2, 3, 4, 1).contiguous()
 
 
-def diag_decoder(nf, ups, upt, img_size, B, seed=5, taps=True):
-    print(f"== decoder nf={nf} ups={ups} img={img_size} B={B}")
+def diag_decoder(nf, ups, upt, img_size, B, seed=5, taps=True, mma=0, oracle=True):
+    print(f"== decoder nf={nf} ups={ups} img={img_size} B={B} mma={mma}")
     sd = T(synth.decoder_state_dict(seed=seed, channel_factor=nf))
     img = 2 * torch.rand(B, 3, img_size, img_size, generator=torch.Generator().manual_seed(41)) - 1
     z = torch.randn(B, 64, generator=torch.Generator().manual_seed(42))
-    t0 = time.time()
-    ref = decoder_ref.generator(sd, img, z, ups, upt, faithful=False)
-    print(f"  oracle {time.time() - t0:.1f}s")
-    h = native.NativeDecoder(nf, 64, ups, upt, True)
+    h = native.NativeDecoder(nf, 64, ups, upt, True, mma=mma)
     h.load(sd)
     img_d, z_d = img.to(dev), z.to(dev)
     out = h.forward(img_d, z_d)
     torch.cuda.synchronize()
-    report("final frames", out, ref)
+    if oracle:
+        t0 = time.time()
+        ref = decoder_ref.generator(sd, img, z, ups, upt, faithful=False)
+        print(f"  oracle {time.time() - t0:.1f}s")
+        report("final frames", out, ref)
+    else:
+        h0 = native.NativeDecoder(nf, 64, ups, upt, True, mma=0)
+        h0.load(sd)
+        report("final frames vs fp32-MFMA path", out, h0.forward(img_d, z_d))
+        del h0
     if taps:
         folded = decoder_ref.fold_spectral_norm(sd)
         blocks = oracle_blocks(folded, img, z, ups, upt)
         for k in range(6):
-            for which, nm in ((1, "lrelu(spade)"), (2, "conv_0"), (3, "lrelu(adain)"), (5, "block out")):
+            for which, nm in (((1, "lrelu(spade)"), (2, "conv_0"), (3, "lrelu(adain)"), (5, "block out")) if mma == 0 else ((2, "conv_0"), (5, "block out"))):
                 r = cl(blocks[k][which])
                 dst = torch.zeros(r.numel(), dtype=torch.float32, device=dev)
                 h.debug_tap(k, which, dst)
@@ -162,3 +168,10 @@ if __name__ == "__main__":
         diag_decoder(64, [2, 1], [2, 1], 64, 1, seed=7, taps=False)
     if "dec64b8" in which:
         diag_decoder(64, [2, 1], [2, 1], 64, 8, seed=7, taps=False)
+    if "f16" in which:
+        diag_decoder(8, [2, 1], [2, 1], 64, 2, mma=1)
+        diag_decoder(8, [2, 2], [2, 1], 128, 1, seed=6, taps=False, mma=1)
+        diag_decoder(64, [2, 1], [2, 1], 64, 1, seed=7, taps=False, mma=1)
+        diag_decoder(32, [2, 2], [2, 1], 128, 1, seed=7, taps=False, mma=1)
+        diag_decoder(64, [2, 1], [2, 1], 64, 16, seed=7, taps=False, mma=1, oracle=False)
+        diag_decoder(64, [2, 1], [2, 1], 64, 16, seed=7, taps=False, mma=0, oracle=False)
