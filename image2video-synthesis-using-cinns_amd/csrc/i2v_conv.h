@@ -56,6 +56,6 @@ struct Conv16Weights {
 
 // in_hl16: channels-last activations in the hl16 format (4 bytes per element, Cin % 8 == 0); out: fp32 channels-last.
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st);
+                   int H, int W, int epi, hipStream_t st, int ablate = 0);
 
 }  // namespace i2v

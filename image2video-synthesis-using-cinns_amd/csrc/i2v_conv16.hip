@@ -28,6 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int C16_BM = 256, C16_KC = 32;
 constexpr int C16_ROW = 144;  // bytes per staged row: 32 channels x 4 B + 16 B pad
+constexpr int C16_SLOTS = 12; // prefetched 16-byte input pieces per thread and chunk (768 halo rows); larger bricks
+                              // stage the remainder synchronously
 
 struct Conv16Args {
     const char* in;   // hl16 channels-last [B][T][H][W][Cin]
@@ -38,10 +40,33 @@ struct Conv16Args {
     int B, T, H, W, Cin, Cout, CoutPad, nchunk;
     int KT, KH, KW, tap_base;
     int TB, TT, TH, TW, nbB, nbT, nbH, nbW;
+    int HWp;   // halo row pitch in positions (>= TW + KW - 1; 12 for 8-wide bricks: conflict-free 4x4 patches)
+    int patch; // 1: MFMA rows are assigned to brick positions in 4x4 (h,w) patches per ds_read_b128 lane group
     int rt, rs, epi;
 };
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+// MFMA tile row (0..255 within the workgroup tile) -> linear brick index m = ((ib*TT + it)*TH + ih)*TW + iw.
+// ds_read_b128 services a wave in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with `patch` every
+// group reads one 4x4 (h,w) patch, whose 16 rows (pitch 12 positions x 144 B) fall on 16 distinct bank quads.
+__device__ __forceinline__ int brick_index(int row, int TH, int TW, int patch) {
+    if (!patch) return row;
+    const int i = row & 31, tile = row >> 5;
+    int grp, q;
+    if (i < 4) { grp = 0; q = i; }
+    else if (i < 12) { grp = 1; q = i - 4; }
+    else if (i < 16) { grp = 0; q = i - 8; }
+    else if (i < 20) { grp = 1; q = i - 8; }
+    else if (i < 28) { grp = 0; q = i - 12; }
+    else { grp = 1; q = i - 16; }
+    const int pidx = tile * 2 + grp;           // 4x4 patch number inside the workgroup tile (TH, TW multiples of 4)
+    const int pw = TW >> 2, ph = TH >> 2;
+    const int px = pidx % pw, py = (pidx / pw) % ph, plane = pidx / (pw * ph);
+    return (plane * TH + py * 4 + (q >> 2)) * TW + px * 4 + (q & 3);
+}
+
+// ABL: ablation switches for tools/conv16_bench (0 in the product build): 1 no MFMA, 2 no operand LDS reads,
+// 4 no weight traffic, 8 no input staging after the first chunk, 16 no per-tap barrier.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     constexpr int C16_BN = 32 * WN * WAVES_N;
     static_assert(32 * WM * WAVES_M == C16_BM && WAVES_M * WAVES_N == 8, "tile");
@@ -53,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     const int kg = lane >> 5, l31 = lane & 31;
 
     const int pt = a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
-    const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.TW + a.KW - 1;
+    const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.HWp;
     const int NPOS = a.TB * HT * HH * HW;
     const int ntaps = a.KT * a.KH * a.KW;
 
@@ -62,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     int* rowpos = reinterpret_cast<int*>(w_lds + 2 * C16_BN * C16_ROW);
     int* rowres = rowpos + C16_BM;
     int* taplist = rowres + C16_BM;
+    int* gpos = taplist + 32;  // [NPOS] linear input position of every staged halo row, -1 = zero padding
 
     const int nNt = a.CoutPad / C16_BN;
     const int ntile = blockIdx.x % nNt;
@@ -73,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     const int n0 = ntile * C16_BN;
 
     if (tid < C16_BM) {
-        int m = tid;
+        int m = brick_index(tid, a.TH, a.TW, a.patch);
         const int iw = m % a.TW; m /= a.TW;
         const int ih = m % a.TH; m /= a.TH;
         const int it = m % a.TT; m /= a.TT;
@@ -93,10 +119,21 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
         taplist[0] = cnt;
     }
 
+    for (int p0 = tid; p0 < NPOS; p0 += 512) {
+        int p = p0;
+        const int iw = p % HW; p /= HW;
+        const int ih = p % HH; p /= HH;
+        const int it = p % HT; p /= HT;
+        const int b = b0 + p, t = t0 + it - pt, h = h0 + ih - ph, w = w0 + iw - pw;
+        const bool ok = b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W &&
+                        iw < a.TW + a.KW - 1;
+        gpos[p0] = ok ? ((b * a.T + t) * a.H + h) * a.W + w : -1;
+    }
+
     int aoff[WM], boff[WN];
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm) {
-        int m = wave_m * (32 * WM) + 32 * wm + l31;
+        int m = brick_index(wave_m * (32 * WM) + 32 * wm + l31, a.TH, a.TW, a.patch);
         const int iw = m % a.TW; m /= a.TW;
         const int ih = m % a.TH; m /= a.TH;
         const int it = m % a.TT; m /= a.TT;
@@ -120,62 +157,103 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     const int ntv = taplist[0];
     const long in_row = (long)a.Cin * 4;
 
+    // Input staging: all (<= C16_SLOTS) 16-byte pieces of a thread are requested back to back (one exposed memory
+    // latency per chunk instead of one per piece) and the NEXT chunk's pieces are requested a few taps before the
+    // current chunk ends, so that latency hides behind MFMA work.
+    const int ngrp = a.Cin >> 3;
+    float4 vin[C16_SLOTS];
+#define C16_REQUEST_INPUT(ch_)                                                                                      \
+    {                                                                                                                \
+        int gp_[C16_SLOTS];                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < C16_SLOTS; ++u) {                                                      \
+            const int idx = tid + u * 512;                                                                           \
+            gp_[u] = gpos[idx < NPOS * 8 ? (idx >> 3) : 0];                                                          \
+        }                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < C16_SLOTS; ++u) {                                                      \
+            const int idx = tid + u * 512;                                                                           \
+            const int q = idx & 7;                                                                                   \
+            const bool ok = idx < NPOS * 8 && gp_[u] >= 0 && (ch_) * 4 + (q >> 1) < ngrp;                            \
+            const long off = ok ? (long)gp_[u] * in_row + (long)(ch_) * 128 + q * 16 : 0;                            \
+            const float4 v = *reinterpret_cast<const float4*>(a.in + off);                                           \
+            vin[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+        }                                                                                                            \
+    }
+    half8 ah[WM], al[WM], bh_[WN], bl[WN];
+    C16_REQUEST_INPUT(0)
+    const int pf_stage = ntv > 4 ? ntv - 4 : 0;
+
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();
-        const int cgrp0 = ch * 4;  // first 8-channel group of this chunk
-        const int ngrp = a.Cin >> 3;
-        for (int idx = tid; idx < NPOS * 8; idx += 512) {
+        if (!(ABL & 8) || ch == 0)
+#pragma unroll
+        for (int u = 0; u < C16_SLOTS; ++u) {
+            const int idx = tid + u * 512;
+            if (idx < NPOS * 8) *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + (idx & 7) * 16) = vin[u];
+        }
+        for (int idx = tid + C16_SLOTS * 512; idx < NPOS * 8; idx += 512) {  // oversized halo bricks only
             const int q = idx & 7;
-            int p = idx >> 3;
-            const int iw = p % HW; p /= HW;
-            const int ih = p % HH; p /= HH;
-            const int it = p % HT; p /= HT;
-            const int b = b0 + p, t = t0 + it - pt, h = h0 + ih - ph, w = w0 + iw - pw;
+            const int gp = gpos[idx >> 3];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W &&
-                cgrp0 + (q >> 1) < ngrp) {
-                v = *reinterpret_cast<const float4*>(a.in + ((((long)b * a.T + t) * a.H + h) * a.W + w) * in_row +
-                                                     (long)ch * 128 + q * 16);
-            }
+            if (gp >= 0 && ch * 4 + (q >> 1) < ngrp)
+                v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)ch * 128 + q * 16);
             *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;
         }
-        if (ntv > 0) {
-            const char* src = a.wp + ((long)(a.tap_base + taplist[1]) * a.nchunk + ch) * slab + (long)n0 * 128;
+        // weights: slab of the first tap straight to LDS, slab of the second tap into registers.  Every thread moves
+        // WLD 16-byte pieces per slab; piece indices are clamped instead of predicated (duplicates rewrite identical
+        // bytes) so the loads stay branch-free and in registers.
+        const long wtap_stride = (long)a.nchunk * slab;
+        const char* wbase = a.wp + (long)ch * slab + (long)n0 * 128 + (long)a.tap_base * wtap_stride;
+        int wf[WLD], wl[WLD];
 #pragma unroll
-            for (int u = 0; u < WLD; ++u) {
-                const int f = tid + u * 512;
-                if (f < WF4) *reinterpret_cast<float4*>(w_lds + (f >> 3) * C16_ROW + (f & 7) * 16) =
-                    *reinterpret_cast<const float4*>(src + (long)f * 16);
-            }
+        for (int u = 0; u < WLD; ++u) {
+            int f = tid + u * 512;
+            f = f < WF4 ? f : WF4 - 1;
+            wf[u] = f * 16;
+            wl[u] = (f >> 3) * C16_ROW + (f & 7) * 16;
+        }
+        float4 wreg0 = make_float4(0.f, 0.f, 0.f, 0.f), wreg1 = wreg0;
+        if (ntv > 0) {
+            const char* src = wbase + (long)taplist[1] * wtap_stride;
+            *reinterpret_cast<float4*>(w_lds + wl[0]) = *reinterpret_cast<const float4*>(src + wf[0]);
+            if (WLD > 1) *reinterpret_cast<float4*>(w_lds + wl[WLD - 1]) = *reinterpret_cast<const float4*>(src + wf[WLD - 1]);
+        }
+        if (ntv > 1) {
+            const char* src = wbase + (long)taplist[2] * wtap_stride;
+            wreg0 = *reinterpret_cast<const float4*>(src + wf[0]);
+            if (WLD > 1) wreg1 = *reinterpret_cast<const float4*>(src + wf[WLD - 1]);
         }
         __syncthreads();
         for (int ti = 0; ti < ntv; ++ti) {
             const int tap = taplist[1 + ti];
-            float4 wreg[WLD];
-            const bool more = ti + 1 < ntv;
-            if (more) {
-                const char* src = a.wp + ((long)(a.tap_base + taplist[2 + ti]) * a.nchunk + ch) * slab + (long)n0 * 128;
-#pragma unroll
-                for (int u = 0; u < WLD; ++u) {
-                    const int f = tid + u * 512;
-                    if (f < WF4) wreg[u] = *reinterpret_cast<const float4*>(src + (long)f * 16);
-                }
+            // the slab of tap ti+1 was requested one full stage ago: park it in the other LDS buffer (every wave left
+            // that buffer at the previous barrier), then request the slab of tap ti+2 into the same registers
+            if (!(ABL & 4) && ti + 1 < ntv) {
+                char* wd = w_lds + ((ti + 1) & 1) * (C16_BN * C16_ROW);
+                *reinterpret_cast<float4*>(wd + wl[0]) = wreg0;
+                if (WLD > 1) *reinterpret_cast<float4*>(wd + wl[WLD - 1]) = wreg1;
             }
+            if (!(ABL & 4) && ti + 2 < ntv) {
+                const char* src = wbase + (long)taplist[3 + ti] * wtap_stride;
+                wreg0 = *reinterpret_cast<const float4*>(src + wf[0]);
+                if (WLD > 1) wreg1 = *reinterpret_cast<const float4*>(src + wf[WLD - 1]);
+            }
+            if (!(ABL & 8) && ti == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)
             const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KW * a.KH);
             const int tapoff = ((dt * HH + dh) * HW + dw) * C16_ROW;
             const char* wb = w_lds + (ti & 1) * (C16_BN * C16_ROW);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                half8 ah[WM], al[WM], bh_[WN], bl[WN];
 #pragma unroll
                 for (int wm = 0; wm < WM; ++wm) {
-                    const char* p = in_lds + aoff[wm] + tapoff + s * 64;
+                    const char* p = in_lds + aoff[wm] + ((ABL & 2) ? 0 : tapoff + s * 64);
+                    if ((ABL & 2) && (ti | s)) continue;
                     ah[wm] = *reinterpret_cast<const half8*>(p);
                     al[wm] = *reinterpret_cast<const half8*>(p + 16);
                 }
 #pragma unroll
                 for (int wn = 0; wn < WN; ++wn) {
                     const char* p = wb + boff[wn] + s * 64;
+                    if ((ABL & 2) && (ti | s)) continue;
                     bh_[wn] = *reinterpret_cast<const half8*>(p);
                     bl[wn] = *reinterpret_cast<const half8*>(p + 16);
                 }
@@ -183,20 +261,16 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
                 for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
                     for (int wn = 0; wn < WN; ++wn) {
+                        if (ABL & 1) {
+                            asm volatile("" ::"v"(ah[wm]), "v"(al[wm]), "v"(bh_[wn]), "v"(bl[wn]));
+                            continue;
+                        }
                         acc_h[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[wm], bh_[wn], acc_h[wm][wn], 0, 0, 0);
                         acc_x[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[wm], bl[wn], acc_x[wm][wn], 0, 0, 0);
                         acc_x[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[wm], bh_[wn], acc_x[wm][wn], 0, 0, 0);
                     }
             }
-            if (more) {
-                char* wd = w_lds + ((ti + 1) & 1) * (C16_BN * C16_ROW);
-#pragma unroll
-                for (int u = 0; u < WLD; ++u) {
-                    const int f = tid + u * 512;
-                    if (f < WF4) *reinterpret_cast<float4*>(wd + (f >> 3) * C16_ROW + (f & 7) * 16) = wreg[u];
-                }
-            }
-            __syncthreads();
+            if (!(ABL & 16)) __syncthreads();
         }
     }
 
@@ -252,9 +326,9 @@ int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int
     return I2V_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int ABL = 0>
 static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
-    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN>;
+    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -267,7 +341,7 @@ static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t 
 }
 
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st) {
+                   int H, int W, int epi, hipStream_t st, int ablate) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv16: weights not packed");
     I2V_REQUIRE(wts.Cin % 8 == 0, I2V_E_INVALID, "conv16: Cin %d must be a multiple of 8", wts.Cin);
     Conv16Args a{};
@@ -290,12 +364,36 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
                 "conv16: cannot tile [T=%d,H=%d,W=%d] into bricks of %d positions", T, H, W, C16_BM);
     a.TB = TB; a.TT = TT; a.TH = TH; a.TW = TW;
     a.nbB = (B + TB - 1) / TB; a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;
-    const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * (TW + a.KW - 1);
+    const int BNsel = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
+    a.HWp = TW + a.KW - 1;
+    a.patch = (TW % 4 == 0 && TH % 4 == 0) ? 1 : 0;
+    if (a.patch && a.HWp == 10) {  // pitch 12 makes the 4x4 patches conflict-free; keep 10 when LDS would overflow
+        const size_t need = (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * 12 * C16_ROW + 2 * (size_t)BNsel * C16_ROW +
+                            (2 * C16_BM + 32) * 4 + (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * 12 * 4;
+        if (need <= 160 * 1024) a.HWp = 12;
+    }
+    const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * a.HWp;
     const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
-    const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)BN * C16_ROW + (2 * C16_BM + 32) * 4;
+    const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)BN * C16_ROW + (2 * C16_BM + 32) * 4 + (size_t)npos * 4;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
+#ifdef I2V_ABLATE
+    if (BN == 128) switch (ablate) {
+        case 1: return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
+        case 2: return launch16<4, 2, 2, 2, 2>(a, (unsigned)nblk, lds, st);
+        case 3: return launch16<4, 2, 2, 2, 3>(a, (unsigned)nblk, lds, st);
+        case 4: return launch16<4, 2, 2, 2, 4>(a, (unsigned)nblk, lds, st);
+        case 8: return launch16<4, 2, 2, 2, 8>(a, (unsigned)nblk, lds, st);
+        case 12: return launch16<4, 2, 2, 2, 12>(a, (unsigned)nblk, lds, st);
+        case 14: return launch16<4, 2, 2, 2, 14>(a, (unsigned)nblk, lds, st);
+        case 16: return launch16<4, 2, 2, 2, 16>(a, (unsigned)nblk, lds, st);
+        case 30: return launch16<4, 2, 2, 2, 30>(a, (unsigned)nblk, lds, st);
+        default: break;
+    }
+#else
+    (void)ablate;
+#endif
     if (BN == 128) return launch16<4, 2, 2, 2>(a, (unsigned)nblk, lds, st);
     if (BN == 64) return launch16<4, 2, 2, 1>(a, (unsigned)nblk, lds, st);
     return launch16<8, 1, 1, 1>(a, (unsigned)nblk, lds, st);

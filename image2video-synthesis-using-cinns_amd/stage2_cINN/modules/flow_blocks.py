@@ -60,8 +60,8 @@ class ConditionalFlow(NativeBacked):
         x2 = x.reshape(x.shape[0], -1).contiguous()
         e2 = embedding.reshape(embedding.shape[0], -1).contiguous()
         if not reverse:
-            if any(int(b.norm_layer.initialized.item()) == 0 for b in self.sub_layers):
-                self._data_dependent_init(x2, e2)
+            if self._native is None and any(int(b.norm_layer.initialized.item()) == 0 for b in self.sub_layers):
+                self._data_dependent_init(x2, e2)  # checked only when the native handle is (re)built: no per-call sync
             out, logdet = self.native().forward(x2, e2)
             return out[:, :, None, None], logdet
         return self.native().inverse(x2, e2)[:, :, None, None]
