@@ -12,6 +12,7 @@ enum ConvEpilogue : int {
     EPI_NONE = 0,
     EPI_LRELU = 1,   // leaky_relu(0.2) on the result (decoder.py:51-52,117)
     EPI_FRAMES = 2,  // tanh + store as [B][T][3][H][W] (decoder.py:118-120)
+    EPI_HL16 = 4,    // store in the split-fp16 operand format (input of i2v_conv16.hip) instead of fp32
 };
 
 // Weights packed for the kernel: [tap][chunk][CoutPad][16] floats (zero padded).
@@ -56,6 +57,18 @@ struct Conv16Weights {
 
 // in_hl16: channels-last activations in the hl16 format (4 bytes per element, Cin % 8 == 0); out: fp32 channels-last.
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st, int ablate = 0);
+                   int H, int W, int epi, hipStream_t st, int ablate = 0, double* stats = nullptr);
+// true when conv16_forward can accumulate per-(sample, channel) sum / sum-of-squares of its output in the epilogue
+bool conv16_can_fuse_stats(int T, int H, int W);
+
+// ---- conv_img (i2v_convimg.hip): Conv3d(nf -> 3) + tanh on the vector ALU, exact fp32
+struct ConvImgWeights {
+    DevBuf w, bias;  // [chunk16][tap][16][4] floats, bias[3]
+    int Cin = 0, nchunk = 0;
+    int pack(const float* w_src, const float* bias_src, int cin);
+};
+bool conv_img_supported(int T, int H, int W, int C);
+// in: fp32 channels-last [B][T][H][W][Cin]; out: frames [B][T][3][H][W] with tanh applied
+int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st);
 
 }  // namespace i2v

@@ -37,6 +37,7 @@ struct Conv16Args {
     const float* bias;
     const float* res;
     float* out;       // fp32 channels-last [B][T][H][W][Cout]
+    double* stats;    // optional [B][Cout][2]: per-(sample, channel) sum / sum of squares of the stored values (TB == 1)
     int B, T, H, W, Cin, Cout, CoutPad, nchunk;
     int KT, KH, KW, tap_base;
     int TB, TT, TH, TW, nbB, nbT, nbH, nbW;
@@ -278,17 +279,20 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         const int n = n0 + wave_n * (32 * WN) + 32 * wn + l31;
-        if (n >= a.Cout) continue;
-        const float bias = a.bias ? a.bias[n] : 0.f;
+        const bool ncol = n < a.Cout;
+        const float bias = (a.bias && ncol) ? a.bias[n] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = wave_m * (32 * WM) + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 const int p = rowpos[m];
-                if (p < 0) continue;
+                if (p < 0 || !ncol) continue;
                 float v = fmaf(acc_x[wm][wn][r], 1.0f / 2048.0f, acc_h[wm][wn][r]) + bias;
                 if (a.res) v += a.res[(long)rowres[m] * a.Cout + n];
+                ssum += v;
+                ssq = fmaf(v, v, ssq);
                 if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
                 if (a.epi & EPI_FRAMES) {
                     const int bt_ = p / HWo, hw = p - bt_ * HWo;
@@ -296,6 +300,18 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
                 } else {
                     a.out[(long)p * a.Cout + n] = v;
                 }
+            }
+        }
+        if (a.stats) {
+            // fused normalisation statistics (InstanceNorm of conv_0's output / GroupNorm of the block output): the
+            // workgroup tile lies inside one sample; lanes l and l^32 hold the same column -> wavefront shuffle, then one
+            // fp64 atomic pair per (wave, column)
+            ssum += __shfl_xor(ssum, 32);
+            ssq += __shfl_xor(ssq, 32);
+            if (kg == 0 && ncol) {
+                double* dst = a.stats + ((long)b0 * a.Cout + n) * 2;
+                atomicAdd(dst, (double)ssum);
+                atomicAdd(dst + 1, (double)ssq);
             }
         }
     }
@@ -340,8 +356,13 @@ static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t 
     return I2V_OK;
 }
 
+bool conv16_can_fuse_stats(int T, int H, int W) {
+    // the 256-position brick stays inside one sample when the sample has at least 256 positions (power-of-two dims)
+    return (long)T * H * W >= C16_BM;
+}
+
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st, int ablate) {
+                   int H, int W, int epi, hipStream_t st, int ablate, double* stats) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv16: weights not packed");
     I2V_REQUIRE(wts.Cin % 8 == 0, I2V_E_INVALID, "conv16: Cin %d must be a multiple of 8", wts.Cin);
     Conv16Args a{};
@@ -353,6 +374,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
         a.tap_base = wts.KH * wts.KW;
     }
     a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
+    a.stats = stats;
     int TW = W < 8 ? W : 8, TH = H < 8 ? H : 8;
     int rem = C16_BM / (TW * TH);
     int TT = T < rem ? T : rem;
@@ -362,15 +384,18 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     const int TB = rem;
     I2V_REQUIRE(TB * TT * TH * TW == C16_BM && T % TT == 0 && H % TH == 0 && W % TW == 0, I2V_E_INVALID,
                 "conv16: cannot tile [T=%d,H=%d,W=%d] into bricks of %d positions", T, H, W, C16_BM);
+    I2V_REQUIRE(!stats || TB == 1, I2V_E_INVALID, "conv16: fused statistics need bricks inside one sample");
     a.TB = TB; a.TT = TT; a.TH = TH; a.TW = TW;
     a.nbB = (B + TB - 1) / TB; a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;
     const int BNsel = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
     a.HWp = TW + a.KW - 1;
     a.patch = (TW % 4 == 0 && TH % 4 == 0) ? 1 : 0;
-    if (a.patch && a.HWp == 10) {  // pitch 12 makes the 4x4 patches conflict-free; keep 10 when LDS would overflow
-        const size_t need = (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * 12 * C16_ROW + 2 * (size_t)BNsel * C16_ROW +
-                            (2 * C16_BM + 32) * 4 + (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * 12 * 4;
-        if (need <= 160 * 1024) a.HWp = 12;
+    if (a.patch) {  // a halo row pitch = 4 or 12 (mod 16) makes the 4x4 patches conflict-free; keep it if LDS allows
+        int hp = a.HWp;
+        while (hp % 16 != 4 && hp % 16 != 12) ++hp;
+        const size_t rows = (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * hp;
+        const size_t need = rows * C16_ROW + 2 * (size_t)BNsel * C16_ROW + (2 * C16_BM + 32) * 4 + rows * 4;
+        if (need <= 160 * 1024) a.HWp = hp;
     }
     const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * a.HWp;
     const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);

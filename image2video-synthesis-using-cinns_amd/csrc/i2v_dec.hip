@@ -91,82 +91,68 @@ __global__ void coef_kernel(const double* __restrict__ sums, float2* __restrict_
 }
 
 // out[b][t][h][w][c] = act( (x[b][t/ut][h/us][w/us][c] * A + B) * gamma'[b][h][w][c] + beta[b][h][w][c] )
-//   gb: [B][H][W][2C] (gamma' = 1 + gamma in [0,C), beta in [C,2C)) or null
-__global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
-                                                       const float* __restrict__ gb, float* __restrict__ out, int B, int T,
-                                                       int H, int W, int C, int ut, int us, int lrelu) {
-    const int C4 = C >> 2;
-    const long total = (long)B * T * H * W * C4;
-    const int Tl = T / ut, Hl = H / us, Wl = W / us;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long p = i / C4;
-        const int w = (int)(p % W); p /= W;
-        const int h = (int)(p % H); p /= H;
-        const int t = (int)(p % T);
-        const int b = (int)(p / T);
-        const float4 v = *reinterpret_cast<const float4*>(
-            x + ((((long)b * Tl + t / ut) * Hl + h / us) * Wl + w / us) * C + 4 * c4);
-        const float4 ab0 = *reinterpret_cast<const float4*>(coef + (long)b * C + 4 * c4);      // (A0,B0,A1,B1)
-        const float4 ab1 = *reinterpret_cast<const float4*>(coef + (long)b * C + 4 * c4 + 2);  // (A2,B2,A3,B3)
-        float4 r;
-        r.x = fmaf(v.x, ab0.x, ab0.y); r.y = fmaf(v.y, ab0.z, ab0.w);
-        r.z = fmaf(v.z, ab1.x, ab1.y); r.w = fmaf(v.w, ab1.z, ab1.w);
-        if (gb) {
-            const float* g = gb + (((long)b * H + h) * W + w) * (2 * C) + 4 * c4;
-            const float4 ga = *reinterpret_cast<const float4*>(g);
-            const float4 be = *reinterpret_cast<const float4*>(g + C);
-            r.x = fmaf(r.x, ga.x, be.x); r.y = fmaf(r.y, ga.y, be.y);
-            r.z = fmaf(r.z, ga.z, be.z); r.w = fmaf(r.w, ga.w, be.w);
-        }
-        if (lrelu) {
-            r.x = r.x >= 0.f ? r.x : 0.2f * r.x; r.y = r.y >= 0.f ? r.y : 0.2f * r.y;
-            r.z = r.z >= 0.f ? r.z : 0.2f * r.z; r.w = r.w >= 0.f ? r.w : 0.2f * r.w;
-        }
-        *reinterpret_cast<float4*>(out + i * 4) = r;
-    }
-}
-
-// Same as modulate_kernel, but writes the result in the split-fp16 operand format of i2v_conv16.hip ("hl16": per 8
-// channels 8 x fp16 hi | 8 x fp16 lo*2^11); one thread = one position x 8 channels (32 bytes in, 32 bytes out).
+//   gb: [B][H][W][2C] (gamma' = 1 + gamma in [0,C), beta in [C,2C)) or null.
+// One thread = one position x 8 channels (32 B in / 32 B out, consecutive threads = consecutive channel groups);
+// blockIdx.y = sample, all per-sample index math in 32 bits.  HL16: write the split-fp16 operand format of
+// i2v_conv16.hip (8 x fp16 hi | 8 x fp16 lo*2^11 per 8 channels) instead of fp32.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void modulate_hl16_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
-                                                            const float* __restrict__ gb, char* __restrict__ out, int B, int T,
-                                                            int H, int W, int C, int ut, int us, int lrelu) {
+template <bool HL16>
+__global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
+                                                       const float* __restrict__ gb, float* __restrict__ out, int T, int H,
+                                                       int W, int C, int ut, int us, int lrelu) {
     const int C8 = C >> 3;
-    const long total = (long)B * T * H * W * C8;
-    const int Tl = T / ut, Hl = H / us, Wl = W / us;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % C8);
-        long p = i / C8;
-        const int w = (int)(p % W); p /= W;
-        const int h = (int)(p % H); p /= H;
-        const int t = (int)(p % T);
-        const int b = (int)(p / T);
-        const float* xp = x + ((((long)b * Tl + t / ut) * Hl + h / us) * Wl + w / us) * C + 8 * c8;
+    const int b = blockIdx.y;
+    const int per = T * H * W * C8;  // < 2^31 per sample
+    const int Hl = H / us, Wl = W / us, Tl = T / ut;
+    const float2* cp0 = coef + (long)b * C;
+    const float* xb = x + (long)b * Tl * Hl * Wl * C;
+    const float* gbb = gb ? gb + (long)b * H * W * 2 * C : nullptr;
+    char* ob = reinterpret_cast<char*>(out) + (long)b * per * 32;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+        const int c8 = i % C8;
+        int p = i / C8;
+        const int w = p % W; p /= W;
+        const int h = p % H;
+        const int t = p / H;
+        const float* xp = xb + (((long)(t / ut) * Hl + h / us) * Wl + w / us) * C + 8 * c8;
         const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 4);
         float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        const float2* cp = coef + (long)b * C + 8 * c8;
+        const float4* cp = reinterpret_cast<const float4*>(cp0 + 8 * c8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float2 ab = cp[j]; r[j] = fmaf(r[j], ab.x, ab.y); }
-        if (gb) {
-            const float* g = gb + (((long)b * H + h) * W + w) * (2 * C) + 8 * c8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = fmaf(r[j], g[j], g[C + j]);
+        for (int j = 0; j < 4; ++j) {
+            const float4 ab = cp[j];
+            r[2 * j] = fmaf(r[2 * j], ab.x, ab.y);
+            r[2 * j + 1] = fmaf(r[2 * j + 1], ab.z, ab.w);
         }
-        half8_t hi, lo;
+        if (gbb) {
+            const float* g = gbb + ((long)h * W + w) * (2 * C) + 8 * c8;
+            const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
+            const float4 e0 = *reinterpret_cast<const float4*>(g + C), e1 = *reinterpret_cast<const float4*>(g + C + 4);
+            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = r[j];
-            if (lrelu) v = v >= 0.f ? v : 0.2f * v;
-            const _Float16 hh = (_Float16)v;
-            hi[j] = hh;
-            lo[j] = (_Float16)((v - (float)hh) * 2048.0f);
+            for (int j = 0; j < 8; ++j) r[j] = fmaf(r[j], ga[j], be[j]);
         }
-        char* o = out + i * 32;
-        *reinterpret_cast<half8_t*>(o) = hi;
-        *reinterpret_cast<half8_t*>(o + 16) = lo;
+        if (lrelu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = r[j] >= 0.f ? r[j] : 0.2f * r[j];
+        }
+        char* o = ob + (long)i * 32;
+        if (HL16) {
+            half8_t hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hh = (_Float16)r[j];
+                hi[j] = hh;
+                lo[j] = (_Float16)((r[j] - (float)hh) * 2048.0f);
+            }
+            *reinterpret_cast<half8_t*>(o) = hi;
+            *reinterpret_cast<half8_t*>(o + 16) = lo;
+        } else {
+            *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(o + 16) = make_float4(r[4], r[5], r[6], r[7]);
+        }
     }
 }
 
@@ -208,7 +194,7 @@ struct Block {
     bool learned = false;
     int groups_spade = 16;
     ConvWeights conv0, conv1, convs, sp_conv, sp_gb;
-    Conv16Weights conv0_16, conv1_16;  // split-fp16 variants (cfg.mma == 1)
+    Conv16Weights conv0_16, conv1_16, sp_gb16;  // split-fp16 variants (cfg.mma == 1)
     DevBuf gn_w, gn_b;
     int zoff = 0;  // offset of this block's ADAIN (gamma|beta) in the z-GEMM output
 };
@@ -224,6 +210,7 @@ struct i2v_dec {
     Block blk[6];
     Level lvl[6];
     ConvWeights fc, zlin, conv_img;
+    ConvImgWeights conv_img_v;  // vector-ALU variant (used when the output geometry tiles into 4x8x8 bricks)
     int Nz = 0;
     int profile = 0;
     struct ProfEv { hipEvent_t e0, e1; double flops; };
@@ -294,19 +281,16 @@ int run_coef(const double* sums, float* coef, int B, int C, int groups, double c
 
 int run_modulate(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
                  int us, int lrelu, hipStream_t st, bool hl16 = false) {
-    if (hl16) {
-        const long tot8 = (long)B * T * H * W * (C / 8);
-        long nb = std::min<long>((tot8 + 255) / 256, 65536);
-        hipLaunchKernelGGL(modulate_hl16_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
-                           reinterpret_cast<char*>(out), B, T, H, W, C, ut, us, lrelu);
-        I2V_HIP_CHECK(hipGetLastError());
-        return I2V_OK;
-    }
-    const long total = (long)B * T * H * W * (C / 4);
-    long blocks = (total + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
-                       out, B, T, H, W, C, ut, us, lrelu);
+    I2V_REQUIRE(C % 8 == 0, I2V_E_INVALID, "modulate: channels %d not a multiple of 8", C);
+    const long per = (long)T * H * W * (C / 8);
+    I2V_REQUIRE(per < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
+    const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
+    if (hl16)
+        hipLaunchKernelGGL(modulate_kernel<true>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb, out,
+                           T, H, W, C, ut, us, lrelu);
+    else
+        hipLaunchKernelGGL(modulate_kernel<false>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb, out,
+                           T, H, W, C, ut, us, lrelu);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -338,9 +322,10 @@ int conv3(i2v_dec* d, const ConvWeights& w, const float* in, float* out, const f
 }
 
 int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* out, const float* res, int rt, int rs, int B,
-             const Level& l, int epi, hipStream_t st) {
+             const Level& l, int epi, hipStream_t st, double* stats = nullptr) {
+    if (stats) I2V_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * w.Cout * 16, st));
     ProfScope ps(d, st, 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0);
-    return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st);
+    return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, 0, stats);
 }
 
 template <class WT>
@@ -471,7 +456,9 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         std::memcpy(wgb.data(), wg, (size_t)b.n_in * 128 * 9 * 4);
         std::memcpy(wgb.data() + (size_t)b.n_in * 128 * 9, wb, (size_t)b.n_in * 128 * 9 * 4);
         for (int c = 0; c < b.n_in; ++c) { bgb[c] = bg[c] + 1.0f; bgb[b.n_in + c] = bb[c]; }  // normalized*(1+gamma)+beta
-        if ((rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0))) return rc;
+        if (d->cfg.mma == 1) rc = b.sp_gb16.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
+        else rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
+        if (rc) return rc;
         // ADAIN linear rows into the shared z-GEMM
         const float* lw = sd.f32(p + "norm_1.linear.weight", (int64_t)2 * b.n_mid * zd);
         const float* lb = sd.f32(p + "norm_1.linear.bias", (int64_t)2 * b.n_mid);
@@ -485,6 +472,7 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         const float* b = sd.f32("conv_img.bias", 3);
         if (!w || !b) return I2V_E_MISSING;
         if ((rc = d->conv_img.pack(w, b, 3, nf, 3, 3, 3, 1.0))) return rc;
+        if ((rc = d->conv_img_v.pack(w, b, nf))) return rc;
     }
     d->loaded = true;
     return I2V_OK;
@@ -575,6 +563,7 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     if ((rc = conv_forward(d->zlin, motion, d->cfg.z_dim, zl, nullptr, 1, 1, B, 1, 1, 1, EPI_NONE, st))) return rc;
     float* x = xA;
     float* xn = xB;
+    bool x_stats_ready = false;
     auto tap = [&](int k, int which, const float* src, size_t count) -> int {
         if (d->tap_dst && d->tap_block == k && d->tap_which == which)
             I2V_HIP_CHECK(hipMemcpyAsync(d->tap_dst, src, std::min(count, d->tap_max) * 4, hipMemcpyDeviceToDevice, st));
@@ -585,8 +574,9 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
         const Level& l = d->lvl[k];
         const int Tl = l.T / l.ut, Hl = l.H / l.us, Wl = l.W / l.us;
         const long Pl = (long)Tl * Hl * Wl, P = (long)l.T * l.H * l.W;
-        // GroupNorm statistics of the (virtually upsampled) block input == statistics of the low-res tensor
-        if ((rc = run_stats(x, sums1, B, Pl, b.n_in, st))) return rc;
+        // GroupNorm statistics of the (virtually upsampled) block input == statistics of the low-res tensor; they are
+        // already in sums1 when the previous block's conv_1 accumulated them in its epilogue
+        if (!x_stats_ready && (rc = run_stats(x, sums1, B, Pl, b.n_in, st))) return rc;
         if ((rc = run_coef(sums1, coef, B, b.n_in, b.groups_spade, (double)Pl, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
         // SPADE branch (normalization_layer.py:20-23)
         {
@@ -595,18 +585,24 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
                                B, img_h, img_w, l.H, l.W);
             I2V_HIP_CHECK(hipGetLastError());
         }
-        if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
-        if ((rc = conv_forward(b.sp_gb, y1, 128, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
+        if (d->cfg.mma == 1) {
+            if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st))) return rc;
+            if ((rc = conv16_forward(b.sp_gb16, y1, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
+        } else {
+            if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
+            if ((rc = conv_forward(b.sp_gb, y1, 128, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
+        }
         if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
         const bool f16 = d->cfg.mma == 1;
         if ((rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16))) return rc;
         if ((rc = tap(k, 1, a, (size_t)B * P * b.n_in))) return rc;
-        if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
+        const bool fuse = f16 && conv16_can_fuse_stats(l.T, l.H, l.W);
+        if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
         else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
         if (rc) return rc;
         if ((rc = tap(k, 2, dx, (size_t)B * P * b.n_mid))) return rc;
         // ADAIN (normalization_layer.py:47-51) + leaky_relu
-        if ((rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
+        if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
         if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, d->Nz, b.zoff, nullptr, nullptr, st))) return rc;
         if ((rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16))) return rc;
         if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
@@ -621,13 +617,22 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
             if ((rc = tap(k, 4, xs_low, (size_t)B * Pl * b.n_out))) return rc;
         }
         // g_4's output only feeds conv_img(leaky_relu(x)) (decoder.py:117): fuse the activation here
-        if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st);
+        // (the shortcut's coefficients were derived from sums1 above, so conv_1 may now overwrite sums1 with the
+        // statistics of the block OUTPUT = the next block's input)
+        const bool fuse_out = fuse && k < 5;
+        if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
         else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st);
         if (rc) return rc;
+        x_stats_ready = fuse_out;
         if ((rc = tap(k, 5, xn, (size_t)B * P * b.n_out))) return rc;
         std::swap(x, xn);
     }
-    if ((rc = conv3(d, d->conv_img, x, out, nullptr, 1, 1, B, d->lvl[5], EPI_FRAMES, st))) return rc;
+    {
+        const Level& l = d->lvl[5];
+        if (conv_img_supported(l.T, l.H, l.W, d->nf)) rc = conv_img_forward(d->conv_img_v, x, out, B, l.T, l.H, l.W, st);
+        else rc = conv_forward(d->conv_img, x, d->nf, out, nullptr, 1, 1, B, l.T, l.H, l.W, EPI_FRAMES, st);
+        if (rc) return rc;
+    }
     return I2V_OK;
 }
 

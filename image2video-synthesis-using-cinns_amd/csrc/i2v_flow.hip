@@ -53,22 +53,37 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void flow_tail_kernel(TailArgs a) 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
+    // everything wave 0 needs later is requested before the reduction so the latencies overlap
+    float x = 0.f, b3 = 0.f, anl = 0.f, ans = 1.f;
+    int sidx = lane;
+    if (w == 0) {
+        x = a.x[(long)b * 64 + lane];
+        if (a.h) b3 = a.b3[lane];
+        if (a.an_loc) { anl = a.an_loc[lane]; ans = a.an_scale[lane]; }
+        if (a.shuf) sidx = a.shuf[lane];
+    }
     if (a.h) {
         // last Linear: lane = (net, c); the waves split K = H, all of a wave's loads are in flight together
         const int net = lane >> 5;
+        constexpr int KCMAX = LIN_MAXK / TAIL_WAVES;
         const int kc = a.H / TAIL_WAVES;
         const float* hp = a.h + ((long)net * a.H + (long)w * kc) * a.B + b;
         const float* wp = a.W3T + (long)w * kc * 64 + lane;
+        float hv[KCMAX], wv[KCMAX];
+#pragma unroll
+        for (int k = 0; k < KCMAX; ++k) {
+            hv[k] = k < kc ? hp[(long)k * a.B] : 0.f;
+            wv[k] = k < kc ? wp[k * 64] : 0.f;
+        }
         float acc = 0.f;
-#pragma unroll 16
-        for (int k = 0; k < kc; ++k) acc = fmaf(hp[(long)k * a.B], wp[k * 64], acc);
+#pragma unroll
+        for (int k = 0; k < KCMAX; ++k) acc = fmaf(hv[k], wv[k], acc);
         part[w][lane] = acc;
     }
     __syncthreads();
     if (w != 0) return;
-    float x = a.x[(long)b * 64 + lane];
     if (a.h) {
-        float st = a.b3[lane];
+        float st = b3;
 #pragma unroll
         for (int q = 0; q < TAIL_WAVES; ++q) st += part[q][lane];
         // lanes 0..31 hold s[c], lanes 32..63 hold t[c]; the transformed half is x[32..63]
@@ -82,16 +97,16 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void flow_tail_kernel(TailArgs a) 
         }
     }
     if (!a.reverse) {
-        if (a.shuf) x = __shfl(x, a.shuf[lane]);            // Shuffle.forward: x[:, idx]
+        if (a.shuf) x = __shfl(x, sidx);                    // Shuffle.forward: x[:, idx]
         if (a.an_loc) {                                     // ActNorm.forward: scale * (x + loc)
-            x = a.an_scale[lane] * (x + a.an_loc[lane]);
+            x = ans * (x + anl);
             if (a.logdet && lane == 0) a.logdet[b] += a.an_logdet;
         }
         if (a.do_lrelu) x = x * (x >= 0.f ? 1.0f : 0.9f);   // InvLeakyRelu.forward (log-det reported as 0, quirk Q2)
     } else {
         if (a.do_lrelu) x = x / (x >= 0.f ? 1.0f : 0.9f);   // InvLeakyRelu.reverse
-        if (a.an_loc) x = x / a.an_scale[lane] - a.an_loc[lane];  // ActNorm.reverse
-        if (a.shuf) x = __shfl(x, a.shuf[lane]);            // Shuffle.reverse: x[:, argsort(idx)]
+        if (a.an_loc) x = x / ans - anl;                    // ActNorm.reverse
+        if (a.shuf) x = __shfl(x, sidx);                    // Shuffle.reverse: x[:, argsort(idx)]
     }
     if (a.do_swap) x = __shfl(x, lane ^ 32);                // chunk / cat[::-1], flow_blocks.py:86,99
     a.x[(long)b * 64 + lane] = x;
@@ -183,7 +198,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         a.N = S * N2;
         a.B = B;
         a.slope = 1.0f;
-        int rc = launch_linear<8, 4>(a, st);
+        int rc = launch_linear<8, 8>(a, st);
         if (rc) return rc;
     }
     auto tail = [&](const float* h, int step, int shuf_block, int an_block, bool lrelu, bool swap) -> int {
@@ -236,7 +251,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         a.N = N2;
         a.B = B;
         a.slope = 0.01f;  // nn.LeakyReLU() default, modules.py:17
-        if ((rc = launch_linear<4, 4>(a, st))) return rc;
+        if ((rc = launch_linear<4, 8>(a, st))) return rc;
         float* cur = hA;
         float* nxt = hB;
         for (int d = 0; d < f->depth; ++d) {
@@ -257,7 +272,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
             m.N = N2;
             m.B = B;
             m.slope = 0.01f;
-            if ((rc = launch_linear<4, 4>(m, st))) return rc;
+            if ((rc = launch_linear<4, 8>(m, st))) return rc;
             std::swap(cur, nxt);
         }
         // last layer + coupling + the ops up to the next half-step's first layer

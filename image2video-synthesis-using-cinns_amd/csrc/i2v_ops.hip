@@ -133,7 +133,7 @@ int i2v_mlp_forward(i2v_mlp* m, const float* x, float* y, void* workspace, size_
         a.B = B;
         if (last) { a.out = y; a.out_sn = 1; a.out_sb = m->out_dim; a.slope = 1.0f; }
         else { a.out = (li & 1) ? hB : hA; a.out_sn = B; a.out_sb = 1; a.slope = 0.01f; }  // nn.LeakyReLU(), modules.py:17
-        int rc = launch_linear<4, 4>(a, st);
+        int rc = launch_linear<4, 8>(a, st);
         if (rc) return rc;
         in = a.out; in_sk = B; in_sb = 1; K = H;
     }
