@@ -40,6 +40,7 @@ CONFIGS = {
     "land128": dict(nf=32, emb=128, img=128, ups=[2, 2], upt=[2, 1], batch=32, name="Landscape 128x128x16 nf=32 E=128"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (the split-fp16 path issues 3 MFMA FLOPs per FLOP)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -151,23 +152,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if gen.mma == 0 else "f32 (split-fp16 MFMA: fp16 hi/lo operand pairs, 3 MFMAs per product, fp32 accumulate)",
             "data": "synthetic (seeded start frames / latents / embeddings, deterministic synthetic weights)",
             "config": {"workload": f"{cfg['name']}, batch {per_gpu}/GPU, vid_length {args.vid_length}: "
                                    "20-block cINN inverse + decoder pass(es)" + (" + RCCL all-gather" if world > 1 else ""),
                        "global_batch": total, "frames_per_step": frames_per_step, "parallelism": f"batch-shard x{world}"},
-            "roofline": {
-                "kernel": "conv_mfma_f32_kernel (3x3x3 Conv3d implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                "bound": "mfma",
-                "achieved": prof["conv3_flops"] / (prof["conv3_ms"] * 1e-3) / 1e12 if prof["conv3_ms"] > 0 else None,
-                "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": (prof["conv3_flops"] / (prof["conv3_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if prof["conv3_ms"] > 0 else None,
-                "traffic": None,
-                "launches": prof["conv3_launches"],
-                "avg_launch_ms": prof["conv3_ms"] / max(prof["conv3_launches"], 1),
-                "time_share": prof["conv3_ms"] * 1e-3 / dt,
-            },
+            "roofline": roofline(prof, dt, gen.mma),
             "roofline_cinn": {
                 "kernel": "cINN inverse pass (flow_linear_kernel + flow_tail_kernel chain)",
                 "bound": "hbm", "bytes_per_pass": cinn_bytes,
@@ -182,6 +172,25 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline(prof, dt, mma):
+    """Dominant kernel = the 3x3x3 Conv3d implicit GEMM.  achieved = ALGORITHMIC FLOPs (2*M*N*K per launch, summed) /
+    summed launch duration (HIP events on the launch stream, inside the timed region).  In split-fp16 mode every
+    algorithmic FLOP costs three fp16 MFMA FLOPs, so the fraction of the dense fp16 peak that the matrix cores are
+    actually issuing is 3x `frac` (reported as mfma_issue_frac)."""
+    if prof["conv3_ms"] <= 0:
+        return None
+    ach = prof["conv3_flops"] / (prof["conv3_ms"] * 1e-3) / 1e12
+    if mma == 1:
+        kernel = "conv_mfma_f16x3_kernel (3x3x3 Conv3d implicit GEMM, split-fp16: 3x v_mfma_f32_32x32x16_f16 per product)"
+        peak, issue = PEAK_F16_MFMA_TFLOPS, 3.0
+    else:
+        kernel = "conv_mfma_f32_kernel (3x3x3 Conv3d implicit GEMM, v_mfma_f32_32x32x2_f32)"
+        peak, issue = PEAK_FP32_MFMA_TFLOPS, 1.0
+    return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": None, "mfma_issue_frac": issue * ach / peak, "launches": prof["conv3_launches"],
+            "avg_launch_ms": prof["conv3_ms"] / max(prof["conv3_launches"], 1), "time_share": prof["conv3_ms"] * 1e-3 / dt}
 
 
 def cpu_baseline(cfg, fsd, dsd):

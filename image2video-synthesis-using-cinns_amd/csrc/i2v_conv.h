@@ -46,12 +46,13 @@ struct ConvArgs {
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
                  int B, int T, int H, int W, int epi, hipStream_t st);
 
-// ---- split-fp16 path (i2v_conv16.hip): operands carried as (fp16 hi, fp16 lo * 2^11) pairs, 3 fp16 MFMAs per product
+// ---- split-fp16 path (i2v_conv16.hip): operands carried as (fp16 hi, fp16 lo = x - hi) pairs, 3 fp16 MFMAs per product
 struct Conv16Weights {
     DevBuf w;      // [tap][chunk32][CoutPad][4 groups x (8 hi | 8 lo) fp16] = 128 B per (n, chunk)
     DevBuf bias;
     int Cin = 0, Cout = 0, CoutPad = 0, nchunk = 0;
     int KT = 1, KH = 1, KW = 1;
+    int wexp = 0;  // weights are stored multiplied by 2^wexp (undone in the epilogue)
     int pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, int kh, int kw, double scale);
 };
 

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
                     const _Float16 hi = (_Float16)v;
                     char* o = reinterpret_cast<char*>(a.out) + (long)p * a.Cout * 4 + (n >> 3) * 32 + (n & 7) * 2;
                     *reinterpret_cast<_Float16*>(o) = hi;
-                    *reinterpret_cast<_Float16*>(o + 16) = (_Float16)((v - (float)hi) * 2048.0f);
+                    *reinterpret_cast<_Float16*>(o + 16) = (_Float16)(v - (float)hi);
                 } else {
                     a.out[(long)p * a.Cout + n] = v;
                 }

@@ -1,23 +1,28 @@
-// 3x3x3 Conv3d as an implicit GEMM on the gfx950 fp16 matrix cores with fp32-class accuracy ("split-fp16").
+// 3x3x3 Conv3d (and the 3x3 SPADE Conv2d) as an implicit GEMM on the gfx950 fp16 matrix cores with fp32-class accuracy.
 //
 // gfx950 has no TF32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the fp16/bf16 rate.  This kernel keeps
-// the reference's fp32 numerics to ~2^-22 per product while using v_mfma_f32_32x32x16_f16: every fp32 operand x is
-// carried as the pair (hi, lo) = (fp16(x), fp16((x - hi) * 2^11)), so x = hi + lo * 2^-11 up to 2^-22 |x|, and
-//     x * w  =  hi_x hi_w  +  2^-11 (hi_x lo_w + lo_x hi_w)  +  O(2^-22)
-// costs three fp16 MFMAs (fp16 x fp16 products are exact in the fp32 accumulator).  Two accumulators per tile
-// (hi*hi, cross terms) are combined in the epilogue.  Effective peak = 2.5 PFLOP/s / 3.
+// the reference's fp32 numerics to ~2^-22 per product while using v_mfma_f32_32x32x16_f16 ("split-fp16"): every fp32
+// operand x is carried as the pair (hi, lo) = (fp16(x), fp16(x - hi)), so x = hi + lo up to 2^-22 |x|, and
+//     x * w  =  hi_x hi_w  +  hi_x lo_w  +  lo_x hi_w  +  O(2^-22 |x w|)
+// costs three fp16 MFMAs into ONE fp32 accumulator (fp16 x fp16 products are exact in fp32; the matrix core honours fp16
+// subnormals -- tools/mfma_denorm_test.hip -- so small lo parts keep an absolute precision of 2^-25).  Weights are
+// pre-scaled by a per-layer power of two so that their lo parts stay in the normal fp16 range; the epilogue undoes it
+// exactly.  Effective peak = 2.5 PFLOP/s / 3.
 //
 // Operand format "hl16" (HBM and LDS): per position, per group of 8 channels: 8 x fp16 hi (16 B) | 8 x fp16 lo (16 B),
 // i.e. 4 bytes per element like fp32; one ds_read_b128 yields one MFMA operand (lane (i, kg): row i, k = 8 kg + j).
 // Activations are produced in this format by the modulate kernel (the split is done once per element, not per tap);
 // weights are split on the host at load time.
 //
-// Tiling: 512 threads = 8 wavefronts (2 per SIMD) per workgroup, 256 output positions (TB x TT x TH x TW brick) x 128
-// output channels, wave tile 64 x 64.  Per 32-channel K chunk the input halo brick is staged once in LDS (rows padded
-// 128 -> 144 B: consecutive rows start 4 banks apart, conflict-free ds_read_b128) and reused by all taps; the
-// [128][32] weight slab of each tap is double-buffered (global loads issued before the tap's 24 MFMAs per wave,
-// written to LDS after them, one barrier per tap).
+// Tiling: 512 threads = 8 wavefronts (2 per SIMD) per workgroup, 256 output positions (TB x TT x TH x TW brick) x BN
+// output channels (128/64/32), wave tile up to 64 x 64.  Per 32-channel K chunk the input halo brick is staged once in
+// LDS (rows padded 128 -> 144 B, MFMA rows assigned to 4x4 (h,w) patches: conflict-free ds_read_b128) and reused by all
+// taps; the next chunk's rows are requested from HBM a few taps ahead.  The [BN][32] weight slab of each tap is
+// double-buffered in LDS and requested one full tap ahead.  The tap loop is software-pipelined: the operands of the
+// next k-step (second half of this tap / first half of the next tap) are read from LDS while the current k-step's 12
+// MFMAs per wave run, with ONE barrier per tap placed between the two k-steps (it publishes the next tap's weights).
 #include <algorithm>
+#include <cmath>
 
 #include "i2v_conv.h"
 
@@ -44,6 +49,7 @@ struct Conv16Args {
     int HWp;   // halo row pitch in positions (>= TW + KW - 1; 12 for 8-wide bricks: conflict-free 4x4 patches)
     int patch; // 1: MFMA rows are assigned to brick positions in 4x4 (h,w) patches per ds_read_b128 lane group
     int rt, rs, epi;
+    float oscale;  // 2^-s: undoes the power-of-two pre-scaling of the weights
 };
 
 // MFMA tile row (0..255 within the workgroup tile) -> linear brick index m = ((ib*TT + it)*TH + ih)*TW + iw.
@@ -65,9 +71,7 @@ __device__ __forceinline__ int brick_index(int row, int TH, int TW, int patch) {
     return (plane * TH + py * 4 + (q >> 2)) * TW + px * 4 + (q & 3);
 }
 
-// ABL: ablation switches for tools/conv16_bench (0 in the product build): 1 no MFMA, 2 no operand LDS reads,
-// 4 no weight traffic, 8 no input staging after the first chunk, 16 no per-tap barrier.
-template <int WAVES_M, int WAVES_N, int WM, int WN, int ABL = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN>
 __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     constexpr int C16_BN = 32 * WN * WAVES_N;
     static_assert(32 * WM * WAVES_M == C16_BM && WAVES_M * WAVES_N == 8, "tile");
@@ -143,13 +147,13 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) boff[wn] = (wave_n * (32 * WN) + 32 * wn + l31) * C16_ROW + kg * 32;
 
-    f32x16 acc_h[WM][WN], acc_x[WM][WN];
+    f32x16 acc[WM][WN];
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc_h[wm][wn][r] = 0.f; acc_x[wm][wn][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
     constexpr int WF4 = C16_BN * 8;            // 16-byte pieces per weight slab
     constexpr int WLD = (WF4 + 511) / 512;
@@ -179,13 +183,41 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
             vin[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
         }                                                                                                            \
     }
-    half8 ah[WM], al[WM], bh_[WN], bl[WN];
+    struct Ops { half8 ah[WM], al[WM], bh[WN], bl[WN]; };
+    Ops o0, o1;
+#define C16_LOAD_OPS(o, aoffs, wbuf, koff)                                                                            \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+            const char* p_ = in_lds + aoff[wm] + (aoffs) + (koff);                                                   \
+            (o).ah[wm] = *reinterpret_cast<const half8*>(p_);                                                        \
+            (o).al[wm] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
+        }                                                                                                            \
+        _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) {                                                          \
+            const char* p_ = (wbuf) + boff[wn] + (koff);                                                             \
+            (o).bh[wn] = *reinterpret_cast<const half8*>(p_);                                                        \
+            (o).bl[wn] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
+        }                                                                                                            \
+    }
+    // three terms, tiles interleaved so that consecutive MFMAs never chain on the same accumulator
+#define C16_MFMA(o)                                                                                                  \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bl[wn], acc[wm][wn], 0, 0, 0);      \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+    }
+    auto tap_off = [&](int tap_) {
+        const int dw_ = tap_ % a.KW, dh_ = (tap_ / a.KW) % a.KH, dt_ = tap_ / (a.KW * a.KH);
+        return ((dt_ * HH + dh_) * HW + dw_) * C16_ROW;
+    };
+
     C16_REQUEST_INPUT(0)
     const int pf_stage = ntv > 4 ? ntv - 4 : 0;
 
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();
-        if (!(ABL & 8) || ch == 0)
 #pragma unroll
         for (int u = 0; u < C16_SLOTS; ++u) {
             const int idx = tid + u * 512;
@@ -224,54 +256,32 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
             if (WLD > 1) wreg1 = *reinterpret_cast<const float4*>(src + wf[WLD - 1]);
         }
         __syncthreads();
+        if (ntv > 0) C16_LOAD_OPS(o0, tap_off(taplist[1]), w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
         for (int ti = 0; ti < ntv; ++ti) {
-            const int tap = taplist[1 + ti];
-            // the slab of tap ti+1 was requested one full stage ago: park it in the other LDS buffer (every wave left
-            // that buffer at the previous barrier), then request the slab of tap ti+2 into the same registers
-            if (!(ABL & 4) && ti + 1 < ntv) {
-                char* wd = w_lds + ((ti + 1) & 1) * (C16_BN * C16_ROW);
-                *reinterpret_cast<float4*>(wd + wl[0]) = wreg0;
-                if (WLD > 1) *reinterpret_cast<float4*>(wd + wl[WLD - 1]) = wreg1;
+            const int toff = tap_off(taplist[1 + ti]);
+            const char* wb = w_lds + (ti & 1) * (C16_BN * C16_ROW);
+            char* wnext = w_lds + ((ti + 1) & 1) * (C16_BN * C16_ROW);
+            // ---- first half: park the slab of tap ti+1 (requested one tap ago) in the other buffer -- its last readers
+            // finished before the previous barrier -- and request tap ti+2 into the same registers
+            if (ti + 1 < ntv) {
+                *reinterpret_cast<float4*>(wnext + wl[0]) = wreg0;
+                if (WLD > 1) *reinterpret_cast<float4*>(wnext + wl[WLD - 1]) = wreg1;
             }
-            if (!(ABL & 4) && ti + 2 < ntv) {
+            if (ti + 2 < ntv) {
                 const char* src = wbase + (long)taplist[3 + ti] * wtap_stride;
                 wreg0 = *reinterpret_cast<const float4*>(src + wf[0]);
                 if (WLD > 1) wreg1 = *reinterpret_cast<const float4*>(src + wf[WLD - 1]);
             }
-            if (!(ABL & 8) && ti == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)
-            const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KW * a.KH);
-            const int tapoff = ((dt * HH + dh) * HW + dw) * C16_ROW;
-            const char* wb = w_lds + (ti & 1) * (C16_BN * C16_ROW);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                for (int wm = 0; wm < WM; ++wm) {
-                    const char* p = in_lds + aoff[wm] + ((ABL & 2) ? 0 : tapoff + s * 64);
-                    if ((ABL & 2) && (ti | s)) continue;
-                    ah[wm] = *reinterpret_cast<const half8*>(p);
-                    al[wm] = *reinterpret_cast<const half8*>(p + 16);
-                }
-#pragma unroll
-                for (int wn = 0; wn < WN; ++wn) {
-                    const char* p = wb + boff[wn] + s * 64;
-                    if ((ABL & 2) && (ti | s)) continue;
-                    bh_[wn] = *reinterpret_cast<const half8*>(p);
-                    bl[wn] = *reinterpret_cast<const half8*>(p + 16);
-                }
-#pragma unroll
-                for (int wm = 0; wm < WM; ++wm)
-#pragma unroll
-                    for (int wn = 0; wn < WN; ++wn) {
-                        if (ABL & 1) {
-                            asm volatile("" ::"v"(ah[wm]), "v"(al[wm]), "v"(bh_[wn]), "v"(bl[wn]));
-                            continue;
-                        }
-                        acc_h[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[wm], bh_[wn], acc_h[wm][wn], 0, 0, 0);
-                        acc_x[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[wm], bl[wn], acc_x[wm][wn], 0, 0, 0);
-                        acc_x[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[wm], bh_[wn], acc_x[wm][wn], 0, 0, 0);
-                    }
-            }
-            if (!(ABL & 16)) __syncthreads();
+            if (ti == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)
+            C16_LOAD_OPS(o1, toff, wb, 64)   // operands of this tap's second k-step ...
+            __builtin_amdgcn_sched_barrier(0);
+            C16_MFMA(o0)                     // ... fly while the first k-step computes
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                 // publishes the slab of tap ti+1
+            if (ti + 1 < ntv) C16_LOAD_OPS(o0, tap_off(taplist[2 + ti]), wnext, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            C16_MFMA(o1)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
                 const int m = wave_m * (32 * WM) + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 const int p = rowpos[m];
                 if (p < 0 || !ncol) continue;
-                float v = fmaf(acc_x[wm][wn][r], 1.0f / 2048.0f, acc_h[wm][wn][r]) + bias;
+                float v = fmaf(acc[wm][wn][r], a.oscale, bias);
                 if (a.res) v += a.res[(long)rowres[m] * a.Cout + n];
                 ssum += v;
                 ssq = fmaf(v, v, ssq);
@@ -323,13 +333,23 @@ int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int
     if (CoutPad > 64 && CoutPad % 128) CoutPad = (CoutPad + 127) / 128 * 128;
     nchunk = (cin + C16_KC - 1) / C16_KC;
     const int ntaps = kt * kh * kw;
+    // power-of-two pre-scale: largest |w| lands in [2^13, 2^14) so every lo part of a non-negligible weight is a normal
+    // fp16 number (full 2^-22 split precision) and hi stays far from the fp16 overflow threshold
+    double wmax = 0.0;
+    for (size_t i = 0; i < (size_t)cout * cin * ntaps; ++i) wmax = std::max(wmax, std::fabs((double)w_src[i] * scale));
+    wexp = 0;
+    if (wmax > 0.0 && std::isfinite(wmax)) {
+        wexp = (int)std::floor(std::log2(16384.0 / wmax));
+        wexp = std::max(-40, std::min(40, wexp));
+    }
+    const double pre = std::ldexp(1.0, wexp);
     std::vector<_Float16> p((size_t)ntaps * nchunk * CoutPad * 64, (_Float16)0.f);
     for (int n = 0; n < cout; ++n)
         for (int c = 0; c < cin; ++c)
             for (int tap = 0; tap < ntaps; ++tap) {
-                const float v = (float)((double)w_src[((size_t)n * cin + c) * ntaps + tap] * scale);
+                const float v = (float)((double)w_src[((size_t)n * cin + c) * ntaps + tap] * scale * pre);
                 const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                const _Float16 lo = (_Float16)(v - (float)hi);
                 const int chunk = c / C16_KC, g = (c % C16_KC) / 8, j = c % 8;
                 _Float16* row = &p[(((size_t)tap * nchunk + chunk) * CoutPad + n) * 64];
                 row[g * 16 + j] = hi;
@@ -342,9 +362,9 @@ int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int
     return I2V_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int ABL = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN>
 static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
-    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, ABL>;
+    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN>;
     static bool attr_set = false;
     if (!attr_set) {
         I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -375,6 +395,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     }
     a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
     a.stats = stats;
+    a.oscale = (float)std::ldexp(1.0, -wts.wexp);
     int TW = W < 8 ? W : 8, TH = H < 8 ? H : 8;
     int rem = C16_BM / (TW * TH);
     int TT = T < rem ? T : rem;
@@ -403,22 +424,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
-#ifdef I2V_ABLATE
-    if (BN == 128) switch (ablate) {
-        case 1: return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
-        case 2: return launch16<4, 2, 2, 2, 2>(a, (unsigned)nblk, lds, st);
-        case 3: return launch16<4, 2, 2, 2, 3>(a, (unsigned)nblk, lds, st);
-        case 4: return launch16<4, 2, 2, 2, 4>(a, (unsigned)nblk, lds, st);
-        case 8: return launch16<4, 2, 2, 2, 8>(a, (unsigned)nblk, lds, st);
-        case 12: return launch16<4, 2, 2, 2, 12>(a, (unsigned)nblk, lds, st);
-        case 14: return launch16<4, 2, 2, 2, 14>(a, (unsigned)nblk, lds, st);
-        case 16: return launch16<4, 2, 2, 2, 16>(a, (unsigned)nblk, lds, st);
-        case 30: return launch16<4, 2, 2, 2, 30>(a, (unsigned)nblk, lds, st);
-        default: break;
-    }
-#else
     (void)ablate;
-#endif
     if (BN == 128) return launch16<4, 2, 2, 2>(a, (unsigned)nblk, lds, st);
     if (BN == 64) return launch16<4, 2, 2, 1>(a, (unsigned)nblk, lds, st);
     return launch16<8, 1, 1, 1>(a, (unsigned)nblk, lds, st);

@@ -94,7 +94,7 @@ __global__ void coef_kernel(const double* __restrict__ sums, float2* __restrict_
 //   gb: [B][H][W][2C] (gamma' = 1 + gamma in [0,C), beta in [C,2C)) or null.
 // One thread = one position x 8 channels (32 B in / 32 B out, consecutive threads = consecutive channel groups);
 // blockIdx.y = sample, all per-sample index math in 32 bits.  HL16: write the split-fp16 operand format of
-// i2v_conv16.hip (8 x fp16 hi | 8 x fp16 lo*2^11 per 8 channels) instead of fp32.
+// i2v_conv16.hip (8 x fp16 hi | 8 x fp16 lo per 8 channels, lo = x - hi) instead of fp32.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
 template <bool HL16>
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
             for (int j = 0; j < 8; ++j) {
                 const _Float16 hh = (_Float16)r[j];
                 hi[j] = hh;
-                lo[j] = (_Float16)((r[j] - (float)hh) * 2048.0f);
+                lo[j] = (_Float16)(r[j] - (float)hh);
             }
             *reinterpret_cast<half8_t*>(o) = hi;
             *reinterpret_cast<half8_t*>(o + 16) = lo;

@@ -19,13 +19,13 @@ int main(int argc, char** argv) {
     if (cw.pack(w.data(), bias.data(), Cout, Cin, 3, 3, 3, 1.0)) { printf("pack: %s\n", i2v_last_error()); return 1; }
     const size_t npos = (size_t)B * T * H * W;
     std::vector<_Float16> in(npos * Cin * 2);
-    for (size_t i = 0; i < in.size(); ++i) in[i] = (_Float16)(rand() / (float)RAND_MAX - 0.5f);
+    for (size_t i = 0; i < in.size(); ++i) in[i] = (_Float16)((rand() / (float)RAND_MAX - 0.5f) * (((i >> 3) & 1) ? 4.8e-4f : 1.0f));  // hi | lo groups
     void* din; float* dout;
     hipMalloc(&din, in.size() * 2);
     hipMalloc(&dout, npos * Cout * 4);
     hipMemcpy(din, in.data(), in.size() * 2, hipMemcpyHostToDevice);
     const double flops = 2.0 * npos * Cin * Cout * 27.0;
-    int variants[] = {0, 1, 2, 3, 4, 8, 12, 14, 16, 30};
+    int variants[] = {0};
     for (int abl : variants) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
