@@ -182,6 +182,24 @@ __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__
     }
 }
 
+// Layout conversion for the stand-alone sub-module entry points: the reference surface is [B][C][T][H][W] ("NCDHW"),
+// the kernels work channels-last.  32x32 tiles through LDS, both sides coalesced.  to_cl: in [B][C][P] -> out [B][P][C].
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int P,
+                                                        int to_cl) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int R = to_cl ? C : P, S = to_cl ? P : C;  // input is [R][S] per sample, output [S][R]
+    const int r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* ip = in + (long)b * R * S;
+    float* op = out + (long)b * R * S;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && s0 + tx < S) tile[i][tx] = ip[(long)(r0 + i) * S + s0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (s0 + i < S && r0 + tx < R) op[(long)(s0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
 }  // namespace i2v
 
 using namespace i2v;
@@ -326,6 +344,79 @@ int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* ou
     if (stats) I2V_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * w.Cout * 16, st));
     ProfScope ps(d, st, 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0);
     return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, 0, stats);
+}
+
+struct BlockBufs {
+    float *a, *dx, *xs_in, *xs_low, *y0, *y1, *gb, *coef;
+    double *sums1, *sums2;
+};
+
+// One GeneratorBlock (decoder.py:33-52) on channels-last tensors: x [B][T/ut][H/us][W/us][n_in] -> xn [B][T][H][W][n_out].
+// `last`: the block output only feeds conv_img(leaky_relu(.)) (decoder.py:117), so the activation is fused here.
+int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, float* xn, const float* img, int img_h, int img_w,
+                  const float* zl, int zstride, int B, const BlockBufs& w, bool& x_stats_ready, bool last, hipStream_t st) {
+    float *a = w.a, *dx = w.dx, *xs_in = w.xs_in, *xs_low = w.xs_low, *y0 = w.y0, *y1 = w.y1, *gb = w.gb, *coef = w.coef;
+    double *sums1 = w.sums1, *sums2 = w.sums2;
+    int rc;
+    auto tap = [&](int k_, int which, const float* src, size_t count) -> int {
+        if (d->tap_dst && d->tap_block == k_ && d->tap_which == which)
+            I2V_HIP_CHECK(hipMemcpyAsync(d->tap_dst, src, std::min(count, d->tap_max) * 4, hipMemcpyDeviceToDevice, st));
+        return I2V_OK;
+    };
+    const int Tl = l.T / l.ut, Hl = l.H / l.us, Wl = l.W / l.us;
+    const long Pl = (long)Tl * Hl * Wl, P = (long)l.T * l.H * l.W;
+    // GroupNorm statistics of the (virtually upsampled) block input == statistics of the low-res tensor; they are
+    // already in sums1 when the previous block's conv_1 accumulated them in its epilogue
+    if (!x_stats_ready && (rc = run_stats(x, sums1, B, Pl, b.n_in, st))) return rc;
+    if ((rc = run_coef(sums1, coef, B, b.n_in, b.groups_spade, (double)Pl, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
+    // SPADE branch (normalization_layer.py:20-23)
+    {
+        const long tot = (long)B * l.H * l.W;
+        hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, y0,
+                           B, img_h, img_w, l.H, l.W);
+        I2V_HIP_CHECK(hipGetLastError());
+    }
+    if (d->cfg.mma == 1) {
+        if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st))) return rc;
+        if ((rc = conv16_forward(b.sp_gb16, y1, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
+    } else {
+        if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
+        if ((rc = conv_forward(b.sp_gb, y1, 128, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
+    }
+    if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
+    const bool f16 = d->cfg.mma == 1;
+    if ((rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16))) return rc;
+    if ((rc = tap(k, 1, a, (size_t)B * P * b.n_in))) return rc;
+    const bool fuse = f16 && conv16_can_fuse_stats(l.T, l.H, l.W);
+    if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
+    else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
+    if (rc) return rc;
+    if ((rc = tap(k, 2, dx, (size_t)B * P * b.n_mid))) return rc;
+    // ADAIN (normalization_layer.py:47-51) + leaky_relu
+    if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
+    if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, zstride, b.zoff, nullptr, nullptr, st))) return rc;
+    if ((rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16))) return rc;
+    if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
+    // shortcut (decoder.py:44-49) at low resolution
+    const float* res = x;
+    if (b.learned) {
+        if ((rc = run_coef(sums1, coef, B, b.n_in, 16, (double)Pl, nullptr, 0, 0, b.gn_w.as<float>(), b.gn_b.as<float>(), st)))
+            return rc;
+        if ((rc = run_modulate(x, coef, nullptr, xs_in, B, Tl, Hl, Wl, b.n_in, 1, 1, 0, st))) return rc;
+        if ((rc = conv_forward(b.convs, xs_in, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, st))) return rc;
+        res = xs_low;
+        if ((rc = tap(k, 4, xs_low, (size_t)B * Pl * b.n_out))) return rc;
+    }
+    // g_4's output only feeds conv_img(leaky_relu(x)) (decoder.py:117): fuse the activation here
+    // (the shortcut's coefficients were derived from sums1 above, so conv_1 may now overwrite sums1 with the
+    // statistics of the block OUTPUT = the next block's input)
+    const bool fuse_out = fuse && !last;
+    if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
+    else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
+    if (rc) return rc;
+    x_stats_ready = fuse_out;
+    if ((rc = tap(k, 5, xn, (size_t)B * P * b.n_out))) return rc;
+    return I2V_OK;
 }
 
 template <class WT>
@@ -564,67 +655,10 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     float* x = xA;
     float* xn = xB;
     bool x_stats_ready = false;
-    auto tap = [&](int k, int which, const float* src, size_t count) -> int {
-        if (d->tap_dst && d->tap_block == k && d->tap_which == which)
-            I2V_HIP_CHECK(hipMemcpyAsync(d->tap_dst, src, std::min(count, d->tap_max) * 4, hipMemcpyDeviceToDevice, st));
-        return I2V_OK;
-    };
+    BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, sums1, sums2};
     for (int k = 0; k < 6; ++k) {
-        Block& b = d->blk[k];
-        const Level& l = d->lvl[k];
-        const int Tl = l.T / l.ut, Hl = l.H / l.us, Wl = l.W / l.us;
-        const long Pl = (long)Tl * Hl * Wl, P = (long)l.T * l.H * l.W;
-        // GroupNorm statistics of the (virtually upsampled) block input == statistics of the low-res tensor; they are
-        // already in sums1 when the previous block's conv_1 accumulated them in its epilogue
-        if (!x_stats_ready && (rc = run_stats(x, sums1, B, Pl, b.n_in, st))) return rc;
-        if ((rc = run_coef(sums1, coef, B, b.n_in, b.groups_spade, (double)Pl, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
-        // SPADE branch (normalization_layer.py:20-23)
-        {
-            const long tot = (long)B * l.H * l.W;
-            hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, y0,
-                               B, img_h, img_w, l.H, l.W);
-            I2V_HIP_CHECK(hipGetLastError());
-        }
-        if (d->cfg.mma == 1) {
-            if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st))) return rc;
-            if ((rc = conv16_forward(b.sp_gb16, y1, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
-        } else {
-            if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
-            if ((rc = conv_forward(b.sp_gb, y1, 128, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
-        }
-        if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
-        const bool f16 = d->cfg.mma == 1;
-        if ((rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16))) return rc;
-        if ((rc = tap(k, 1, a, (size_t)B * P * b.n_in))) return rc;
-        const bool fuse = f16 && conv16_can_fuse_stats(l.T, l.H, l.W);
-        if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
-        else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
-        if (rc) return rc;
-        if ((rc = tap(k, 2, dx, (size_t)B * P * b.n_mid))) return rc;
-        // ADAIN (normalization_layer.py:47-51) + leaky_relu
-        if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
-        if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, d->Nz, b.zoff, nullptr, nullptr, st))) return rc;
-        if ((rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16))) return rc;
-        if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
-        // shortcut (decoder.py:44-49) at low resolution
-        const float* res = x;
-        if (b.learned) {
-            if ((rc = run_coef(sums1, coef, B, b.n_in, 16, (double)Pl, nullptr, 0, 0, b.gn_w.as<float>(), b.gn_b.as<float>(), st)))
-                return rc;
-            if ((rc = run_modulate(x, coef, nullptr, xs_in, B, Tl, Hl, Wl, b.n_in, 1, 1, 0, st))) return rc;
-            if ((rc = conv_forward(b.convs, xs_in, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, st))) return rc;
-            res = xs_low;
-            if ((rc = tap(k, 4, xs_low, (size_t)B * Pl * b.n_out))) return rc;
-        }
-        // g_4's output only feeds conv_img(leaky_relu(x)) (decoder.py:117): fuse the activation here
-        // (the shortcut's coefficients were derived from sums1 above, so conv_1 may now overwrite sums1 with the
-        // statistics of the block OUTPUT = the next block's input)
-        const bool fuse_out = fuse && k < 5;
-        if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
-        else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, k == 5 ? EPI_LRELU : EPI_NONE, st);
-        if (rc) return rc;
-        x_stats_ready = fuse_out;
-        if ((rc = tap(k, 5, xn, (size_t)B * P * b.n_out))) return rc;
+        if ((rc = block_forward(d, k, d->blk[k], d->lvl[k], x, xn, img, img_h, img_w, zl, d->Nz, B, bufs, x_stats_ready, k == 5, st)))
+            return rc;
         std::swap(x, xn);
     }
     {
@@ -634,6 +668,207 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
         if (rc) return rc;
     }
     return I2V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stand-alone GeneratorBlock / Spade / ADAIN / Norm3D (reference tensors [B][C][T][H][W] in and out)
+// ------------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct i2v_gblock {
+    i2v_dec ctx;       // carries cfg.mma and the (unused) profiling / tap state for the shared block code
+    Block b;
+    ConvWeights zlin;  // this block's ADAIN Linear(z_dim, 2*n_mid)
+    int z_dim = 0;
+    bool has_convs = false, has_spade = false, has_adain = false, has_norm_s = false;
+};
+
+namespace {
+
+struct GbWs { size_t x_cl, out_cl, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, total; };
+
+GbWs gb_ws(const i2v_gblock* g, int B, int T, int H, int W) {
+    const Block& b = g->b;
+    const size_t P = (size_t)T * H * W, cm = std::max(b.n_in, std::max(b.n_mid, b.n_out));
+    GbWs L;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o = align_up(o + floats * 4, 256); return r; };
+    L.x_cl = take(B * P * cm); L.out_cl = take(B * P * cm); L.a = take(B * P * cm); L.dx = take(B * P * b.n_mid);
+    L.xs_in = take(B * P * b.n_in); L.xs_low = take(B * P * b.n_out);
+    L.y0 = take((size_t)B * H * W * 16); L.y1 = take((size_t)B * H * W * 128); L.gb = take((size_t)B * H * W * 2 * b.n_in);
+    L.zl = take((size_t)B * 2 * b.n_mid);
+    L.sums1 = take((size_t)B * cm * 4); L.sums2 = take((size_t)B * cm * 4); L.coef = take((size_t)B * cm * 2);
+    L.total = o;
+    return L;
+}
+
+int run_transpose(const float* in, float* out, int B, int C, long P, bool to_cl, hipStream_t st) {
+    const int R = to_cl ? C : (int)P, S = to_cl ? (int)P : C;
+    hipLaunchKernelGGL(transpose_kernel, dim3((S + 31) / 32, (R + 31) / 32, B), dim3(256), 0, st, in, out, C, (int)P, to_cl ? 1 : 0);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int i2v_gblock_create(int32_t n_in, int32_t n_out, int32_t z_dim, int32_t spectral_norm, int32_t mma, i2v_gblock** out) {
+    I2V_REQUIRE(out && n_in > 0 && n_out > 0 && n_in % 8 == 0 && n_out % 8 == 0 && n_in <= 1024 && n_out <= 1024, I2V_E_INVALID,
+                "i2v_gblock_create: channel counts must be multiples of 8 in [8, 1024]");
+    I2V_REQUIRE(z_dim > 0 && z_dim % 4 == 0 && (mma == 0 || mma == 1), I2V_E_INVALID, "i2v_gblock_create: bad z_dim / mma");
+    int ndev = 0;
+    I2V_HIP_CHECK(hipGetDeviceCount(&ndev));
+    I2V_REQUIRE(ndev > 0, I2V_E_HIP, "i2v_gblock_create: no HIP device");
+    auto g = std::make_unique<i2v_gblock>();
+    g->ctx.cfg = i2v_dec_cfg{};
+    g->ctx.cfg.mma = mma;
+    g->ctx.cfg.spectral_norm = spectral_norm;
+    g->ctx.cfg.z_dim = z_dim;
+    g->z_dim = z_dim;
+    Block& b = g->b;
+    b.name = "";
+    b.n_in = n_in; b.n_out = n_out; b.n_mid = std::min(n_in, n_out);
+    b.learned = n_in != n_out;
+    int grp = 16;
+    while (n_in % grp) --grp;
+    b.groups_spade = grp;
+    b.zoff = 0;
+    *out = g.release();
+    return I2V_OK;
+}
+
+void i2v_gblock_destroy(i2v_gblock* g) { delete g; }
+
+int i2v_gblock_load(i2v_gblock* g, const i2v_tensor* tensors, int32_t n_tensors) {
+    I2V_REQUIRE(g && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_gblock_load: null argument");
+    StateDict sd(tensors, n_tensors);
+    Block& b = g->b;
+    const bool sn = g->ctx.cfg.spectral_norm != 0, f16 = g->ctx.cfg.mma == 1;
+    int rc;
+    g->has_convs = g->has_spade = g->has_adain = g->has_norm_s = false;
+    if (sd.has(sn ? "conv_0.weight_orig" : "conv_0.weight")) {
+        if (f16) {
+            if ((rc = sn_pack(sd, "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0_16))) return rc;
+            if ((rc = sn_pack(sd, "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1_16))) return rc;
+        } else {
+            if ((rc = sn_pack(sd, "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
+            if ((rc = sn_pack(sd, "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
+        }
+        if (b.learned && (rc = sn_pack(sd, "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs))) return rc;
+        g->has_convs = true;
+    }
+    if (sd.has("norm_s.bn.weight")) {
+        const float* gw = sd.f32("norm_s.bn.weight", b.n_in);
+        const float* gb = sd.f32("norm_s.bn.bias", b.n_in);
+        if (!gw || !gb) return I2V_E_MISSING;
+        if ((rc = b.gn_w.upload(gw, (size_t)b.n_in * 4))) return rc;
+        if ((rc = b.gn_b.upload(gb, (size_t)b.n_in * 4))) return rc;
+        g->has_norm_s = true;
+    }
+    if (sd.has("norm_0.conv.weight")) {
+        const float* w1 = sd.f32("norm_0.conv.weight", 128 * 3 * 9);
+        const float* b1 = sd.f32("norm_0.conv.bias", 128);
+        const float* wg = sd.f32("norm_0.conv_gamma.weight", (int64_t)b.n_in * 128 * 9);
+        const float* bg = sd.f32("norm_0.conv_gamma.bias", b.n_in);
+        const float* wb = sd.f32("norm_0.conv_beta.weight", (int64_t)b.n_in * 128 * 9);
+        const float* bb = sd.f32("norm_0.conv_beta.bias", b.n_in);
+        if (!w1 || !b1 || !wg || !bg || !wb || !bb) return I2V_E_MISSING;
+        if ((rc = b.sp_conv.pack(w1, b1, 128, 3, 1, 3, 3, 1.0))) return rc;
+        std::vector<float> wgb((size_t)2 * b.n_in * 128 * 9), bgb((size_t)2 * b.n_in);
+        std::memcpy(wgb.data(), wg, (size_t)b.n_in * 128 * 9 * 4);
+        std::memcpy(wgb.data() + (size_t)b.n_in * 128 * 9, wb, (size_t)b.n_in * 128 * 9 * 4);
+        for (int c = 0; c < b.n_in; ++c) { bgb[c] = bg[c] + 1.0f; bgb[b.n_in + c] = bb[c]; }
+        if (f16) rc = b.sp_gb16.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
+        else rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
+        if (rc) return rc;
+        g->has_spade = true;
+    }
+    if (sd.has("norm_1.linear.weight")) {
+        const float* lw = sd.f32("norm_1.linear.weight", (int64_t)2 * b.n_mid * g->z_dim);
+        const float* lb = sd.f32("norm_1.linear.bias", (int64_t)2 * b.n_mid);
+        if (!lw || !lb) return I2V_E_MISSING;
+        if ((rc = g->zlin.pack(lw, lb, 2 * b.n_mid, g->z_dim, 1, 1, 1, 1.0))) return rc;
+        g->has_adain = true;
+    }
+    I2V_REQUIRE(g->has_convs || g->has_spade || g->has_adain || g->has_norm_s, I2V_E_MISSING,
+                "i2v_gblock_load: no GeneratorBlock / Spade / ADAIN / Norm3D keys found");
+    return I2V_OK;
+}
+
+size_t i2v_gblock_workspace_bytes(const i2v_gblock* g, int32_t batch, int32_t t, int32_t h, int32_t w) {
+    if (!g || batch <= 0 || t <= 0 || h <= 0 || w <= 0) return 0;
+    return gb_ws(g, batch, t, h, w).total;
+}
+
+int i2v_gblock_forward(i2v_gblock* g, const float* x, const float* z, const float* img, int32_t img_h, int32_t img_w, float* out,
+                       void* workspace, size_t workspace_bytes, int32_t batch, int32_t t, int32_t h, int32_t w, void* stream) {
+    I2V_REQUIRE(g && g->has_convs && g->has_spade && g->has_adain && (!g->b.learned || g->has_norm_s), I2V_E_STATE,
+                "i2v_gblock_forward: block weights not (fully) loaded");
+    I2V_REQUIRE(x && z && img && out && workspace && batch > 0, I2V_E_INVALID, "i2v_gblock_forward: null argument");
+    const GbWs L = gb_ws(g, batch, t, h, w);
+    I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_gblock_forward: workspace %zu < required %zu", workspace_bytes, L.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const long P = (long)t * h * w;
+    Block& b = g->b;
+    int rc;
+    if ((rc = run_transpose(x, F(L.x_cl), batch, b.n_in, P, true, st))) return rc;
+    if ((rc = conv_forward(g->zlin, z, g->z_dim, F(L.zl), nullptr, 1, 1, batch, 1, 1, 1, EPI_NONE, st))) return rc;
+    BlockBufs bufs{F(L.a), F(L.dx), F(L.xs_in), F(L.xs_low), F(L.y0), F(L.y1), F(L.gb), F(L.coef),
+                   reinterpret_cast<double*>(ws + L.sums1), reinterpret_cast<double*>(ws + L.sums2)};
+    bool ready = false;
+    const Level l{t, h, w, 1, 1};
+    if ((rc = block_forward(&g->ctx, 0, b, l, F(L.x_cl), F(L.out_cl), img, img_h, img_w, F(L.zl), 2 * b.n_mid, batch, bufs, ready,
+                            false, st)))
+        return rc;
+    return run_transpose(F(L.out_cl), out, batch, b.n_out, P, false, st);
+}
+
+int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* cond, int32_t img_h, int32_t img_w, float* out,
+                    void* workspace, size_t workspace_bytes, int32_t batch, int32_t t, int32_t h, int32_t w, void* stream) {
+    I2V_REQUIRE(g && x && out && workspace && batch > 0 && part >= 0 && part <= 2, I2V_E_INVALID, "i2v_gblock_norm: bad argument");
+    const GbWs L = gb_ws(g, batch, t, h, w);
+    I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_gblock_norm: workspace %zu < required %zu", workspace_bytes, L.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const long P = (long)t * h * w;
+    Block& b = g->b;
+    const int B = batch;
+    double* sums = reinterpret_cast<double*>(ws + L.sums1);
+    float *x_cl = F(L.x_cl), *a = F(L.a), *coef = F(L.coef);
+    int rc;
+    const int C = part == 1 ? b.n_mid : b.n_in;
+    if ((rc = run_transpose(x, x_cl, B, C, P, true, st))) return rc;
+    if ((rc = run_stats(x_cl, sums, B, P, C, st))) return rc;
+    if (part == 0) {        // Spade.forward(x, img), normalization_layer.py:18-24
+        I2V_REQUIRE(g->has_spade && cond, I2V_E_STATE, "i2v_gblock_norm: Spade weights not loaded / no start frame");
+        if ((rc = run_coef(sums, coef, B, C, b.groups_spade, (double)P, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
+        const long tot = (long)B * h * w;
+        hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, cond, F(L.y0), B,
+                           img_h, img_w, h, w);
+        I2V_HIP_CHECK(hipGetLastError());
+        if (g->ctx.cfg.mma == 1) {
+            if ((rc = conv_forward(b.sp_conv, F(L.y0), 16, F(L.y1), nullptr, 1, 1, B, 1, h, w, EPI_LRELU | EPI_HL16, st))) return rc;
+            if ((rc = conv16_forward(b.sp_gb16, F(L.y1), F(L.gb), nullptr, 1, 1, B, 1, h, w, EPI_NONE, st))) return rc;
+        } else {
+            if ((rc = conv_forward(b.sp_conv, F(L.y0), 16, F(L.y1), nullptr, 1, 1, B, 1, h, w, EPI_LRELU, st))) return rc;
+            if ((rc = conv_forward(b.sp_gb, F(L.y1), 128, F(L.gb), nullptr, 1, 1, B, 1, h, w, EPI_NONE, st))) return rc;
+        }
+        if ((rc = run_modulate(x_cl, coef, F(L.gb), a, B, t, h, w, C, 1, 1, 0, st))) return rc;
+    } else if (part == 1) { // ADAIN.forward(x, z), normalization_layer.py:47-51
+        I2V_REQUIRE(g->has_adain && cond, I2V_E_STATE, "i2v_gblock_norm: ADAIN weights not loaded / no latent");
+        if ((rc = conv_forward(g->zlin, cond, g->z_dim, F(L.zl), nullptr, 1, 1, B, 1, 1, 1, EPI_NONE, st))) return rc;
+        if ((rc = run_coef(sums, coef, B, C, C, (double)P, F(L.zl), 2 * b.n_mid, 0, nullptr, nullptr, st))) return rc;
+        if ((rc = run_modulate(x_cl, coef, nullptr, a, B, t, h, w, C, 1, 1, 0, st))) return rc;
+    } else {                // Norm3D.forward(x), normalization_layer.py:33-35
+        I2V_REQUIRE(g->has_norm_s && C % 16 == 0, I2V_E_STATE, "i2v_gblock_norm: Norm3D weights not loaded or C %% 16 != 0");
+        if ((rc = run_coef(sums, coef, B, C, 16, (double)P, nullptr, 0, 0, b.gn_w.as<float>(), b.gn_b.as<float>(), st))) return rc;
+        if ((rc = run_modulate(x_cl, coef, nullptr, a, B, t, h, w, C, 1, 1, 0, st))) return rc;
+    }
+    return run_transpose(a, out, B, C, P, false, st);
 }
 
 }  // extern "C"

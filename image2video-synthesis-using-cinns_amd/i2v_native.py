@@ -60,6 +60,14 @@ SYMBOLS = {
                                  c_float, c_void_p]),
     "i2v_row_mean_std": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "i2v_actnorm_logdet": (c_int32, [c_void_p, c_int32, c_float, c_void_p, c_int32, c_void_p]),
+    "i2v_gblock_create": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "i2v_gblock_destroy": (None, [c_void_p]),
+    "i2v_gblock_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
+    "i2v_gblock_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32, c_int32, c_int32]),
+    "i2v_gblock_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
+                                     c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "i2v_gblock_norm": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_int32,
+                                  c_int32, c_int32, c_int32, c_void_p]),
     "i2v_dec_create": (c_int32, [POINTER(DecCfg), POINTER(c_void_p)]),
     "i2v_dec_destroy": (None, [c_void_p]),
     "i2v_dec_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
@@ -345,3 +353,77 @@ def channel_mean_std(flat):
     std = torch.empty(C, dtype=torch.float32, device=flat.device)
     _check(lib().i2v_row_mean_std(flat.data_ptr(), C, N, mean.data_ptr(), std.data_ptr(), _stream()), "i2v_row_mean_std")
     return mean, std
+
+
+def default_mma():
+    """Matrix-core mode of the 3x3x3 convolutions: 1 = split-fp16 (default), 0 = exact fp32 MFMA; env I2V_DEC_MMA."""
+    return int(os.environ.get("I2V_DEC_MMA", "1"))
+
+
+class NativeGBlock:
+    """Handle for ``i2v_gblock_*`` (GeneratorBlock, decoder.py:7-52; tensors in the reference layout [B,C,T,H,W])."""
+
+    def __init__(self, n_in, n_out, z_dim, spectral_norm=True, mma=None):
+        h = c_void_p()
+        _check(lib().i2v_gblock_create(n_in, n_out, z_dim, int(bool(spectral_norm)), default_mma() if mma is None else mma,
+                                       ctypes.byref(h)), "i2v_gblock_create")
+        self._h = h
+        self.n_in, self.n_out, self.n_mid, self.z_dim = n_in, n_out, min(n_in, n_out), z_dim
+        self._ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.i2v_gblock_destroy(self._h)
+            self._h = None
+
+    def load(self, state_dict):
+        arr, keep = _pack_state_dict(state_dict)
+        _check(lib().i2v_gblock_load(self._h, arr, len(arr)), "i2v_gblock_load")
+        del keep
+
+    def _geom(self, x, channels):
+        if x.dim() != 5 or x.shape[1] != channels:
+            raise I2VError(f"expected x [B,{channels},T,H,W], got {tuple(x.shape)}")
+        B, _, T, H, W = x.shape
+        ws = self._ws.get(lib().i2v_gblock_workspace_bytes(self._h, B, T, H, W), x.device)
+        return B, T, H, W, ws
+
+    def forward(self, x, z, img):
+        _require_gpu(x, z, img)
+        B, T, H, W, ws = self._geom(x, self.n_in)
+        if z.shape != (B, self.z_dim) or img.dim() != 4 or img.shape[:2] != (B, 3):
+            raise I2VError(f"GeneratorBlock: expected z [B,{self.z_dim}] and img [B,3,h,w], got {tuple(z.shape)}, {tuple(img.shape)}")
+        out = torch.empty(B, self.n_out, T, H, W, dtype=torch.float32, device=x.device)
+        _check(lib().i2v_gblock_forward(self._h, x.data_ptr(), z.data_ptr(), img.data_ptr(), img.shape[2], img.shape[3],
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, W, _stream()), "i2v_gblock_forward")
+        return out
+
+    def norm(self, part, x, cond):
+        _require_gpu(x, cond)
+        B, T, H, W, ws = self._geom(x, self.n_mid if part == 1 else self.n_in)
+        ih = iw = 0
+        if part == 0:
+            if cond is None or cond.dim() != 4 or cond.shape[:2] != (B, 3):
+                raise I2VError("Spade: expected the start frame [B,3,h,w]")
+            ih, iw = cond.shape[2], cond.shape[3]
+        if part == 1 and (cond is None or cond.shape != (B, self.z_dim)):
+            raise I2VError(f"ADAIN: expected z [B,{self.z_dim}]")
+        out = torch.empty_like(x)
+        _check(lib().i2v_gblock_norm(self._h, part, x.data_ptr(), cond.data_ptr() if cond is not None else None, ih, iw,
+                                     out.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, W, _stream()), "i2v_gblock_norm")
+        return out
+
+
+class NativeNorm:
+    """A lone Spade / ADAIN / Norm3D (normalization_layer.py:5-51) on top of a partially loaded ``i2v_gblock``."""
+    _PART = {"spade": (0, "norm_0."), "adain": (1, "norm_1."), "norm3d": (2, "norm_s.")}
+
+    def __init__(self, kind, num_features, z_dim, mma=None):
+        self.part, self.prefix = self._PART[kind]
+        self.blk = NativeGBlock(num_features, num_features, z_dim if z_dim else 64, spectral_norm=False, mma=mma)
+
+    def load(self, state_dict):
+        self.blk.load({self.prefix + k: v for k, v in state_dict.items()})
+
+    def forward(self, x, cond):
+        return self.blk.norm(self.part, x, cond)

@@ -155,6 +155,27 @@ int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, int64
  * 2 = conv_0 output, 3 = lrelu(ADAIN(.)), 4 = shortcut (low resolution), 5 = block output.  dst = NULL disables. */
 int i2v_dec_debug_tap(i2v_dec* d, int32_t block, int32_t which, float* dst, size_t max_floats);
 
+/* ------------------------------------------------------------------------------------------
+ * Decoder sub-modules, individually callable with the reference's [B][C][T][H][W] tensors:
+ * GeneratorBlock (decoder.py:7-52), Spade / Norm3D / ADAIN (normalization_layer.py:5-51).
+ * T, H, W must be powers of two (>= 1) so the convolutions tile into bricks.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct i2v_gblock i2v_gblock;
+int i2v_gblock_create(int32_t n_in, int32_t n_out, int32_t z_dim, int32_t spectral_norm, int32_t mma, i2v_gblock** out);
+void i2v_gblock_destroy(i2v_gblock* g);
+/* Keys relative to the block: conv_{0,1,s}.*, norm_0.{conv,conv_gamma,conv_beta}.*, norm_1.linear.*, norm_s.bn.*.
+ * Groups of keys that are absent are skipped, so a handle can carry a lone Spade / ADAIN / Norm3D. */
+int i2v_gblock_load(i2v_gblock* g, const i2v_tensor* tensors, int32_t n_tensors);
+size_t i2v_gblock_workspace_bytes(const i2v_gblock* g, int32_t batch, int32_t t, int32_t h, int32_t w);
+/* GeneratorBlock.forward(x, cond1 = z, cond2 = img): x [B,n_in,T,H,W] -> out [B,n_out,T,H,W]. */
+int i2v_gblock_forward(i2v_gblock* g, const float* x, const float* z, const float* img, int32_t img_h, int32_t img_w,
+                       float* out, void* workspace, size_t workspace_bytes, int32_t batch, int32_t t, int32_t h, int32_t w,
+                       void* stream);
+/* part 0: Spade.forward(x, cond = img [B,3,img_h,img_w]); part 1: ADAIN.forward(x [B,n_mid,...], cond = z [B,z_dim]);
+ * part 2: Norm3D.forward(x).  Output has the shape of x. */
+int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* cond, int32_t img_h, int32_t img_w, float* out,
+                    void* workspace, size_t workspace_bytes, int32_t batch, int32_t t, int32_t h, int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

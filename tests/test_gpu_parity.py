@@ -3,6 +3,8 @@ the reference modules and against the CPU oracle.  Run on the GPU box: pytest -m
 
 Tolerances (BASELINE.json north_star / SURVEY §8d): frames and z within 1e-4 relative L2, logdet within 1e-4
 abs-rel, flow round trip <= 1e-4 max-abs on the synthetic (expansive) flow."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -203,11 +205,46 @@ def test_decoder_negative_sigma_and_resized_start_frame():
     assert rel_l2(out.cpu(), ref) < TOL
 
 
-def test_model_forward_semantics_vs_golden(tmp_path):
-    """get_model.Model from YAML + checkpoints on disk: T = 32 autoregressive, quirk Q3 batch slice."""
+def test_decoder_submodules_vs_golden():
+    """Spade / ADAIN / Norm3D / GeneratorBlock called on their own with the reference's [B,C,T,H,W] tensors (F7, F8),
+    in both matrix-core modes; the negative-sigma block pins quirk D6."""
+    from stage1_VAE.modules import decoder as dec, normalization_layer as nl
+    g, meta = load_golden("dec_units")
+    sd = T(synth.decoder_state_dict(**meta["synth"]))
+    x, img, z = cu(g["u_x"]), cu(g["u_img"]), cu(g["u_z"])
+    sp = nl.Spade(32)
+    sp.load_state_dict(sub(sd, "g_3.norm_0."))
+    assert rel_l2(sp.cuda()(x, img).cpu(), g["spade"]) < TOL
+    ad = nl.ADAIN(16, 64)
+    ad.load_state_dict(sub(sd, "g_3.norm_1."))
+    assert rel_l2(ad.cuda()(x[:, :16].contiguous(), z).cpu(), g["adain"]) < TOL
+    n3 = nl.Norm3D(32)
+    n3.load_state_dict(sub(sd, "g_3.norm_s."))
+    assert rel_l2(n3.cuda()(x).cpu(), g["norm3d"]) < TOL
+    xb = cu(g["b_x"])
+    assert meta["sigma_g1_conv0"] < 0
+    for name, n_out, key in (("g_1", 64, "block_g1"), ("g_0", 128, "block_g0")):
+        blk = dec.GeneratorBlock(128, n_out, True, 64)
+        blk.load_state_dict(sub(sd, name + "."))
+        out = blk.cuda()(xb, z, img)
+        assert out.shape == (2, n_out, 2, 8, 8) and rel_l2(out.cpu(), g[key]) < TOL
+
+
+def test_both_matrix_core_modes_agree():
+    """mma = 0 (exact fp32 MFMA) and mma = 1 (split-fp16) against the same golden frames."""
+    from stage1_VAE.modules.decoder import Generator
+    g, meta = load_golden("dec_nf8_bair")
+    for mma in (0, 1):
+        gen = Generator({"channel_factor": 8, "z_dim": 64, "upsample_s": [2, 1], "upsample_t": [2, 1], "spectral_norm": True,
+                         "mma": mma})
+        gen.load_state_dict(T(synth.decoder_state_dict(**meta["synth"])))
+        assert rel_l2(gen.cuda().eval()(cu(g["img"]), cu(g["z"])).cpu(), g["out"]) < TOL
+
+
+def _write_checkpoints(tmp_path, meta):
+    """Checkpoint tree as get_model.Model expects it (get_model.py:15-43): <stage2>/config_stage2.yaml + cINN.pth,
+    <stage1>/config_stage1.yaml + best_PFVD_GEN.pth."""
     import yaml
-    from get_model import Model
-    g, meta = load_golden("model_nf8")
     s1 = tmp_path / "stage1" / "run"
     s2 = tmp_path / "stage2"
     s1.mkdir(parents=True)
@@ -222,7 +259,14 @@ def test_model_forward_semantics_vs_golden(tmp_path):
                               "model_name": "run", "model_path": str(tmp_path / "stage1") + "/"},
         "Training": {"bs": 50}, "Data": {"img_size": 64}}))
     torch.save({"state_dict": T(synth.flow_state_dict(**meta["synth_flow"]))}, s2 / "cINN.pth")
-    model = Model(str(s2) + "/", 32)
+    return str(s2) + "/"
+
+
+def test_model_forward_semantics_vs_golden(tmp_path):
+    """get_model.Model from YAML + checkpoints on disk: T = 32 autoregressive, quirk Q3 batch slice."""
+    from get_model import Model
+    g, meta = load_golden("model_nf8")
+    model = Model(_write_checkpoints(tmp_path, meta), 32)
     y32 = model(cu(g["x1"]), residual=cu(g["r1"]), embed=cu(g["e1"]))
     assert y32.shape == (1, 32, 3, 64, 64) and rel_l2(y32.cpu(), g["y32"]) < TOL
     model.vid_length = 2
@@ -232,6 +276,24 @@ def test_model_forward_semantics_vs_golden(tmp_path):
     model.vid_length = 20
     assert list(model(cu(g["x1"]), residual=cu(g["r1"]), embed=cu(g["e1"])).shape) == list(g["y20_shape"])
     assert model.synthesize(cu(g["x3"]), residual=cu(g["r3"]), embed=cu(g["e3"])).shape[0] == 3
+
+
+def test_generate_samples_cli(tmp_path, monkeypatch):
+    """The sampling CLI end to end: PNG start frames -> results.gif (B = 5 images, -bs 2 -> short last batch)."""
+    from PIL import Image
+    import generate_samples
+    _, meta = load_golden("model_nf8")
+    ckpt = _write_checkpoints(tmp_path, meta)
+    img_dir = tmp_path / "imgs"
+    img_dir.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(5):
+        Image.fromarray(rng.integers(0, 255, (48, 72, 3), dtype=np.uint8)).save(img_dir / f"f{i}.png")
+    out_dir = tmp_path / "out"
+    generate_samples.main(["-gpu", os.environ.get("HIP_VISIBLE_DEVICES", "0"), "-dataset", "bair", "-ckpt_path", ckpt,
+                           "-bs", "2", "-embed_seed", "1", "-img_path", str(img_dir) + "/", "-out_path", str(out_dir) + "/"])
+    gif = Image.open(out_dir / "results.gif")
+    assert gif.n_frames == 16 and gif.size == (5 * 64, 64)
 
 
 def test_full_size_properties_bair_b8():
