@@ -157,7 +157,7 @@ def main():
             "config": {"workload": f"{cfg['name']}, batch {per_gpu}/GPU, vid_length {args.vid_length}: "
                                    "20-block cINN inverse + decoder pass(es)" + (" + RCCL all-gather" if world > 1 else ""),
                        "global_batch": total, "frames_per_step": frames_per_step, "parallelism": f"batch-shard x{world}"},
-            "roofline": roofline(prof, dt, gen.mma),
+            "roofline": roofline(prof, dt, gen.mma, args.config == "bair64" and per_gpu == 64 and args.vid_length == 16),
             "roofline_cinn": {
                 "kernel": "cINN inverse pass (flow_linear_kernel + flow_tail_kernel chain)",
                 "bound": "hbm", "bytes_per_pass": cinn_bytes,
@@ -174,7 +174,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(prof, dt, mma):
+def roofline(prof, dt, mma, default_workload=False):
     """Dominant kernel = the 3x3x3 Conv3d implicit GEMM.  achieved = ALGORITHMIC FLOPs (2*M*N*K per launch, summed) /
     summed launch duration (HIP events on the launch stream, inside the timed region).  In split-fp16 mode every
     algorithmic FLOP costs three fp16 MFMA FLOPs, so the fraction of the dense fp16 peak that the matrix cores are
@@ -188,8 +188,18 @@ def roofline(prof, dt, mma):
     else:
         kernel = "conv_mfma_f32_kernel (3x3x3 Conv3d implicit GEMM, v_mfma_f32_32x32x2_f32)"
         peak, issue = PEAK_FP32_MFMA_TFLOPS, 1.0
+    # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
+    # rocprofv3 --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/r01_c_pmc_hbm_traffic.json).
+    # bench.py cannot read PMCs itself: the figure is valid for the default workload (bair64, batch 64, mma = 1) only.
+    traffic = None
+    if mma == 1 and default_workload:
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_c_pmc_hbm_traffic.json")) as f:
+                traffic = json.load(f)["dominant_kernel"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
     return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-            "traffic": None, "mfma_issue_frac": issue * ach / peak, "launches": prof["conv3_launches"],
+            "traffic": traffic, "mfma_issue_frac": issue * ach / peak, "launches": prof["conv3_launches"],
             "avg_launch_ms": prof["conv3_ms"] / max(prof["conv3_launches"], 1), "time_share": prof["conv3_ms"] * 1e-3 / dt}
 
 

@@ -1,9 +1,10 @@
 // conv_img: Conv3d(nf -> 3, 3x3x3, pad 1) + tanh, stored as [B][T][3][H][W]  (reference decoder.py:81,117-120).
 //
 // N = 3 output channels cannot feed a 32-wide matrix-core tile (the generic MFMA kernel wastes 10/11 of its columns
-// here), so this layer runs on the vector ALU in exact fp32: one thread per output position, three accumulators, the
-// 4x8x8 position brick's input halo staged in LDS per 16-channel chunk (rows padded to 20 floats, ds_read_b128), and the
-// [tap][16][3(+1)] weight slab read through the scalar cache (wave-uniform addresses -> s_load, SGPR operands of v_fma).
+// here), so this layer runs on the vector ALU in exact fp32: the 4x8x8 position brick's input halo is staged in LDS per
+// 16-channel chunk (rows padded to 20 floats, ds_read_b128) together with the chunk's [27][16][3(+1)] weight slab.
+// (A first version read the weights through the scalar cache: the 20 KB weight set thrashes the 16 KB scalar cache and
+// the kernel ran 5x slower.)
 #include <algorithm>
 
 #include "i2v_conv.h"
@@ -15,10 +16,13 @@ constexpr int CI_HT = CI_TT + 2, CI_HH = CI_TH + 2, CI_HW = CI_TW + 2;
 constexpr int CI_NPOS = CI_HT * CI_HH * CI_HW;  // 600
 constexpr int CI_LS = 20;
 
-__global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+// One thread = TWO output positions (w and w+4 of the same brick row): every weight float4 fetched from LDS (a broadcast
+// read, all lanes the same address) feeds two FMA triplets, which keeps the LDS pipe below the VALU time.
+__global__ __launch_bounds__(128) void conv_img_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int T,
                                                        int H, int W, int C, int nchunk) {
     __shared__ __attribute__((aligned(16))) float in_lds[CI_NPOS * CI_LS];
+    __shared__ __attribute__((aligned(16))) float w_lds[27 * 64];
     __shared__ int gpos[CI_NPOS];
     const int tid = threadIdx.x;
     int brick = blockIdx.x;
@@ -27,7 +31,7 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
     const int bh = brick % nbH; brick /= nbH;
     const int bt = brick % nbT; brick /= nbT;
     const int b = brick, t0 = bt * CI_TT, h0 = bh * CI_TH, w0 = bw * CI_TW;
-    for (int p0 = tid; p0 < CI_NPOS; p0 += 256) {
+    for (int p0 = tid; p0 < CI_NPOS; p0 += 128) {
         int p = p0;
         const int iw = p % CI_HW; p /= CI_HW;
         const int ih = p % CI_HH; p /= CI_HH;
@@ -35,32 +39,42 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
         const bool ok = (unsigned)t < (unsigned)T && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
         gpos[p0] = ok ? ((b * T + t) * H + h) * W + w : -1;
     }
-    const int iw = tid % CI_TW, ih = (tid / CI_TW) % CI_TH, it = tid / (CI_TW * CI_TH);
+    const int iw = tid & 3, ih = (tid >> 2) % CI_TH, it = tid / (4 * CI_TH);   // positions (iw) and (iw + 4)
     const float* my = in_lds + ((it * CI_HH + ih) * CI_HW + iw) * CI_LS;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
     __syncthreads();
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();
         const int c0 = ch * 16;
         {   // all of a thread's pieces are requested back to back (branch-free, clamped): one exposed latency per chunk
-            constexpr int NS = (CI_NPOS * 4 + 255) / 256;
+            constexpr int NS = (CI_NPOS * 4 + 127) / 128;
             float4 v[NS];
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
-                const int idx = tid + u * 256;
+                const int idx = tid + u * 128;
                 const int q = idx & 3, gp = gpos[idx < CI_NPOS * 4 ? (idx >> 2) : 0];
                 const bool ok = idx < CI_NPOS * 4 && gp >= 0 && c0 + 4 * q < C;
                 const float4 t4 = *reinterpret_cast<const float4*>(in + (ok ? (long)gp * C + c0 + 4 * q : 0));
                 v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            float4 wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = tid + u * 128;  // 27*64/4 = 432 float4
+                wv[u] = *reinterpret_cast<const float4*>(wp + (long)ch * 27 * 64 + (f < 432 ? f : 0) * 4);
+            }
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
-                const int idx = tid + u * 256;
+                const int idx = tid + u * 128;
                 if (idx < CI_NPOS * 4) *reinterpret_cast<float4*>(in_lds + (idx >> 2) * CI_LS + 4 * (idx & 3)) = v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = tid + u * 128;
+                if (f < 432) *reinterpret_cast<float4*>(w_lds + f * 4) = wv[u];
             }
         }
         __syncthreads();
-        const float* wc = wp + (long)ch * 27 * 64;
 #pragma unroll 1
         for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -68,17 +82,17 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
 #pragma unroll
                 for (int dw = 0; dw < 3; ++dw) {
                     const float* row = my + ((dt * CI_HH + dh) * CI_HW + dw) * CI_LS;
-                    const float* wt = wc + ((dt * 3 + dh) * 3 + dw) * 64;  // [16 c][4]
+                    const float* wt = w_lds + ((dt * 3 + dh) * 3 + dw) * 64;  // [16 c][4]
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
-                        const float x[4] = {v.x, v.y, v.z, v.w};
+                        const float4 xa = *reinterpret_cast<const float4*>(row + 4 * q);
+                        const float4 xb = *reinterpret_cast<const float4*>(row + 4 * CI_LS + 4 * q);
+                        const float pa[4] = {xa.x, xa.y, xa.z, xa.w}, pb[4] = {xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float* w4 = wt + (4 * q + j) * 4;
-                            acc0 = fmaf(x[j], w4[0], acc0);
-                            acc1 = fmaf(x[j], w4[1], acc1);
-                            acc2 = fmaf(x[j], w4[2], acc2);
+                            const float4 w4 = *reinterpret_cast<const float4*>(wt + (4 * q + j) * 4);
+                            a0 = fmaf(pa[j], w4.x, a0); a1 = fmaf(pa[j], w4.y, a1); a2 = fmaf(pa[j], w4.z, a2);
+                            b0 = fmaf(pb[j], w4.x, b0); b1 = fmaf(pb[j], w4.y, b1); b2 = fmaf(pb[j], w4.z, b2);
                         }
                     }
                 }
@@ -86,9 +100,9 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
     const int t = t0 + it, h = h0 + ih, w = w0 + iw;
     const long HWo = (long)H * W;
     float* o = out + ((long)(b * T + t) * 3) * HWo + (long)h * W + w;
-    o[0] = tanhf(acc0 + bias[0]);
-    o[HWo] = tanhf(acc1 + bias[1]);
-    o[2 * HWo] = tanhf(acc2 + bias[2]);
+    const float c0_ = bias[0], c1_ = bias[1], c2_ = bias[2];
+    o[0] = tanhf(a0 + c0_); o[HWo] = tanhf(a1 + c1_); o[2 * HWo] = tanhf(a2 + c2_);
+    o[4] = tanhf(b0 + c0_); o[HWo + 4] = tanhf(b1 + c1_); o[2 * HWo + 4] = tanhf(b2 + c2_);
 }
 
 int ConvImgWeights::pack(const float* w_src, const float* bias_src, int cin) {
@@ -110,7 +124,7 @@ int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv_img: weights not packed");
     I2V_REQUIRE(conv_img_supported(T, H, W, wts.Cin), I2V_E_INVALID, "conv_img: unsupported geometry");
     const long nblk = (long)B * (T / CI_TT) * (H / CI_TH) * (W / CI_TW);
-    hipLaunchKernelGGL(conv_img_kernel, dim3((unsigned)nblk), dim3(256), 0, st, in, wts.w.as<float>(), wts.bias.as<float>(), out,
+    hipLaunchKernelGGL(conv_img_kernel, dim3((unsigned)nblk), dim3(128), 0, st, in, wts.w.as<float>(), wts.bias.as<float>(), out,
                        B, T, H, W, wts.Cin, wts.nchunk);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;

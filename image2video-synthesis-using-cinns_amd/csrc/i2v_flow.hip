@@ -25,6 +25,7 @@
 #include "i2v_linear.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 namespace i2v {
@@ -129,6 +130,7 @@ struct i2v_flow {
     i2v_flow_cfg cfg;
     int device = 0;
     bool loaded = false;
+    int nt = 4;     // rows per workgroup of the hidden-layer launches (env I2V_FLOW_NT = 4 | 8)
     int S = 0;      // half-steps = 2 * n_flows
     int H = 0, E = 0, ld0 = 0, depth = 0;
     DevBuf W0, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;
@@ -272,7 +274,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
             m.N = N2;
             m.B = B;
             m.slope = 0.01f;
-            if ((rc = launch_linear<4, 8>(m, st))) return rc;
+            if ((rc = (f->nt == 8 ? launch_linear<8, 8>(m, st) : launch_linear<4, 8>(m, st)))) return rc;
             std::swap(cur, nxt);
         }
         // last layer + coupling + the ops up to the next half-step's first layer
@@ -366,6 +368,7 @@ int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out) {
     f->E = cfg->embedding_dim;
     f->ld0 = 32 + cfg->embedding_dim;
     f->depth = cfg->hidden_depth;
+    if (const char* e = getenv("I2V_FLOW_NT")) f->nt = atoi(e) == 8 ? 8 : 4;
     *out = f.release();
     return I2V_OK;
 }
