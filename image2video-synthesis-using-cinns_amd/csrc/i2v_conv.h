@@ -31,6 +31,7 @@ struct ConvArgs {
     const float* wp;
     const float* bias;
     const float* res;   // channels-last [B][T/rt][H/rs][W/rs][Cout] or null
+    const float* coef;  // optional per-(b,c) affine (A,B) pairs applied to the input on load: x*A + B (1x1x1 convs only)
     float* out;
     int B, T, H, W;
     int CinAct;         // channel stride of `in` (>= Cin of the weights)
@@ -44,7 +45,7 @@ struct ConvArgs {
 
 // Chooses the brick and the tile variant and enqueues the kernel.
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
-                 int B, int T, int H, int W, int epi, hipStream_t st);
+                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef = nullptr);
 
 // ---- split-fp16 path (i2v_conv16.hip): operands carried as (fp16 hi, fp16 lo = x - hi) pairs, 3 fp16 MFMAs per product
 struct Conv16Weights {

@@ -124,6 +124,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
             if (b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W &&
                 c < a.CinAct) {
                 v = *reinterpret_cast<const float4*>(a.in + ((((long)b * a.T + t) * a.H + h) * a.W + w) * a.CinAct + c);
+                if (a.coef) {  // normalisation folded into the load: norm(x)*g + beta == x*A + B per (sample, channel)
+                    const float4 ab0 = *reinterpret_cast<const float4*>(a.coef + ((long)b * a.CinAct + c) * 2);
+                    const float4 ab1 = *reinterpret_cast<const float4*>(a.coef + ((long)b * a.CinAct + c) * 2 + 4);
+                    v.x = fmaf(v.x, ab0.x, ab0.y); v.y = fmaf(v.y, ab0.z, ab0.w);
+                    v.z = fmaf(v.z, ab1.x, ab1.y); v.w = fmaf(v.w, ab1.z, ab1.w);
+                }
             }
             *reinterpret_cast<float4*>(in_lds + (idx >> 2) * LS + 4 * q) = v;
         }
@@ -259,11 +265,14 @@ int launch(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
 }  // namespace
 
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
-                 int B, int T, int H, int W, int epi, hipStream_t st) {
+                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv: weights not packed");
     I2V_REQUIRE(cin_act % 4 == 0 && cin_act >= wts.Cin, I2V_E_INVALID, "conv: activation channels %d (weights %d)",
                 cin_act, wts.Cin);
+    I2V_REQUIRE(!coef || (wts.KT == 1 && wts.KH == 1 && wts.KW == 1), I2V_E_INVALID,
+                "conv: the on-load affine is only valid without padding (1x1x1 kernels)");
     ConvArgs a{};
+    a.coef = coef;
     a.in = in; a.wp = wts.w.as<float>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
     a.B = B; a.T = T; a.H = H; a.W = W; a.CinAct = cin_act;
     a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;

@@ -44,7 +44,7 @@ struct Conv16Args {
     float* out;       // fp32 channels-last [B][T][H][W][Cout]
     double* stats;    // optional [B][Cout][2]: per-(sample, channel) sum / sum of squares of the stored values (TB == 1)
     int B, T, H, W, Cin, Cout, CoutPad, nchunk;
-    int KT, KH, KW, tap_base;
+    int KT, KH, KW, tap_base, ztap;  // ztap: index of the all-zero weight slab (stage padding)
     int TB, TT, TH, TW, nbB, nbT, nbH, nbW;
     int HWp;   // halo row pitch in positions (>= TW + KW - 1; 12 for 8-wide bricks: conflict-free 4x4 patches)
     int patch; // 1: MFMA rows are assigned to brick positions in 4x4 (h,w) patches per ds_read_b128 lane group
@@ -71,9 +71,12 @@ __device__ __forceinline__ int brick_index(int row, int TH, int TW, int patch) {
     return (plane * TH + py * 4 + (q >> 2)) * TW + px * 4 + (q & 3);
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+// TPS = taps per pipeline stage: the narrower the channel tile, the more taps share one weight buffer / barrier
+// (BN x TPS = 128 rows per buffer for every variant).
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
 __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     constexpr int C16_BN = 32 * WN * WAVES_N;
+    constexpr int WBUF = TPS * C16_BN * C16_ROW;  // bytes per weight buffer
     static_assert(32 * WM * WAVES_M == C16_BM && WAVES_M * WAVES_N == 8, "tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -89,10 +92,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
 
     char* in_lds = smem;
     char* w_lds = smem + NPOS * C16_ROW;
-    int* rowpos = reinterpret_cast<int*>(w_lds + 2 * C16_BN * C16_ROW);
+    int* rowpos = reinterpret_cast<int*>(w_lds + 2 * WBUF);
     int* rowres = rowpos + C16_BM;
-    int* taplist = rowres + C16_BM;
-    int* gpos = taplist + 32;  // [NPOS] linear input position of every staged halo row, -1 = zero padding
+    int* taplist = rowres + C16_BM;  // [0] = padded tap count, [1..32] weight-slab index, [33..64] LDS byte offset of the tap
+    int* gpos = taplist + 72;  // [NPOS] linear input position of every staged halo row, -1 = zero padding
 
     const int nNt = a.CoutPad / C16_BN;
     const int ntile = blockIdx.x % nNt;
@@ -116,10 +119,17 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     if (tid == 0) {
         int cnt = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
-            const int dt = tap / (a.KH * a.KW);
+            const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KH * a.KW);
             const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
-            if (hi < 0 || lo >= a.T) continue;
-            taplist[1 + cnt++] = tap;
+            if (hi < 0 || lo >= a.T) continue;  // the whole brick meets zero padding only
+            taplist[1 + cnt] = a.tap_base + tap;
+            taplist[33 + cnt] = ((dt * HH + dh) * HW + dw) * C16_ROW;
+            ++cnt;
+        }
+        while (cnt % TPS) {  // pad the stage with the all-zero weight slab
+            taplist[1 + cnt] = a.ztap;
+            taplist[33 + cnt] = 0;
+            ++cnt;
         }
         taplist[0] = cnt;
     }
@@ -155,8 +165,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
-    constexpr int WF4 = C16_BN * 8;            // 16-byte pieces per weight slab
-    constexpr int WLD = (WF4 + 511) / 512;
+    constexpr int WF4 = TPS * C16_BN * 8;      // 16-byte pieces per stage of weights (TPS slabs)
+    constexpr int WLD = WF4 / 512;
+    static_assert(WF4 % 512 == 0 && WLD <= 2, "weight pieces per thread");
     const long slab = (long)a.CoutPad * 128;  // bytes per (tap, chunk)
     __syncthreads();
     const int ntv = taplist[0];
@@ -208,13 +219,24 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
             acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
     }
-    auto tap_off = [&](int tap_) {
-        const int dw_ = tap_ % a.KW, dh_ = (tap_ / a.KW) % a.KH, dt_ = tap_ / (a.KW * a.KH);
-        return ((dt_ * HH + dh_) * HW + dw_) * C16_ROW;
-    };
-
     C16_REQUEST_INPUT(0)
-    const int pf_stage = ntv > 4 ? ntv - 4 : 0;
+    const int nst = ntv / TPS;  // stages per chunk
+    constexpr int PF = TPS >= 4 ? 1 : 4 / TPS;
+    const int pf_stage = nst > PF ? nst - PF : 0;
+    const int* tapw = taplist + 1;
+    const int* tapo = taplist + 33;
+    // per-thread weight piece geometry (constant over the kernel): piece f of a stage = tap f / (BN*8) of the stage,
+    // 16-byte piece f % (BN*8) of that tap's [BN][128 B] slab
+    int wtis[WLD], wsrc[WLD], wdst[WLD];
+#pragma unroll
+    for (int u = 0; u < WLD; ++u) {
+        const int f = tid + u * 512;
+        const int tis = f / (C16_BN * 8), fr = f % (C16_BN * 8);
+        wtis[u] = tis;
+        wsrc[u] = fr * 16;
+        wdst[u] = tis * (C16_BN * C16_ROW) + (fr >> 3) * C16_ROW + (fr & 7) * 16;
+    }
+    const long wtap_stride = (long)a.nchunk * slab;
 
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();
@@ -231,57 +253,55 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
                 v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)ch * 128 + q * 16);
             *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;
         }
-        // weights: slab of the first tap straight to LDS, slab of the second tap into registers.  Every thread moves
-        // WLD 16-byte pieces per slab; piece indices are clamped instead of predicated (duplicates rewrite identical
-        // bytes) so the loads stay branch-free and in registers.
-        const long wtap_stride = (long)a.nchunk * slab;
-        const char* wbase = a.wp + (long)ch * slab + (long)n0 * 128 + (long)a.tap_base * wtap_stride;
-        int wf[WLD], wl[WLD];
+        // weights: stage 0 straight to LDS, stage 1 into registers (branch-free, always in registers)
+        const char* wbase = a.wp + (long)ch * slab + (long)n0 * 128;
+        float4 wreg[WLD];
 #pragma unroll
-        for (int u = 0; u < WLD; ++u) {
-            int f = tid + u * 512;
-            f = f < WF4 ? f : WF4 - 1;
-            wf[u] = f * 16;
-            wl[u] = (f >> 3) * C16_ROW + (f & 7) * 16;
+        for (int u = 0; u < WLD; ++u) wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nst > 0) {
+#pragma unroll
+            for (int u = 0; u < WLD; ++u)
+                *reinterpret_cast<float4*>(w_lds + wdst[u]) =
+                    *reinterpret_cast<const float4*>(wbase + (long)tapw[wtis[u]] * wtap_stride + wsrc[u]);
         }
-        float4 wreg0 = make_float4(0.f, 0.f, 0.f, 0.f), wreg1 = wreg0;
-        if (ntv > 0) {
-            const char* src = wbase + (long)taplist[1] * wtap_stride;
-            *reinterpret_cast<float4*>(w_lds + wl[0]) = *reinterpret_cast<const float4*>(src + wf[0]);
-            if (WLD > 1) *reinterpret_cast<float4*>(w_lds + wl[WLD - 1]) = *reinterpret_cast<const float4*>(src + wf[WLD - 1]);
-        }
-        if (ntv > 1) {
-            const char* src = wbase + (long)taplist[2] * wtap_stride;
-            wreg0 = *reinterpret_cast<const float4*>(src + wf[0]);
-            if (WLD > 1) wreg1 = *reinterpret_cast<const float4*>(src + wf[WLD - 1]);
+        if (nst > 1) {
+#pragma unroll
+            for (int u = 0; u < WLD; ++u)
+                wreg[u] = *reinterpret_cast<const float4*>(wbase + (long)tapw[TPS + wtis[u]] * wtap_stride + wsrc[u]);
         }
         __syncthreads();
-        if (ntv > 0) C16_LOAD_OPS(o0, tap_off(taplist[1]), w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
-        for (int ti = 0; ti < ntv; ++ti) {
-            const int toff = tap_off(taplist[1 + ti]);
-            const char* wb = w_lds + (ti & 1) * (C16_BN * C16_ROW);
-            char* wnext = w_lds + ((ti + 1) & 1) * (C16_BN * C16_ROW);
-            // ---- first half: park the slab of tap ti+1 (requested one tap ago) in the other buffer -- its last readers
-            // finished before the previous barrier -- and request tap ti+2 into the same registers
-            if (ti + 1 < ntv) {
-                *reinterpret_cast<float4*>(wnext + wl[0]) = wreg0;
-                if (WLD > 1) *reinterpret_cast<float4*>(wnext + wl[WLD - 1]) = wreg1;
+        if (nst > 0) C16_LOAD_OPS(o0, tapo[0], w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
+        for (int st = 0; st < nst; ++st) {
+            const char* wb = w_lds + (st & 1) * WBUF;
+            char* wnext = w_lds + ((st + 1) & 1) * WBUF;
+            // park the weights of stage st+1 (requested one stage ago) in the other buffer -- its last readers finished
+            // before the previous barrier -- and request stage st+2 into the same registers
+            if (st + 1 < nst) {
+#pragma unroll
+                for (int u = 0; u < WLD; ++u) *reinterpret_cast<float4*>(wnext + wdst[u]) = wreg[u];
             }
-            if (ti + 2 < ntv) {
-                const char* src = wbase + (long)taplist[3 + ti] * wtap_stride;
-                wreg0 = *reinterpret_cast<const float4*>(src + wf[0]);
-                if (WLD > 1) wreg1 = *reinterpret_cast<const float4*>(src + wf[WLD - 1]);
+            if (st + 2 < nst) {
+#pragma unroll
+                for (int u = 0; u < WLD; ++u)
+                    wreg[u] = *reinterpret_cast<const float4*>(wbase + (long)tapw[(st + 2) * TPS + wtis[u]] * wtap_stride + wsrc[u]);
             }
-            if (ti == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)
-            C16_LOAD_OPS(o1, toff, wb, 64)   // operands of this tap's second k-step ...
-            __builtin_amdgcn_sched_barrier(0);
-            C16_MFMA(o0)                     // ... fly while the first k-step computes
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                 // publishes the slab of tap ti+1
-            if (ti + 1 < ntv) C16_LOAD_OPS(o0, tap_off(taplist[2 + ti]), wnext, 0)
-            __builtin_amdgcn_sched_barrier(0);
-            C16_MFMA(o1)
-            __builtin_amdgcn_sched_barrier(0);
+            if (st == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)
+            // 2*TPS k-steps: the operands of k-step q+1 are read from LDS while k-step q's MFMAs run; the stage's single
+            // barrier sits in front of the last k-step and publishes the next stage's weights
+#pragma unroll
+            for (int q = 0; q < 2 * TPS; ++q) {
+                if (q + 1 < 2 * TPS) {
+                    const int tq = (q + 1) >> 1, sq = (q + 1) & 1;
+                    if ((q + 1) & 1) C16_LOAD_OPS(o1, tapo[st * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)
+                    else C16_LOAD_OPS(o0, tapo[st * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)
+                } else {
+                    __syncthreads();
+                    if (st + 1 < nst) C16_LOAD_OPS(o0, tapo[(st + 1) * TPS], wnext, 0)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (q & 1) C16_MFMA(o1) else C16_MFMA(o0)
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -343,7 +363,7 @@ int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int
         wexp = std::max(-40, std::min(40, wexp));
     }
     const double pre = std::ldexp(1.0, wexp);
-    std::vector<_Float16> p((size_t)ntaps * nchunk * CoutPad * 64, (_Float16)0.f);
+    std::vector<_Float16> p((size_t)(ntaps + 1) * nchunk * CoutPad * 64, (_Float16)0.f);  // + one all-zero tap
     for (int n = 0; n < cout; ++n)
         for (int c = 0; c < cin; ++c)
             for (int tap = 0; tap < ntaps; ++tap) {
@@ -362,9 +382,9 @@ int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int
     return I2V_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
 static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
-    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN>;
+    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS>;
     static bool attr_set = false;
     if (!attr_set) {
         I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -389,6 +409,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     a.in = static_cast<const char*>(in_hl16); a.wp = wts.w.as<char>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
     a.B = B; a.T = T; a.H = H; a.W = W; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
     a.KT = wts.KT; a.KH = wts.KH; a.KW = wts.KW; a.tap_base = 0;
+    a.ztap = wts.KT * wts.KH * wts.KW;
     if (T == 1 && wts.KT == 3) {  // a single frame only ever meets the centre time-slice of the kernel (rest is padding)
         a.KT = 1;
         a.tap_base = wts.KH * wts.KW;
@@ -408,26 +429,25 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     I2V_REQUIRE(!stats || TB == 1, I2V_E_INVALID, "conv16: fused statistics need bricks inside one sample");
     a.TB = TB; a.TT = TT; a.TH = TH; a.TW = TW;
     a.nbB = (B + TB - 1) / TB; a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;
-    const int BNsel = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
     a.HWp = TW + a.KW - 1;
     a.patch = (TW % 4 == 0 && TH % 4 == 0) ? 1 : 0;
     if (a.patch) {  // a halo row pitch = 4 or 12 (mod 16) makes the 4x4 patches conflict-free; keep it if LDS allows
         int hp = a.HWp;
         while (hp % 16 != 4 && hp % 16 != 12) ++hp;
         const size_t rows = (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * hp;
-        const size_t need = rows * C16_ROW + 2 * (size_t)BNsel * C16_ROW + (2 * C16_BM + 32) * 4 + rows * 4;
+        const size_t need = rows * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + rows * 4;
         if (need <= 160 * 1024) a.HWp = hp;
     }
     const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * a.HWp;
     const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
-    const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)BN * C16_ROW + (2 * C16_BM + 32) * 4 + (size_t)npos * 4;
+    const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + (size_t)npos * 4;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
     (void)ablate;
-    if (BN == 128) return launch16<4, 2, 2, 2>(a, (unsigned)nblk, lds, st);
-    if (BN == 64) return launch16<4, 2, 2, 1>(a, (unsigned)nblk, lds, st);
-    return launch16<8, 1, 1, 1>(a, (unsigned)nblk, lds, st);
+    if (BN == 128) return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
+    if (BN == 64) return launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
+    return launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);
 }
 
 }  // namespace i2v

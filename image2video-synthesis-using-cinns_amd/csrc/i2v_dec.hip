@@ -402,8 +402,9 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     if (b.learned) {
         if ((rc = run_coef(sums1, coef, B, b.n_in, 16, (double)Pl, nullptr, 0, 0, b.gn_w.as<float>(), b.gn_b.as<float>(), st)))
             return rc;
-        if ((rc = run_modulate(x, coef, nullptr, xs_in, B, Tl, Hl, Wl, b.n_in, 1, 1, 0, st))) return rc;
-        if ((rc = conv_forward(b.convs, xs_in, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, st))) return rc;
+        // Norm3D folded into the 1x1x1 conv's loads (no padding taps -> exact): no normalised copy of x is written
+        (void)xs_in;
+        if ((rc = conv_forward(b.convs, x, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, st, coef))) return rc;
         res = xs_low;
         if ((rc = tap(k, 4, xs_low, (size_t)B * Pl * b.n_out))) return rc;
     }
