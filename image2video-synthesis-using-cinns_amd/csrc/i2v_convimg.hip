@@ -14,7 +14,10 @@ namespace i2v {
 constexpr int CI_TT = 4, CI_TH = 8, CI_TW = 8;
 constexpr int CI_HT = CI_TT + 2, CI_HH = CI_TH + 2, CI_HW = CI_TW + 2;
 constexpr int CI_NPOS = CI_HT * CI_HH * CI_HW;  // 600
-constexpr int CI_LS = 20;
+constexpr int CI_KC = 8;                       // channels per chunk (small chunk -> 35 KB LDS -> 4 workgroups per CU)
+constexpr int CI_LS = CI_KC + 4;               // floats per staged row (+4 pad)
+constexpr int CI_Q = CI_KC / 4;                // float4 pieces per row
+constexpr int CI_WCH = 27 * CI_KC * 4;         // weight floats per chunk: [tap][c][3(+1)]
 
 // One thread = TWO output positions (w and w+4 of the same brick row): every weight float4 fetched from LDS (a broadcast
 // read, all lanes the same address) feeds two FMA triplets, which keeps the LDS pipe below the VALU time.
@@ -22,7 +25,7 @@ __global__ __launch_bounds__(128) void conv_img_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int T,
                                                        int H, int W, int C, int nchunk) {
     __shared__ __attribute__((aligned(16))) float in_lds[CI_NPOS * CI_LS];
-    __shared__ __attribute__((aligned(16))) float w_lds[27 * 64];
+    __shared__ __attribute__((aligned(16))) float w_lds[CI_WCH];
     __shared__ int gpos[CI_NPOS];
     const int tid = threadIdx.x;
     int brick = blockIdx.x;
@@ -45,33 +48,34 @@ __global__ __launch_bounds__(128) void conv_img_kernel(const float* __restrict__
     __syncthreads();
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();
-        const int c0 = ch * 16;
+        const int c0 = ch * CI_KC;
         {   // all of a thread's pieces are requested back to back (branch-free, clamped): one exposed latency per chunk
-            constexpr int NS = (CI_NPOS * 4 + 127) / 128;
+            constexpr int NS = (CI_NPOS * CI_Q + 127) / 128;
             float4 v[NS];
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const int idx = tid + u * 128;
-                const int q = idx & 3, gp = gpos[idx < CI_NPOS * 4 ? (idx >> 2) : 0];
-                const bool ok = idx < CI_NPOS * 4 && gp >= 0 && c0 + 4 * q < C;
+                const int q = idx % CI_Q, gp = gpos[idx < CI_NPOS * CI_Q ? (idx / CI_Q) : 0];
+                const bool ok = idx < CI_NPOS * CI_Q && gp >= 0 && c0 + 4 * q < C;
                 const float4 t4 = *reinterpret_cast<const float4*>(in + (ok ? (long)gp * C + c0 + 4 * q : 0));
                 v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            float4 wv[4];
+            constexpr int NW4 = CI_WCH / 4, NWS = (NW4 + 127) / 128;
+            float4 wv[NWS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = tid + u * 128;  // 27*64/4 = 432 float4
-                wv[u] = *reinterpret_cast<const float4*>(wp + (long)ch * 27 * 64 + (f < 432 ? f : 0) * 4);
+            for (int u = 0; u < NWS; ++u) {
+                const int f = tid + u * 128;
+                wv[u] = *reinterpret_cast<const float4*>(wp + (long)ch * CI_WCH + (f < NW4 ? f : 0) * 4);
             }
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const int idx = tid + u * 128;
-                if (idx < CI_NPOS * 4) *reinterpret_cast<float4*>(in_lds + (idx >> 2) * CI_LS + 4 * (idx & 3)) = v[u];
+                if (idx < CI_NPOS * CI_Q) *reinterpret_cast<float4*>(in_lds + (idx / CI_Q) * CI_LS + 4 * (idx % CI_Q)) = v[u];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NWS; ++u) {
                 const int f = tid + u * 128;
-                if (f < 432) *reinterpret_cast<float4*>(w_lds + f * 4) = wv[u];
+                if (f < NW4) *reinterpret_cast<float4*>(w_lds + f * 4) = wv[u];
             }
         }
         __syncthreads();
@@ -82,9 +86,9 @@ __global__ __launch_bounds__(128) void conv_img_kernel(const float* __restrict__
 #pragma unroll
                 for (int dw = 0; dw < 3; ++dw) {
                     const float* row = my + ((dt * CI_HH + dh) * CI_HW + dw) * CI_LS;
-                    const float* wt = w_lds + ((dt * 3 + dh) * 3 + dw) * 64;  // [16 c][4]
+                    const float* wt = w_lds + ((dt * 3 + dh) * 3 + dw) * (CI_KC * 4);  // [c][4]
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < CI_Q; ++q) {
                         const float4 xa = *reinterpret_cast<const float4*>(row + 4 * q);
                         const float4 xb = *reinterpret_cast<const float4*>(row + 4 * CI_LS + 4 * q);
                         const float pa[4] = {xa.x, xa.y, xa.z, xa.w}, pb[4] = {xb.x, xb.y, xb.z, xb.w};
@@ -107,12 +111,12 @@ __global__ __launch_bounds__(128) void conv_img_kernel(const float* __restrict__
 
 int ConvImgWeights::pack(const float* w_src, const float* bias_src, int cin) {
     Cin = cin;
-    nchunk = (cin + 15) / 16;
-    std::vector<float> p((size_t)nchunk * 27 * 64, 0.f);
+    nchunk = (cin + CI_KC - 1) / CI_KC;
+    std::vector<float> p((size_t)nchunk * CI_WCH, 0.f);
     for (int o = 0; o < 3; ++o)
         for (int c = 0; c < cin; ++c)
             for (int tap = 0; tap < 27; ++tap)
-                p[(((size_t)(c / 16) * 27 + tap) * 16 + c % 16) * 4 + o] = w_src[((size_t)o * cin + c) * 27 + tap];
+                p[(((size_t)(c / CI_KC) * 27 + tap) * CI_KC + c % CI_KC) * 4 + o] = w_src[((size_t)o * cin + c) * 27 + tap];
     int rc = w.upload(p.data(), p.size() * 4);
     if (rc) return rc;
     return bias.upload(bias_src, 12);

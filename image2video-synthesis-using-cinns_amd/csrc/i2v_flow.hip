@@ -36,7 +36,7 @@ struct TailArgs {
     const float* b3;   // [64]
     float* x;          // [B][64] state, updated in place
     float* logdet;     // [B] or null
-    int H, B;
+    int H, B, Bp;  // Bp: row stride of h
     int reverse;
     // elementwise ops applied after the coupling, before the next half-step's first layer
     const int* shuf;       // [64] gather indices or null
@@ -68,12 +68,12 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void flow_tail_kernel(TailArgs a) 
         const int net = lane >> 5;
         constexpr int KCMAX = LIN_MAXK / TAIL_WAVES;
         const int kc = a.H / TAIL_WAVES;
-        const float* hp = a.h + ((long)net * a.H + (long)w * kc) * a.B + b;
+        const float* hp = a.h + ((long)net * a.H + (long)w * kc) * a.Bp + b;
         const float* wp = a.W3T + (long)w * kc * 64 + lane;
         float hv[KCMAX], wv[KCMAX];
 #pragma unroll
         for (int k = 0; k < KCMAX; ++k) {
-            hv[k] = k < kc ? hp[(long)k * a.B] : 0.f;
+            hv[k] = k < kc ? hp[(long)k * a.Bp] : 0.f;
             wv[k] = k < kc ? wp[k * 64] : 0.f;
         }
         float acc = 0.f;
@@ -130,7 +130,6 @@ struct i2v_flow {
     i2v_flow_cfg cfg;
     int device = 0;
     bool loaded = false;
-    int nt = 4;     // rows per workgroup of the hidden-layer launches (env I2V_FLOW_NT = 4 | 8)
     int S = 0;      // half-steps = 2 * n_flows
     int H = 0, E = 0, ld0 = 0, depth = 0;
     DevBuf W0, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;
@@ -163,8 +162,9 @@ WsLayout ws_layout(const i2v_flow* f, int B) {
     L.embed = take((size_t)B * f->E * 4);
     L.logdet = take((size_t)B * 4);
     L.pre = take((size_t)f->S * 2 * f->H * B * 4);
-    L.hA = take((size_t)2 * f->H * B * 4);
-    L.hB = take((size_t)2 * f->H * B * 4);
+    const size_t Bp = (size_t)(B + 63) / 64 * 64;  // hidden activations are [2H][Bp]
+    L.hA = take((size_t)2 * f->H * Bp * 4);
+    L.hB = take((size_t)2 * f->H * Bp * 4);
     L.total = o;
     return L;
 }
@@ -179,6 +179,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
     float* hA = reinterpret_cast<float*>(ws + L.hA);
     float* hB = reinterpret_cast<float*>(ws + L.hB);
     const int H = f->H, N2 = 2 * f->H, S = f->S;
+    const int Bp = (B + 63) / 64 * 64;
     const bool act = f->cfg.activation != 0, an = !f->cfg.skip_actnorm, sh = !f->cfg.skip_shuffle;
 
     if (!reverse) I2V_HIP_CHECK(hipMemsetAsync(logdet, 0, (size_t)B * 4, st));
@@ -212,6 +213,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         t.logdet = reverse ? nullptr : logdet;
         t.H = H;
         t.B = B;
+        t.Bp = Bp;
         t.reverse = reverse ? 1 : 0;
         t.shuf = shuf_block >= 0 ? (reverse ? f->shuf_b.as<int>() : f->shuf_f.as<int>()) + shuf_block * 64 : nullptr;
         t.an_loc = an_block >= 0 ? f->an_loc.as<float>() + an_block * 64 : nullptr;
@@ -248,7 +250,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         a.bias_vec = nullptr;
         a.bias_mat = pre + (size_t)step * N2 * B;
         a.out = hA;
-        a.out_sn = B;
+        a.out_sn = Bp;
         a.out_sb = 1;
         a.N = N2;
         a.B = B;
@@ -257,24 +259,19 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         float* cur = hA;
         float* nxt = hB;
         for (int d = 0; d < f->depth; ++d) {
-            LinArgs m{};
+            HidArgs m{};
             m.W = f->Wmid.as<float>() + ((size_t)step * f->depth + d) * N2 * H;
             m.ldw = H;
             m.K = H;
             m.in = cur;
-            m.in_sk = B;
-            m.in_sb = 1;
-            m.in_group_stride = (long)H * B;
+            m.in_group_stride = (long)H * Bp;
             m.group_rows = H;
-            m.bias_vec = f->bmid.as<float>() + ((size_t)step * f->depth + d) * N2;
-            m.bias_mat = nullptr;
+            m.bias = f->bmid.as<float>() + ((size_t)step * f->depth + d) * N2;
             m.out = nxt;
-            m.out_sn = B;
-            m.out_sb = 1;
             m.N = N2;
-            m.B = B;
+            m.Bp = Bp;
             m.slope = 0.01f;
-            if ((rc = (f->nt == 8 ? launch_linear<8, 8>(m, st) : launch_linear<4, 8>(m, st)))) return rc;
+            if ((rc = launch_hidden(m, st))) return rc;
             std::swap(cur, nxt);
         }
         // last layer + coupling + the ops up to the next half-step's first layer
@@ -368,7 +365,6 @@ int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out) {
     f->E = cfg->embedding_dim;
     f->ld0 = 32 + cfg->embedding_dim;
     f->depth = cfg->hidden_depth;
-    if (const char* e = getenv("I2V_FLOW_NT")) f->nt = atoi(e) == 8 ? 8 : 4;
     *out = f.release();
     return I2V_OK;
 }

@@ -122,6 +122,115 @@ __global__ __launch_bounds__(64 * KW) void flow_linear_kernel(LinArgs a) {
     }
 }
 
+// Hidden layers of the chain (in and out both [rows][Bp] with Bp = batch rounded up to 64): the cost of such a launch
+// is set by the NUMBER of memory requests, not by bytes (tools/flow_bench.hip: 13.5 us at 64 dword loads per lane,
+// independent of the batch).  So every lane loads float4 = 4 consecutive samples of a row, 16 lanes cover a 64-sample
+// row, one wave instruction fetches 4 rows: 16 requests per wave instead of 64.  Lane = (kr = lane >> 4, bq = lane & 15);
+// the four kr groups of a wave are reduced with two wavefront shuffles, the KW waves through LDS.
+struct HidArgs {
+    const float* W;   // rows [N][ldw], row-group g = n / group_rows reads input group g
+    int ldw, K;
+    const float* in;  // [groups][K][Bp]
+    long in_group_stride;
+    int group_rows;
+    const float* bias;  // [N]
+    float* out;         // [N][Bp]
+    int N, Bp;
+    float slope;
+};
+
+template <int KW>
+__global__ __launch_bounds__(64 * KW) void flow_hidden_kernel(HidArgs a) {
+    constexpr int NT = 4;
+    __shared__ __attribute__((aligned(16))) float wtT[LIN_MAXK][NT];  // transposed tile: one ds_read_b128 = 4 rows' weights
+    __shared__ __attribute__((aligned(16))) float4 red[KW][NT][16];
+    constexpr int NTHR = 64 * KW;
+    constexpr int WPT = (NT * LIN_MAXK + NTHR - 1) / NTHR;
+    constexpr int NI = LIN_MAXK / (4 * KW);  // float4 row loads per lane
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kr = lane >> 4, bq = lane & 15;
+    const int n0 = blockIdx.x * NT;
+    const int b0 = blockIdx.y * 64;
+    const int g = n0 / a.group_rows;
+    const int K = a.K;
+    const float* Wr = a.W + (long)n0 * a.ldw;
+    float wreg[WPT];
+    const int nw = NT * K;
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int i = tid + u * NTHR;
+        const int ic = i < nw ? i : 0;
+        const int j = ic / K, k = ic - j * K;
+        wreg[u] = (n0 + j < a.N) ? Wr[(long)j * a.ldw + k] : 0.f;
+    }
+    const int kc = K / KW;  // multiple of 4 (K is a multiple of 64)
+    const int k0 = w * kc;
+    const int ni = kc >> 2;
+    const float* inp = a.in + (long)g * a.in_group_stride + (long)(k0 + kr) * a.Bp + b0 + 4 * bq;
+    float4 v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = i < ni ? *reinterpret_cast<const float4*>(inp + (long)(4 * i) * a.Bp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float bias = 0.f;
+    if (tid < NT * 16 && n0 + (tid >> 4) < a.N) bias = a.bias[n0 + (tid >> 4)];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int i = tid + u * NTHR;
+        if (i < nw) { const int j = i / K; wtT[i - j * K][j] = wreg[u]; }
+    }
+    __syncthreads();
+    float4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (i < ni) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&wtT[k0 + 4 * i + kr][0]);
+            const float wj[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j].x = fmaf(wj[j], v[i].x, acc[j].x);
+                acc[j].y = fmaf(wj[j], v[i].y, acc[j].y);
+                acc[j].z = fmaf(wj[j], v[i].z, acc[j].z);
+                acc[j].w = fmaf(wj[j], v[i].w, acc[j].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            acc[j].x += __shfl_xor(acc[j].x, off);
+            acc[j].y += __shfl_xor(acc[j].y, off);
+            acc[j].z += __shfl_xor(acc[j].z, off);
+            acc[j].w += __shfl_xor(acc[j].w, off);
+        }
+        if (kr == 0) red[w][j][bq] = acc[j];
+    }
+    __syncthreads();
+    if (tid < NT * 16) {
+        const int j = tid >> 4, q = tid & 15;
+        float4 s = make_float4(bias, bias, bias, bias);
+#pragma unroll
+        for (int x = 0; x < KW; ++x) {
+            const float4 r = red[x][j][q];
+            s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+        }
+        s.x = s.x >= 0.f ? s.x : s.x * a.slope; s.y = s.y >= 0.f ? s.y : s.y * a.slope;
+        s.z = s.z >= 0.f ? s.z : s.z * a.slope; s.w = s.w >= 0.f ? s.w : s.w * a.slope;
+        if (n0 + j < a.N) *reinterpret_cast<float4*>(a.out + (long)(n0 + j) * a.Bp + b0 + 4 * q) = s;
+    }
+}
+
+inline int launch_hidden(const HidArgs& a, hipStream_t st) {
+    I2V_REQUIRE(a.K <= LIN_MAXK && a.K % 64 == 0 && a.Bp % 64 == 0 && a.N % 4 == 0, I2V_E_INVALID,
+                "hidden layer: K = %d / Bp = %d / N = %d unsupported", a.K, a.Bp, a.N);
+    hipLaunchKernelGGL((flow_hidden_kernel<8>), dim3(a.N / 4, a.Bp / 64), dim3(512), 0, st, a);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
 template <int NT, int KW>
 inline int launch_linear(const LinArgs& a, hipStream_t st) {
     I2V_REQUIRE(a.K <= LIN_MAXK && a.K <= KW * LIN_KPW, I2V_E_INVALID, "linear: K = %d exceeds %d", a.K, KW * LIN_KPW < LIN_MAXK ? KW * LIN_KPW : LIN_MAXK);
