@@ -54,10 +54,16 @@ struct Conv16Weights {
     int Cin = 0, Cout = 0, CoutPad = 0, nchunk = 0;
     int KT = 1, KH = 1, KW = 1;
     int wexp = 0;  // weights are stored multiplied by 2^wexp (undone in the epilogue)
+    bool tdup = false;   // packed by pack_tdup: two parity sets of a 2x3x3 kernel
+    long set_bytes = 0;  // bytes of one parity set
     int pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, int kh, int kw, double scale);
+    // 3x3x3 conv whose input is a x2 nearest up-sampling IN TIME of a half-rate tensor (frames 2i and 2i+1 identical):
+    // packs the equivalent pair of 2-tap temporal kernels; conv16_forward then reads the half-rate tensor directly.
+    int pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale);
 };
 
 // in_hl16: channels-last activations in the hl16 format (4 bytes per element, Cin % 8 == 0); out: fp32 channels-last.
+// T,H,W = OUTPUT geometry (for pack_tdup weights the input tensor has T/2 frames).
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
                    int H, int W, int epi, hipStream_t st, int ablate = 0, double* stats = nullptr);
 // true when conv16_forward can accumulate per-(sample, channel) sum / sum-of-squares of its output in the epilogue

@@ -43,7 +43,9 @@ struct Conv16Args {
     const float* res;
     float* out;       // fp32 channels-last [B][T][H][W][Cout]
     double* stats;    // optional [B][Cout][2]: per-(sample, channel) sum / sum of squares of the stored values (TB == 1)
-    int B, T, H, W, Cin, Cout, CoutPad, nchunk;
+    int B, T, H, W, Cin, Cout, CoutPad, nchunk;  // T,H,W: geometry of the INPUT tensor
+    int tdup;            // 1: temporal-duplication mode -- the output has 2T frames, grid.y = output frame parity
+    long wset_stride;    // bytes between the two parity weight sets (tdup)
     int KT, KH, KW, tap_base, ztap;  // ztap: index of the all-zero weight slab (stage padding)
     int TB, TT, TH, TW, nbB, nbT, nbH, nbW;
     int HWp;   // halo row pitch in positions (>= TW + KW - 1; 12 for 8-wide bricks: conflict-free 4x4 patches)
@@ -85,7 +87,11 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int kg = lane >> 5, l31 = lane & 31;
 
-    const int pt = a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
+    // Temporal-duplication mode (conv_0 behind a x2 nearest up-sampling in time): the virtual input satisfies
+    // a[2i] == a[2i+1], so even output frames see (a[i-1], a[i], a[i]) and odd ones (a[i], a[i], a[i+1]): a 2-tap
+    // temporal kernel on the HALF-rate tensor with pre-summed weights (W0, W1+W2) resp. (W0+W1, W2).
+    const int par = a.tdup ? (int)blockIdx.y : 0;
+    const int pt = a.tdup ? 1 - par : a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
     const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.HWp;
     const int NPOS = a.TB * HT * HH * HW;
     const int ntaps = a.KT * a.KH * a.KW;
@@ -113,8 +119,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
         const int it = m % a.TT; m /= a.TT;
         const int b = b0 + m, t = t0 + it, h = h0 + ih, w = w0 + iw;
         const bool ok = b < a.B;
-        rowpos[tid] = ok ? ((b * a.T + t) * a.H + h) * a.W + w : -1;
-        rowres[tid] = ok ? ((b * (a.T / a.rt) + t / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs) + w / a.rs : 0;
+        const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + par : t;  // output frame
+        rowpos[tid] = ok ? ((b * To + to) * a.H + h) * a.W + w : -1;
+        rowres[tid] = ok ? ((b * (To / a.rt) + to / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs) + w / a.rs : 0;
     }
     if (tid == 0) {
         int cnt = 0;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
             *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;
         }
         // weights: stage 0 straight to LDS, stage 1 into registers (branch-free, always in registers)
-        const char* wbase = a.wp + (long)ch * slab + (long)n0 * 128;
+        const char* wbase = a.wp + (long)par * a.wset_stride + (long)ch * slab + (long)n0 * 128;
         float4 wreg[WLD];
 #pragma unroll
         for (int u = 0; u < WLD; ++u) wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -382,6 +389,51 @@ int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int
     return I2V_OK;
 }
 
+int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale) {
+    // two 2x3x3 kernels from one 3x3x3 kernel: parity 0 = (W[0], W[1]+W[2]), parity 1 = (W[0]+W[1], W[2]) along time
+    std::vector<float> w2((size_t)2 * cout * cin * 18);
+    for (int par = 0; par < 2; ++par)
+        for (size_t nc = 0; nc < (size_t)cout * cin; ++nc)
+            for (int hw = 0; hw < 9; ++hw) {
+                const double w0 = w_src[nc * 27 + hw], w1 = w_src[nc * 27 + 9 + hw], w2v = w_src[nc * 27 + 18 + hw];
+                float* dst = &w2[((size_t)par * cout * cin + nc) * 18];
+                dst[hw] = (float)(par == 0 ? w0 : w0 + w1);
+                dst[9 + hw] = (float)(par == 0 ? w1 + w2v : w2v);
+            }
+    // both sets share one power-of-two pre-scale: pack them as one [2*cout] tensor, then split the buffer
+    Conv16Weights tmp;
+    Cin = cin; Cout = cout; KT = 2; KH = 3; KW = 3; tdup = true;
+    CoutPad = (cout + 31) / 32 * 32;
+    if (CoutPad > 64 && CoutPad % 128) CoutPad = (CoutPad + 127) / 128 * 128;
+    nchunk = (cin + C16_KC - 1) / C16_KC;
+    const int ntaps = 18;
+    double wmax = 0.0;
+    for (float v : w2) wmax = std::max(wmax, std::fabs((double)v * scale));
+    wexp = 0;
+    if (wmax > 0.0 && std::isfinite(wmax)) wexp = std::max(-40, std::min(40, (int)std::floor(std::log2(16384.0 / wmax))));
+    const double pre = std::ldexp(1.0, wexp);
+    const size_t set_halfs = (size_t)(ntaps + 1) * nchunk * CoutPad * 64;
+    std::vector<_Float16> p(2 * set_halfs, (_Float16)0.f);
+    for (int par = 0; par < 2; ++par)
+        for (int n = 0; n < cout; ++n)
+            for (int c = 0; c < cin; ++c)
+                for (int tap = 0; tap < ntaps; ++tap) {
+                    const float v = (float)((double)w2[(((size_t)par * cout + n) * cin + c) * 18 + tap] * scale * pre);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const int chunk = c / C16_KC, g = (c % C16_KC) / 8, j = c % 8;
+                    _Float16* row = &p[par * set_halfs + (((size_t)tap * nchunk + chunk) * CoutPad + n) * 64];
+                    row[g * 16 + j] = hi;
+                    row[g * 16 + 8 + j] = lo;
+                }
+    set_bytes = (long)set_halfs * 2;
+    int rc = w.upload(p.data(), p.size() * 2);
+    if (rc) return rc;
+    if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
+    bias.release();
+    return I2V_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
 static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
     auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS>;
@@ -391,7 +443,7 @@ static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t 
                                           160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(nblk, a.tdup ? 2 : 1), dim3(512), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -410,6 +462,13 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     a.B = B; a.T = T; a.H = H; a.W = W; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
     a.KT = wts.KT; a.KH = wts.KH; a.KW = wts.KW; a.tap_base = 0;
     a.ztap = wts.KT * wts.KH * wts.KW;
+    a.tdup = wts.tdup ? 1 : 0;
+    a.wset_stride = wts.set_bytes;
+    if (wts.tdup) {  // T is the OUTPUT frame count; the (half-rate) input has T / 2 frames
+        I2V_REQUIRE(T % 2 == 0 && !res, I2V_E_INVALID, "conv16: temporal-duplication mode needs an even frame count and no residual");
+        T /= 2;
+        a.T = T;
+    }
     if (T == 1 && wts.KT == 3) {  // a single frame only ever meets the centre time-slice of the kernel (rest is padding)
         a.KT = 1;
         a.tap_base = wts.KH * wts.KW;

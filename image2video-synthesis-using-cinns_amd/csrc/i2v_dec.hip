@@ -385,9 +385,12 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     }
     if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
     const bool f16 = d->cfg.mma == 1;
-    if ((rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16))) return rc;
-    if ((rc = tap(k, 1, a, (size_t)B * P * b.n_in))) return rc;
-    const bool fuse = f16 && conv16_can_fuse_stats(l.T, l.H, l.W);
+    const bool tdup = f16 && b.conv0_16.tdup;  // a0 is kept at the half temporal rate (its frames 2i and 2i+1 coincide)
+    if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true);
+    else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16);
+    if (rc) return rc;
+    if ((rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
+    const bool fuse = f16 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
     if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
     if (rc) return rc;
@@ -411,7 +414,7 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // g_4's output only feeds conv_img(leaky_relu(x)) (decoder.py:117): fuse the activation here
     // (the shortcut's coefficients were derived from sums1 above, so conv_1 may now overwrite sums1 with the
     // statistics of the block OUTPUT = the next block's input)
-    const bool fuse_out = fuse && !last;
+    const bool fuse_out = f16 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
     if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
     else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
     if (rc) return rc;
@@ -420,23 +423,18 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     return I2V_OK;
 }
 
-template <class WT>
-int sn_pack(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, int k, bool has_bias,
-            WT& out) {
-    const int64_t numel = (int64_t)cout * cin * k * k * k;
-    const float* bias = nullptr;
-    if (has_bias) { bias = sd.f32(name + ".bias", cout); if (!bias) return I2V_E_MISSING; }
+// sigma = u . (W_mat v), W_mat = weight_orig.reshape(Cout, -1); signed, no abs (torch spectral_norm, eval mode)
+int sn_scale(const StateDict& sd, const std::string& name, bool spectral, int cout, int64_t kk, const float** w_out,
+             double* scale_out) {
     if (!spectral) {
-        const float* w = sd.f32(name + ".weight", numel);
-        if (!w) return I2V_E_MISSING;
-        return out.pack(w, bias, cout, cin, k, k, k, 1.0);
+        *w_out = sd.f32(name + ".weight", (int64_t)cout * kk);
+        *scale_out = 1.0;
+        return *w_out ? I2V_OK : I2V_E_MISSING;
     }
-    const int64_t kk = (int64_t)cin * k * k * k;
-    const float* w = sd.f32(name + ".weight_orig", numel);
+    const float* w = sd.f32(name + ".weight_orig", (int64_t)cout * kk);
     const float* u = sd.f32(name + ".weight_u", cout);
     const float* v = sd.f32(name + ".weight_v", kk);
     if (!w || !u || !v) return I2V_E_MISSING;
-    // sigma = u . (W_mat v), W_mat = weight_orig.reshape(Cout, -1); signed, no abs (torch spectral_norm, eval mode)
     double sigma = 0.0;
     for (int n = 0; n < cout; ++n) {
         double r = 0.0;
@@ -445,7 +443,32 @@ int sn_pack(const StateDict& sd, const std::string& name, bool spectral, int cou
         sigma += r * u[n];
     }
     I2V_REQUIRE(sigma != 0.0 && std::isfinite(sigma), I2V_E_INVALID, "spectral norm sigma of %s is %g", name.c_str(), sigma);
-    return out.pack(w, bias, cout, cin, k, k, k, 1.0 / sigma);
+    *w_out = w;
+    *scale_out = 1.0 / sigma;
+    return I2V_OK;
+}
+
+template <class WT>
+int sn_pack(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, int k, bool has_bias,
+            WT& out) {
+    const float* bias = nullptr;
+    if (has_bias) { bias = sd.f32(name + ".bias", cout); if (!bias) return I2V_E_MISSING; }
+    const float* w = nullptr;
+    double scale = 1.0;
+    int rc = sn_scale(sd, name, spectral, cout, (int64_t)cin * k * k * k, &w, &scale);
+    if (rc) return rc;
+    return out.pack(w, bias, cout, cin, k, k, k, scale);
+}
+
+// conv_0 of a block that sits behind a x2 temporal up-sampling: packed for the half-rate input (Conv16Weights::pack_tdup)
+int sn_pack_tdup(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, Conv16Weights& out) {
+    const float* bias = sd.f32(name + ".bias", cout);
+    if (!bias) return I2V_E_MISSING;
+    const float* w = nullptr;
+    double scale = 1.0;
+    int rc = sn_scale(sd, name, spectral, cout, (int64_t)cin * 27, &w, &scale);
+    if (rc) return rc;
+    return out.pack_tdup(w, bias, cout, cin, scale);
 }
 
 }  // namespace
@@ -521,7 +544,11 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         Block& b = d->blk[k];
         const std::string p = b.name + ".";
         if (d->cfg.mma == 1) {
-            if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0_16))) return rc;
+            // behind a x2 up-sampling in time, SPADE's output is identical for frames 2i and 2i+1 (gamma/beta do not depend
+            // on t): conv_0 runs on the half-rate tensor with two pre-summed 2-tap temporal kernels (-1/3 of its MACs)
+            if (d->lvl[k].ut == 2) rc = sn_pack_tdup(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.conv0_16);
+            else rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0_16);
+            if (rc) return rc;
             if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1_16))) return rc;
         } else {
             if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
