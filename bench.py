@@ -178,16 +178,17 @@ def roofline(prof, dt, mma, default_workload=False):
     """Dominant kernel = the 3x3x3 Conv3d implicit GEMM.  achieved = ALGORITHMIC FLOPs (2*M*N*K per launch, summed) /
     summed launch duration (HIP events on the launch stream, inside the timed region).  In split-fp16 mode every
     algorithmic FLOP costs three fp16 MFMA FLOPs, so the fraction of the dense fp16 peak that the matrix cores are
-    actually issuing is 3x `frac` (reported as mfma_issue_frac)."""
+    actually issuing is reported separately as mfma_issue_frac (3 MFMA FLOPs per executed product; conv_0 behind a x2
+    temporal up-sampling executes 18 of the 27 algorithmic taps)."""
     if prof["conv3_ms"] <= 0:
         return None
     ach = prof["conv3_flops"] / (prof["conv3_ms"] * 1e-3) / 1e12
     if mma == 1:
         kernel = "conv_mfma_f16x3_kernel (3x3x3 Conv3d implicit GEMM, split-fp16: 3x v_mfma_f32_32x32x16_f16 per product)"
-        peak, issue = PEAK_F16_MFMA_TFLOPS, 3.0
+        peak = PEAK_F16_MFMA_TFLOPS
     else:
         kernel = "conv_mfma_f32_kernel (3x3x3 Conv3d implicit GEMM, v_mfma_f32_32x32x2_f32)"
-        peak, issue = PEAK_FP32_MFMA_TFLOPS, 1.0
+        peak = PEAK_FP32_MFMA_TFLOPS
     # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
     # rocprofv3 --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/r01_c_pmc_hbm_traffic.json).
     # bench.py cannot read PMCs itself: the figure is valid for the default workload (bair64, batch 64, mma = 1) only.
@@ -199,7 +200,8 @@ def roofline(prof, dt, mma, default_workload=False):
         except (OSError, KeyError, ValueError):
             traffic = None
     return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-            "traffic": traffic, "mfma_issue_frac": issue * ach / peak, "launches": prof["conv3_launches"],
+            "traffic": traffic, "mfma_issue_frac": prof["conv3_mfma_flops"] / (prof["conv3_ms"] * 1e-3) / 1e12 / peak,
+            "launches": prof["conv3_launches"],
             "avg_launch_ms": prof["conv3_ms"] / max(prof["conv3_launches"], 1), "time_share": prof["conv3_ms"] * 1e-3 / dt}
 
 
@@ -211,13 +213,15 @@ def cpu_baseline(cfg, fsd, dsd):
     # one thread per physical core of one socket is what torch-CPU conv3d scales to; 256 SMT threads ran 4x slower
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
-    nb = 2
+    nb = 8  # 2 timed calls of batch 8 = ~10 s of CPU work on a 64-core EPYC
     x0, residual, embed = synth.bench_inputs(nb, cfg["img"], cfg["emb"])
     folded = decoder_ref.fold_spectral_norm(dsd)
     model_ref.synthesize(fsd, folded, x0[:1], residual[:1], embed[:1], 16, cfg["ups"], cfg["upt"], faithful=False)  # warm-up
     t0 = time.perf_counter()
-    seq = model_ref.synthesize(fsd, folded, x0, residual, embed, 16, cfg["ups"], cfg["upt"], faithful=False)
-    dt = time.perf_counter() - t0
+    ncall = 2
+    for _ in range(ncall):
+        seq = model_ref.synthesize(fsd, folded, x0, residual, embed, 16, cfg["ups"], cfg["upt"], faithful=False)
+    dt = (time.perf_counter() - t0) / ncall
     cpu = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -225,7 +229,7 @@ def cpu_baseline(cfg, fsd, dsd):
     except OSError:
         pass
     return {"value": seq.shape[0] * seq.shape[1] / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 warm call (after a batch-1 warm-up), batch {nb} x 16 frames, same geometry and weights (oracle/model_ref.synthesize, folded)",
+            "sample": f"mean of 2 warm calls (after a batch-1 warm-up), batch {nb} x 16 frames, same geometry and weights (oracle/model_ref.synthesize, folded)",
             "cpu": cpu, "seconds": dt}
 
 

@@ -231,9 +231,9 @@ struct i2v_dec {
     ConvImgWeights conv_img_v;  // vector-ALU variant (used when the output geometry tiles into 4x8x8 bricks)
     int Nz = 0;
     int profile = 0;
-    struct ProfEv { hipEvent_t e0, e1; double flops; };
+    struct ProfEv { hipEvent_t e0, e1; double flops, exec_flops; };
     std::vector<ProfEv> prof_events;
-    double prof_conv3_ms = 0, prof_conv3_flops = 0;
+    double prof_conv3_ms = 0, prof_conv3_flops = 0, prof_conv3_exec = 0;
     long prof_conv3_launches = 0;
     // debug tap: copy one intermediate (channels-last) of one block out of the workspace during forward
     int tap_block = -1, tap_which = -1;
@@ -319,8 +319,8 @@ struct ProfScope {
     i2v_dec* d;
     hipStream_t st;
     hipEvent_t e0 = nullptr;
-    double flops;
-    ProfScope(i2v_dec* d_, hipStream_t st_, double flops_) : d(d_), st(st_), flops(flops_) {
+    double flops, exec_flops;
+    ProfScope(i2v_dec* d_, hipStream_t st_, double flops_, double exec_) : d(d_), st(st_), flops(flops_), exec_flops(exec_) {
         if (d->profile) { (void)hipEventCreate(&e0); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
@@ -328,21 +328,25 @@ struct ProfScope {
             hipEvent_t e1 = nullptr;
             (void)hipEventCreate(&e1);
             (void)hipEventRecord(e1, st);
-            d->prof_events.push_back({e0, e1, flops});
+            d->prof_events.push_back({e0, e1, flops, exec_flops});
         }
     }
 };
 
 int conv3(i2v_dec* d, const ConvWeights& w, const float* in, float* out, const float* res, int rt, int rs, int B,
           const Level& l, int epi, hipStream_t st) {
-    ProfScope ps(d, st, 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0);
+    const double fl = 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0;
+    ProfScope ps(d, st, fl, fl);
     return conv_forward(w, in, w.Cin, out, res, rt, rs, B, l.T, l.H, l.W, epi, st);
 }
 
 int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* out, const float* res, int rt, int rs, int B,
              const Level& l, int epi, hipStream_t st, double* stats = nullptr) {
     if (stats) I2V_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * w.Cout * 16, st));
-    ProfScope ps(d, st, 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0);
+    // algorithmic FLOPs of the reference's 3x3x3 conv; matrix-core FLOPs actually issued = 3 fp16 MFMAs per product, on
+    // 18 instead of 27 taps in temporal-duplication mode
+    const double fl = 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0;
+    ProfScope ps(d, st, fl, 3.0 * fl * (w.tdup ? 18.0 / 27.0 : 1.0));
     return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, 0, stats);
 }
 
@@ -629,7 +633,7 @@ double i2v_dec_flops_per_sample(const i2v_dec* d, int32_t img_h, int32_t img_w) 
 int i2v_dec_set_profile(i2v_dec* d, int32_t on) {
     I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_set_profile: null");
     d->profile = on;
-    d->prof_conv3_ms = d->prof_conv3_flops = 0;
+    d->prof_conv3_ms = d->prof_conv3_flops = d->prof_conv3_exec = 0;
     d->prof_conv3_launches = 0;
     return I2V_OK;
 }
@@ -640,7 +644,7 @@ int i2v_dec_debug_tap(i2v_dec* d, int32_t block, int32_t which, float* dst, size
     return I2V_OK;
 }
 
-int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, int64_t* conv3_launches) {
+int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, double* conv3_mfma_flops, int64_t* conv3_launches) {
     I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_get_profile: null");
     for (auto& ev : d->prof_events) {
         I2V_HIP_CHECK(hipEventSynchronize(ev.e1));
@@ -648,6 +652,7 @@ int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, int64
         I2V_HIP_CHECK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
         d->prof_conv3_ms += ms;
         d->prof_conv3_flops += ev.flops;
+        d->prof_conv3_exec += ev.exec_flops;
         d->prof_conv3_launches += 1;
         (void)hipEventDestroy(ev.e0);
         (void)hipEventDestroy(ev.e1);
@@ -655,6 +660,7 @@ int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, int64
     d->prof_events.clear();
     if (conv3_ms) *conv3_ms = d->prof_conv3_ms;
     if (conv3_flops) *conv3_flops = d->prof_conv3_flops;
+    if (conv3_mfma_flops) *conv3_mfma_flops = d->prof_conv3_exec;
     if (conv3_launches) *conv3_launches = d->prof_conv3_launches;
     return I2V_OK;
 }

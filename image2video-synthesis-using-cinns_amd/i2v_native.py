@@ -77,7 +77,7 @@ SYMBOLS = {
     "i2v_dec_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
     "i2v_dec_set_profile": (c_int32, [c_void_p, c_int32]),
     "i2v_dec_debug_tap": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t]),
-    "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
 }
 
 
@@ -244,9 +244,10 @@ class NativeDecoder:
         _check(lib().i2v_dec_set_profile(self._h, int(on)), "i2v_dec_set_profile")
 
     def get_profile(self):
-        a, b, c = c_double(), c_double(), c_int64()
-        _check(lib().i2v_dec_get_profile(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "i2v_dec_get_profile")
-        return {"conv3_ms": a.value, "conv3_flops": b.value, "conv3_launches": c.value}
+        a, b, e, c = c_double(), c_double(), c_double(), c_int64()
+        _check(lib().i2v_dec_get_profile(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(e), ctypes.byref(c)),
+               "i2v_dec_get_profile")
+        return {"conv3_ms": a.value, "conv3_flops": b.value, "conv3_mfma_flops": e.value, "conv3_launches": c.value}
 
     def debug_tap(self, block, which, dst):
         """Test hook (i2v_dec_debug_tap): dst = float32 CUDA tensor or None."""

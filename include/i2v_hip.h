@@ -147,9 +147,10 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
 /* Roofline instrumentation.  With profiling on, every 3x3x3 Conv3d launch (the dominant kernel) is bracketed by HIP
  * events recorded on the launch stream -- no synchronisation is added to the forward.  After the caller has
  * synchronised, i2v_dec_get_profile resolves the pending pairs and returns the totals since set_profile(d, 1):
- * summed kernel time [ms], summed algorithmic FLOPs (2*M*N*K per launch) and the number of launches. */
+ * summed kernel time [ms], summed algorithmic FLOPs (2*M*N*K of the reference's conv per launch), summed matrix-core
+ * FLOPs actually issued (3 per product in split-fp16 mode, 18 of 27 taps in temporal-duplication mode) and launches. */
 int i2v_dec_set_profile(i2v_dec* d, int32_t on);
-int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, int64_t* conv3_launches);
+int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, double* conv3_mfma_flops, int64_t* conv3_launches);
 /* Test hook: during the next forwards copy up to max_floats of one channels-last intermediate of GeneratorBlock
  * `block` (0 = head_0 .. 5 = g_4) into dst (device).  which: 0 = SPADE (1+gamma | beta) [B,H,W,2C], 1 = lrelu(Spade(x)),
  * 2 = conv_0 output, 3 = lrelu(ADAIN(.)), 4 = shortcut (low resolution), 5 = block output.  dst = NULL disables. */
