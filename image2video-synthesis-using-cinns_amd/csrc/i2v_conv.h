@@ -37,6 +37,8 @@ struct ConvArgs {
     int CinAct;         // channel stride of `in` (>= Cin of the weights)
     int Cout, CoutPad, nchunk;
     int KT, KH, KW;
+    int sS;                   // spatial stride (1 or 2; the embedder's ResNet); T, H, W are OUTPUT dims, the input is
+                              // [B][T][H*sS][W*sS][CinAct]
     int TB, TT, TH, TW;       // output brick handled by one workgroup (TB*TT*TH*TW == CONV_BM)
     int nbB, nbT, nbH, nbW;   // bricks per dimension
     int rt, rs;               // nearest-upsample factors applied when reading `res`
@@ -45,7 +47,7 @@ struct ConvArgs {
 
 // Chooses the brick and the tile variant and enqueues the kernel.
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
-                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef = nullptr);
+                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef = nullptr, int stride = 1);
 
 // ---- split-fp16 path (i2v_conv16.hip): operands carried as (fp16 hi, fp16 lo = x - hi) pairs, 3 fp16 MFMAs per product
 struct Conv16Weights {
@@ -68,6 +70,14 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
                    int H, int W, int epi, hipStream_t st, int ablate = 0, double* stats = nullptr);
 // true when conv16_forward can accumulate per-(sample, channel) sum / sum-of-squares of its output in the epilogue
 bool conv16_can_fuse_stats(int T, int H, int W);
+
+// ---- helpers implemented in i2v_dec.hip, shared with the embedder (i2v_embed.hip)
+// per-(b,c) sum / sum of squares (fp64) of a channels-last tensor [B][P][C]
+int stats_forward(const float* x, double* sums, int B, long P, int C, hipStream_t st);
+// (sum, sumsq) -> per-(b,c) (A, B) pairs with norm(x) == x*A + B (biased variance, eps 1e-5)
+int coef_forward(const double* sums, float* coef, int B, int C, int groups, double count, hipStream_t st);
+// bilinear (align_corners=True) NCHW [B,3,Hi,Wi] -> channels-last [B][Ho][Wo][16] (channels 3..15 zero)
+int resize_forward(const float* img, float* out, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t st);
 
 // ---- conv_img (i2v_convimg.hip): Conv3d(nf -> 3) + tanh on the vector ALU, exact fp32
 struct ConvImgWeights {

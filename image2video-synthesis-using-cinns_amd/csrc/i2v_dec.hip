@@ -25,9 +25,12 @@ namespace i2v {
 
 // ------------------------------------------------------------------------------------------------ statistics
 // x [B][P][C] -> sums[b][c] = (sum, sumsq) in fp64.  grid (chunks, B), block 256 = R rows x C4 float4 columns.
+// Channel counts above 1024 are covered by blockIdx.z slices of 1024 channels (Ctot = row stride, C = slice width).
 __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int P, int C,
-                                                    int rows_per_block) {
+                                                    int rows_per_block, int Ctot) {
     __shared__ double red[256][8];
+    x += (long)blockIdx.z * 1024;
+    sums += (long)blockIdx.z * 2048;
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int R = 256 / C4;            // rows handled concurrently (C4 <= 256)
@@ -37,9 +40,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
     const int p1 = min(P, p0 + rows_per_block);
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (r < R) {
-        const float* base = x + (long)b * P * C + 4 * col;
+        const float* base = x + (long)b * P * Ctot + 4 * col;
         for (int p = p0 + r; p < p1; p += R) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (long)p * C);
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)p * Ctot);
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
         }
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s[j] += red[rr * C4 + col][j]; q[j] += red[rr * C4 + col][4 + j]; }
         }
-        double* dst = sums + ((long)b * C + 4 * col) * 2;
+        double* dst = sums + ((long)b * Ctot + 4 * col) * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             atomicAdd(dst + 2 * j, s[j]);
@@ -277,14 +280,15 @@ DecWs dec_ws(const i2v_dec* d, int B) {
 }
 
 int run_stats(const float* x, double* sums, int B, long P, int C, hipStream_t st) {
-    I2V_REQUIRE(C % 4 == 0 && C / 4 <= 256, I2V_E_INVALID, "stats: unsupported channel count %d", C);
+    I2V_REQUIRE(C % 4 == 0 && (C <= 1024 || C % 1024 == 0), I2V_E_INVALID, "stats: unsupported channel count %d", C);
     I2V_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)B * C * 16, st));
-    const int R = 256 / (C / 4);
+    const int Cs = C > 1024 ? 1024 : C, nz = C / Cs;  // channel slices
+    const int R = 256 / (Cs / 4);
     long rows = R * 16;                       // at least 16 rows per thread-row
     const long want = (P + 1023) / 1024;      // at most ~1024 chunks per sample
     if (rows < want) rows = (want + R - 1) / R * R;
     const int chunks = (int)((P + rows - 1) / rows);
-    hipLaunchKernelGGL(stats_kernel, dim3(chunks, B), dim3(256), 0, st, x, sums, (int)P, C, (int)rows);
+    hipLaunchKernelGGL(stats_kernel, dim3(chunks, B, nz), dim3(256), 0, st, x, sums, (int)P, Cs, (int)rows, C);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -349,6 +353,25 @@ int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* ou
     ProfScope ps(d, st, fl, 3.0 * fl * (w.tdup ? 18.0 / 27.0 : 1.0));
     return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, 0, stats);
 }
+
+}  // namespace
+
+namespace i2v {
+// exported to i2v_embed.hip
+int stats_forward(const float* x, double* sums, int B, long P, int C, hipStream_t st) { return run_stats(x, sums, B, P, C, st); }
+int coef_forward(const double* sums, float* coef, int B, int C, int groups, double count, hipStream_t st) {
+    return run_coef(sums, coef, B, C, groups, count, nullptr, 0, 0, nullptr, nullptr, st);
+}
+int resize_forward(const float* img, float* out, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
+    const long tot = (long)B * Ho * Wo;
+    hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, out, B, Hi, Wi,
+                       Ho, Wo);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+}  // namespace i2v
+
+namespace {
 
 struct BlockBufs {
     float *a, *dx, *xs_in, *xs_low, *y0, *y1, *gb, *coef;

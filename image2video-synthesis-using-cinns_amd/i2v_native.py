@@ -68,6 +68,11 @@ SYMBOLS = {
                                      c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "i2v_gblock_norm": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_int32,
                                   c_int32, c_int32, c_int32, c_void_p]),
+    "i2v_embedder_create": (c_int32, [c_int32, c_int32, POINTER(c_void_p)]),
+    "i2v_embedder_destroy": (None, [c_void_p]),
+    "i2v_embedder_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
+    "i2v_embedder_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32, c_int32]),
+    "i2v_embedder_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
     "i2v_dec_create": (c_int32, [POINTER(DecCfg), POINTER(c_void_p)]),
     "i2v_dec_destroy": (None, [c_void_p]),
     "i2v_dec_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
@@ -428,3 +433,35 @@ class NativeNorm:
 
     def forward(self, x, cond):
         return self.blk.norm(self.part, x, cond)
+
+
+class NativeEmbedder:
+    """Handle for ``i2v_embedder_*`` (ResnetEncoder.encode(x).mode(), AE.py:91-166)."""
+
+    def __init__(self, z_dim, use_batchnorm):
+        h = c_void_p()
+        _check(lib().i2v_embedder_create(z_dim, int(bool(use_batchnorm)), ctypes.byref(h)), "i2v_embedder_create")
+        self._h = h
+        self.z_dim = z_dim
+        self._ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.i2v_embedder_destroy(self._h)
+            self._h = None
+
+    def load(self, state_dict):
+        arr, keep = _pack_state_dict(state_dict)
+        _check(lib().i2v_embedder_load(self._h, arr, len(arr)), "i2v_embedder_load")
+        del keep
+
+    def forward(self, img):
+        _require_gpu(img)
+        if img.dim() != 4 or img.shape[1] != 3:
+            raise I2VError(f"embedder: expected img [B,3,H,W], got {tuple(img.shape)}")
+        B, _, H, W = img.shape
+        ws = self._ws.get(lib().i2v_embedder_workspace_bytes(self._h, B, H, W), img.device)
+        out = torch.empty(B, self.z_dim, dtype=torch.float32, device=img.device)
+        _check(lib().i2v_embedder_forward(self._h, img.data_ptr(), H, W, out.data_ptr(), ws.data_ptr(), ws.numel(), B, _stream()),
+               "i2v_embedder_forward")
+        return out

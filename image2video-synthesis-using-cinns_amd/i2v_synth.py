@@ -24,7 +24,7 @@ Requirements the synthesiser meets (found by running the reference)
 """
 import numpy as np
 
-__all__ = ["flow_state_dict", "decoder_state_dict", "bench_inputs"]
+__all__ = ["flow_state_dict", "decoder_state_dict", "embedder_state_dict", "bench_inputs"]
 
 
 def _uniform(rng, shape, bound):
@@ -155,6 +155,45 @@ def decoder_state_dict(seed=7, channel_factor=64, z_dim=64, spectral_norm=True, 
     fan_in = nf * 27
     sd["conv_img.weight"] = _uniform(rng, (3, nf, 3, 3, 3), 1.2 / np.sqrt(fan_in))
     sd["conv_img.bias"] = _uniform(rng, (3,), 0.1)
+    return sd
+
+
+def embedder_state_dict(seed=7, z_dim=64, norm="in"):
+    """state_dict of ``ResnetEncoder`` (stage2_cINN/AE/modules/AE.py:91-124: torchvision-0.8.1 resnet50 with the given
+    norm layer, fc = Conv2d(2048, 2*z_dim, 1)) as {key: np.ndarray}; He-style weights so activations stay O(1)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        sd[name + ".weight"] = _uniform(rng, (cout, cin, k, k), np.sqrt(3.0 / (cin * k * k)))
+
+    def bn(name, c):
+        if norm != "bn":
+            return
+        sd[name + ".weight"] = (1.0 + _uniform(rng, (c,), 0.2)).astype(np.float32)
+        sd[name + ".bias"] = _uniform(rng, (c,), 0.2)
+        sd[name + ".running_mean"] = _uniform(rng, (c,), 0.3)
+        sd[name + ".running_var"] = (1.0 + _uniform(rng, (c,), 0.5)).astype(np.float32)
+        sd[name + ".num_batches_tracked"] = np.array(100, dtype=np.int64)
+
+    conv("model.conv1", 64, 3, 7)
+    bn("model.bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(((64, 3), (128, 4), (256, 6), (512, 3)), start=1):
+        for i in range(blocks):
+            p = f"model.layer{li}.{i}."
+            conv(p + "conv1", planes, inplanes, 1)
+            bn(p + "bn1", planes)
+            conv(p + "conv2", planes, planes, 3)
+            bn(p + "bn2", planes)
+            conv(p + "conv3", planes * 4, planes, 1)
+            bn(p + "bn3", planes * 4)
+            if i == 0:
+                conv(p + "downsample.0", planes * 4, inplanes, 1)
+                bn(p + "downsample.1", planes * 4)
+            inplanes = planes * 4
+    sd["model.fc.sub_layers.0.weight"] = _uniform(rng, (2 * z_dim, 2048, 1, 1), 1.0 / np.sqrt(2048))
+    sd["model.fc.sub_layers.0.bias"] = _uniform(rng, (2 * z_dim,), 0.1)
     return sd
 
 

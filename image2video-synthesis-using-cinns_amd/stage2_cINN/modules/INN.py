@@ -1,13 +1,18 @@
 """Mirror of the reference's ``stage2_cINN/modules/INN.py``: ``SupervisedTransformer`` owns the conditional flow
 and the frozen conditioning embedder and dispatches forward / reverse (reference INN.py:8-73).
 
-The ResNet-50 conditioning embedder (stage2_cINN/AE/modules/AE.py:91-166) sits in FRONT of the hot path and is the
-first "next" row of the coverage contract.  Until it is built, the embedding is supplied by the
-caller (``embed=``) or by a user-provided ``embedder`` object exposing ``encode(x).mode()``."""
+The ResNet-50 conditioning embedder (stage2_cINN/AE/modules/AE.py:91-166, row N1) is built like the reference does
+(INN.py:36-41) from ``dic['model_path'] + dic['model_name'] + '/config_stage2_AE.yaml'`` and ``<checkpoint_name>.pth``
+when those files exist; otherwise the embedding has to be supplied by the caller (``embed=``) or through an injected
+``embedder`` object exposing ``encode(x).mode()``."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 
+import i2v_config
+from stage2_cINN.AE.modules.AE import ResnetEncoder
 from stage2_cINN.modules.flow_blocks import ConditionalFlow
 
 
@@ -26,9 +31,16 @@ class SupervisedTransformer(nn.Module):
         self.flow = ConditionalFlow(in_channels=in_channels, embedding_dim=embedding_channels + self.cond_size * 3,
                                     hidden_dim=mid_channels, hidden_depth=hidden_depth, n_flows=n_flows,
                                     conditioning_option=conditioning_option, control=self.control)
-        # reference INN.py:36-41 builds ResnetEncoder(config.AE) from dic['model_path'] + dic['model_name'];
-        # here an embedder object can be injected instead (row N1)
         self.embedder = kwargs.get("embedder", None)
+        dic = kwargs.get("dic", None)
+        if self.embedder is None and dic is not None and dic.get("model_path") is not None:
+            model_path = dic["model_path"] + dic["model_name"] + "/"                      # INN.py:37
+            cfg, ckpt = model_path + "config_stage2_AE.yaml", model_path + dic["checkpoint_name"] + ".pth"
+            if os.path.exists(cfg) and os.path.exists(ckpt):
+                config = i2v_config.load(cfg)                                              # INN.py:38
+                self.embedder = ResnetEncoder(config.AE)                                   # INN.py:39
+                self.embedder.load_state_dict(torch.load(ckpt, map_location="cpu")["state_dict"])  # INN.py:40
+                _ = self.embedder.eval()
 
     def embed_pos(self, pos):
         """Three one-hots of 10 bins at index floor(pos*10 - 1e-4) (reference INN.py:49-57)."""
@@ -42,8 +54,8 @@ class SupervisedTransformer(nn.Module):
     def _embed(self, input, cond, embed):
         if embed is None:
             if self.embedder is None:
-                raise RuntimeError("SupervisedTransformer: no conditioning embedder is attached (ResNet-50 embedder is "
-                                   "row N1 of the coverage contract); pass embed=[B,E] explicitly")
+                raise RuntimeError("SupervisedTransformer: no conditioning embedder is attached (its config / checkpoint "
+                                   "were not found under Conditioning_Model.model_path); pass embed=[B,E] explicitly")
             with torch.no_grad():
                 embed = self.embedder.encode(cond[0]).mode().reshape(input.size(0), -1).detach()
         if self.control:

@@ -177,6 +177,23 @@ int i2v_gblock_forward(i2v_gblock* g, const float* x, const float* z, const floa
 int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* cond, int32_t img_h, int32_t img_w, float* out,
                     void* workspace, size_t workspace_bytes, int32_t batch, int32_t t, int32_t h, int32_t w, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Conditioning embedder (row N1): ResnetEncoder.encode(x).mode() -- stage2_cINN/AE/modules/AE.py:91-166,
+ * distributions.py:41-42.  torchvision-0.8.1 ResNet-50 with InstanceNorm2d (use_batchnorm = 0) or eval-mode
+ * BatchNorm2d (1), fc = Conv2d(2048, 2E, 1); returns the posterior mean [B, E].
+ * Keys: model.conv1.weight, model.layer{1..4}.{i}.conv{1,2,3}.weight, model.layer{k}.0.downsample.0.weight,
+ * (BatchNorm) model.bn1.*, ...bn{1,2,3}.*, ...downsample.1.* {weight,bias,running_mean,running_var},
+ * model.fc.sub_layers.0.{weight,bias}.  Image side must be a power of two >= 64.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct i2v_embedder i2v_embedder;
+int i2v_embedder_create(int32_t z_dim, int32_t use_batchnorm, i2v_embedder** out);
+void i2v_embedder_destroy(i2v_embedder* e);
+int i2v_embedder_load(i2v_embedder* e, const i2v_tensor* tensors, int32_t n_tensors);
+size_t i2v_embedder_workspace_bytes(const i2v_embedder* e, int32_t batch, int32_t h, int32_t w);
+/* img [B,3,h,w] in [-1,1] (NCHW) -> embed [B, z_dim] */
+int i2v_embedder_forward(i2v_embedder* e, const float* img, int32_t h, int32_t w, float* embed, void* workspace,
+                         size_t workspace_bytes, int32_t batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

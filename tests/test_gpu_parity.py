@@ -241,7 +241,7 @@ def test_both_matrix_core_modes_agree():
         assert rel_l2(gen.cuda().eval()(cu(g["img"]), cu(g["z"])).cpu(), g["out"]) < TOL
 
 
-def _write_checkpoints(tmp_path, meta):
+def _write_checkpoints(tmp_path, meta, with_embedder=False):
     """Checkpoint tree as get_model.Model expects it (get_model.py:15-43): <stage2>/config_stage2.yaml + cINN.pth,
     <stage1>/config_stage1.yaml + best_PFVD_GEN.pth."""
     import yaml
@@ -259,6 +259,12 @@ def _write_checkpoints(tmp_path, meta):
                               "model_name": "run", "model_path": str(tmp_path / "stage1") + "/"},
         "Training": {"bs": 50}, "Data": {"img_size": 64}}))
     torch.save({"state_dict": T(synth.flow_state_dict(**meta["synth_flow"]))}, s2 / "cINN.pth")
+    if with_embedder:   # Conditioning_Model.model_path + model_name = <tmp>/ae/ (INN.py:37)
+        ae = tmp_path / "ae"
+        ae.mkdir()
+        (ae / "config_stage2_AE.yaml").write_text(yaml.safe_dump({"AE": {
+            "deterministic": False, "in_size": 64, "norm": "in", "encoder_type": "resnet50", "z_dim": 64}}))
+        torch.save({"state_dict": T(synth.embedder_state_dict(seed=3, z_dim=64, norm="in"))}, ae / "Encoder_stage2.pth")
     return str(s2) + "/"
 
 
@@ -278,6 +284,24 @@ def test_model_forward_semantics_vs_golden(tmp_path):
     assert model.synthesize(cu(g["x3"]), residual=cu(g["r3"]), embed=cu(g["e3"])).shape[0] == 3
 
 
+def test_model_from_pixels_with_embedder(tmp_path):
+    """Model.forward(x_0) end to end from pixels: ResNet-50 embedder -> cINN inverse -> decoder, vs the CPU oracle chain."""
+    from get_model import Model
+    from oracle import embedder_ref, model_ref, decoder_ref
+    _, meta = load_golden("model_nf8")
+    model = Model(_write_checkpoints(tmp_path, meta, with_embedder=True), 16)
+    assert model.flow.embedder is not None
+    x0, residual, _ = synth.bench_inputs(2, 64, 64)
+    out = model(x0.cuda(), residual=residual.cuda())
+    esd = T(synth.embedder_state_dict(seed=3, z_dim=64, norm="in"))
+    embed = embedder_ref.encode_mode(esd, x0, "in").reshape(2, -1)
+    ref = model_ref.model_forward(T(synth.flow_state_dict(**meta["synth_flow"])),
+                                  decoder_ref.fold_spectral_norm(T(synth.decoder_state_dict(**meta["synth_dec"]))), x0, residual,
+                                  embed, 16, upsample_s=meta["upsample_s"], upsample_t=meta["upsample_t"], faithful=False)
+    # (the 64x64 InstanceNorm embedder is ill-conditioned, see test_embedder_vs_oracle: its fp32 noise propagates)
+    assert out.shape == (2, 16, 3, 64, 64) and rel_l2(out.cpu(), ref) < 2e-3
+
+
 def test_generate_samples_cli(tmp_path, monkeypatch):
     """The sampling CLI end to end: PNG start frames -> results.gif (B = 5 images, -bs 2 -> short last batch)."""
     from PIL import Image
@@ -294,6 +318,27 @@ def test_generate_samples_cli(tmp_path, monkeypatch):
                            "-bs", "2", "-embed_seed", "1", "-img_path", str(img_dir) + "/", "-out_path", str(out_dir) + "/"])
     gif = Image.open(out_dir / "results.gif")
     assert gif.n_frames == 16 and gif.size == (5 * 64, 64)
+
+
+@pytest.mark.parametrize("norm,size", [("in", 64), ("bn", 128), ("in", 128)])
+def test_embedder_vs_oracle(norm, size):
+    """Row N1: ResnetEncoder.encode(x).mode() on the HIP path vs the (unpinned, see oracle/embedder_ref.py) CPU restatement."""
+    from oracle import embedder_ref
+    from stage2_cINN.AE.modules.AE import ResnetEncoder
+    sd = T(synth.embedder_state_dict(seed=3, z_dim=64, norm=norm))
+    enc = ResnetEncoder({"z_dim": 64, "deterministic": False, "in_size": size, "encoder_type": "resnet50", "norm": norm})
+    enc.load_state_dict(sd)
+    enc = enc.cuda().eval()
+    x = 2 * torch.rand(3, 3, size, size, generator=torch.Generator().manual_seed(9)) - 1
+    ref32 = embedder_ref.encode_mode(sd, x, norm)
+    sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    ref64 = embedder_ref.encode_mode(sd64, x.double(), norm)
+    out = enc.encode(x.cuda()).mode()
+    assert out.shape == (3, 64, 1, 1)
+    # InstanceNorm over the 2x2 / 4x4 maps of the last stages (64x64 inputs) is ill-conditioned: the fp32 CPU oracle itself
+    # sits 2.9e-4 (64^2) / 1.4e-5 (128^2) from its fp64 evaluation.  Gate: 1e-4, or 3x the oracle's own fp32 noise.
+    noise = rel_l2(ref32, ref64)
+    assert rel_l2(out.cpu(), ref64) < max(TOL, 3 * noise), (rel_l2(out.cpu(), ref64), noise)
 
 
 def test_full_size_properties_bair_b8():

@@ -52,6 +52,19 @@ def test_state_dict_layout_matches_reference_keys():
     assert set(gen2.state_dict()) == set(synth.decoder_state_dict(seed=1, channel_factor=8, spectral_norm=False))
 
 
+def test_embedder_state_dict_layout():
+    from stage2_cINN.AE.modules.AE import ResnetEncoder
+    for norm in ("in", "bn"):
+        ref = synth.embedder_state_dict(seed=1, z_dim=128, norm=norm)
+        enc = ResnetEncoder({"z_dim": 128, "deterministic": False, "in_size": 128, "encoder_type": "resnet50", "norm": norm})
+        mine = enc.state_dict()
+        assert set(mine) == set(ref), set(mine) ^ set(ref)
+        for k, v in ref.items():
+            assert tuple(mine[k].shape) == tuple(np.asarray(v).shape), k
+    # torchvision resnet50: 25,557,032 parameters - fc (2,049,000) - BatchNorm (53,120) = 23,454,912 conv weights
+    assert sum(v.size for v in synth.embedder_state_dict(z_dim=64, norm="in").values()) == 23454912 + 2048 * 128 + 128
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly off-GPU instead of computing on the CPU."""
     import i2v_native
