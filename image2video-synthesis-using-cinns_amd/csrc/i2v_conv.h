@@ -37,8 +37,8 @@ struct ConvArgs {
     int CinAct;         // channel stride of `in` (>= Cin of the weights)
     int Cout, CoutPad, nchunk;
     int KT, KH, KW;
-    int sS;                   // spatial stride (1 or 2; the embedder's ResNet); T, H, W are OUTPUT dims, the input is
-                              // [B][T][H*sS][W*sS][CinAct]
+    int sS, sT;               // spatial / temporal stride (1 or 2; embedder and motion encoder); T, H, W are OUTPUT
+                              // dims, the input is [B][T*sT][H*sS][W*sS][CinAct]
     int TB, TT, TH, TW;       // output brick handled by one workgroup (TB*TT*TH*TW == CONV_BM)
     int nbB, nbT, nbH, nbW;   // bricks per dimension
     int rt, rs;               // nearest-upsample factors applied when reading `res`
@@ -47,7 +47,8 @@ struct ConvArgs {
 
 // Chooses the brick and the tile variant and enqueues the kernel.
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
-                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef = nullptr, int stride = 1);
+                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef = nullptr, int stride = 1,
+                 int stride_t = 1);
 
 // ---- split-fp16 path (i2v_conv16.hip): operands carried as (fp16 hi, fp16 lo = x - hi) pairs, 3 fp16 MFMAs per product
 struct Conv16Weights {
@@ -75,7 +76,12 @@ bool conv16_can_fuse_stats(int T, int H, int W);
 // per-(b,c) sum / sum of squares (fp64) of a channels-last tensor [B][P][C]
 int stats_forward(const float* x, double* sums, int B, long P, int C, hipStream_t st);
 // (sum, sumsq) -> per-(b,c) (A, B) pairs with norm(x) == x*A + B (biased variance, eps 1e-5)
-int coef_forward(const double* sums, float* coef, int B, int C, int groups, double count, hipStream_t st);
+// gw/gb: optional per-channel affine weight / bias folded into the pairs (GroupNorm(affine=True))
+int coef_forward(const double* sums, float* coef, int B, int C, int groups, double count, hipStream_t st,
+                 const float* gw = nullptr, const float* gb = nullptr);
+// out = act(x * A + B (+ res)) on a channels-last [B][P][C] tensor; coef index = b * cstride + c (i2v_embed.hip)
+int norm_act_forward(const float* x, const float* coef, long cstride, const float* res, float* out, int B, long P, int C, bool relu,
+                     hipStream_t st);
 // bilinear (align_corners=True) NCHW [B,3,Hi,Wi] -> channels-last [B][Ho][Wo][16] (channels 3..15 zero)
 int resize_forward(const float* img, float* out, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t st);
 

@@ -39,11 +39,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
     const int half = lane >> 5, l31 = lane & 31;
 
     const int pt = a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
-    const int sS = a.sS;  // spatial stride: the halo brick covers (TH-1)*sS + KH input rows
-    const int HT = a.TT + a.KT - 1, HH = (a.TH - 1) * sS + a.KH, HW = (a.TW - 1) * sS + a.KW;
+    const int sS = a.sS, sT = a.sT;  // strides: the halo brick covers (TH-1)*sS + KH input rows
+    const int HT = (a.TT - 1) * sT + a.KT, HH = (a.TH - 1) * sS + a.KH, HW = (a.TW - 1) * sS + a.KW;
     const int NPOS = a.TB * HT * HH * HW;
     const int ntaps = a.KT * a.KH * a.KW;
-    const int Hin = a.H * sS, Win = a.W * sS;
+    const int Hin = a.H * sS, Win = a.W * sS, Tin = a.T * sT;
 
     float* in_lds = smem;
     float* w_lds = smem + NPOS * LS;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
         const int ih = m % a.TH; m /= a.TH;
         const int it = m % a.TT; m /= a.TT;
         const int b = b0 + m, t = t0 + it, h = h0 + ih, w = w0 + iw;
-        const bool ok = b < a.B;
+        const bool ok = b < a.B && m < a.TB;  // (a brick may be only partly filled when LDS limits TB)
         rowpos[tid] = ok ? ((b * a.T + t) * a.H + h) * a.W + w : -1;
         rowres[tid] = ok ? ((b * (a.T / a.rt) + t / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs) + w / a.rs : 0;
     }
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
         int cnt = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
             const int dt = tap / (a.KH * a.KW);
-            const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
-            if (hi < 0 || lo >= a.T) continue;  // the whole brick reads zero padding for this tap
+            const int lo = t0 * sT + dt - pt, hi = lo + (a.TT - 1) * sT;
+            if (hi < 0 || lo >= Tin) continue;  // the whole brick reads zero padding for this tap
             taplist[1 + cnt++] = tap;
         }
         taplist[0] = cnt;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
         const int iw = m % a.TW; m /= a.TW;
         const int ih = m % a.TH; m /= a.TH;
         const int it = m % a.TT; m /= a.TT;
-        aoff[wm] = (((m * HT + it) * HH + ih * sS) * HW + iw * sS) * LS + 4 * half;
+        aoff[wm] = ((((m < a.TB ? m : 0) * HT + it * sT) * HH + ih * sS) * HW + iw * sS) * LS + 4 * half;
     }
     int boff[WN];
 #pragma unroll
@@ -120,12 +120,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
             const int iw = p % HW; p /= HW;
             const int ih = p % HH; p /= HH;
             const int it = p % HT; p /= HT;
-            const int b = b0 + p, t = t0 + it - pt, h = h0 * sS + ih - ph, w = w0 * sS + iw - pw;
+            const int b = b0 + p, t = t0 * sT + it - pt, h = h0 * sS + ih - ph, w = w0 * sS + iw - pw;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int c = c0 + 4 * q;
-            if (b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)Hin && (unsigned)w < (unsigned)Win &&
+            if (b < a.B && (unsigned)t < (unsigned)Tin && (unsigned)h < (unsigned)Hin && (unsigned)w < (unsigned)Win &&
                 c < a.CinAct) {
-                v = *reinterpret_cast<const float4*>(a.in + ((((long)b * a.T + t) * Hin + h) * Win + w) * a.CinAct + c);
+                v = *reinterpret_cast<const float4*>(a.in + ((((long)b * Tin + t) * Hin + h) * Win + w) * a.CinAct + c);
                 if (a.coef) {  // normalisation folded into the load: norm(x)*g + beta == x*A + B per (sample, channel)
                     const float4 ab0 = *reinterpret_cast<const float4*>(a.coef + ((long)b * a.CinAct + c) * 2);
                     const float4 ab1 = *reinterpret_cast<const float4*>(a.coef + ((long)b * a.CinAct + c) * 2 + 4);
@@ -267,17 +267,19 @@ int launch(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
 }  // namespace
 
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
-                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef, int stride) {
+                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef, int stride, int stride_t) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv: weights not packed");
     I2V_REQUIRE(cin_act % 4 == 0 && cin_act >= wts.Cin, I2V_E_INVALID, "conv: activation channels %d (weights %d)",
                 cin_act, wts.Cin);
     I2V_REQUIRE(!coef || (wts.KT == 1 && wts.KH == 1 && wts.KW == 1), I2V_E_INVALID,
                 "conv: the on-load affine is only valid without padding (1x1x1 kernels)");
     I2V_REQUIRE(stride == 1 || stride == 2, I2V_E_INVALID, "conv: stride %d", stride);
-    I2V_REQUIRE(wts.KT * wts.KH * wts.KW <= 49, I2V_E_INVALID, "conv: kernel too large");
+    I2V_REQUIRE(wts.KT * wts.KH * wts.KW <= 150, I2V_E_INVALID, "conv: kernel too large");
     ConvArgs a{};
     a.coef = coef;
     a.sS = stride;
+    a.sT = stride_t;
+    I2V_REQUIRE(stride_t == 1 || stride_t == 2, I2V_E_INVALID, "conv: temporal stride %d", stride_t);
     a.in = in; a.wp = wts.w.as<float>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
     a.B = B; a.T = T; a.H = H; a.W = W; a.CinAct = cin_act;
     a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
@@ -290,15 +292,19 @@ int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* ou
     rem /= TT;
     while (rem > 1 && W >= TW * 2) { TW *= 2; rem /= 2; }
     while (rem > 1 && H >= TH * 2) { TH *= 2; rem /= 2; }
-    const int TB = rem;
+    int TB = rem;
     I2V_REQUIRE(TB * TT * TH * TW == CONV_BM && T % TT == 0 && H % TH == 0 && W % TW == 0, I2V_E_INVALID,
                 "conv: cannot tile [T=%d,H=%d,W=%d] into bricks of %d positions (dims must be powers of two)", T, H, W,
                 CONV_BM);
+    const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
+    const int pos1 = ((TT - 1) * stride_t + a.KT) * ((TH - 1) * stride + a.KH) * ((TW - 1) * stride + a.KW);  // halo rows per sample
+    auto lds_of = [&](int tb) {
+        return ((size_t)tb * pos1 * CONV_LDS_STRIDE + 2 * (size_t)BN * CONV_LDS_STRIDE) * 4 + (2 * CONV_BM + 160) * 4;
+    };
+    while (TB > 1 && lds_of(TB) > 160 * 1024) TB /= 2;  // fewer samples per brick: the tile's unused rows are masked
     a.TB = TB; a.TT = TT; a.TH = TH; a.TW = TW;
     a.nbB = (B + TB - 1) / TB; a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;
-    const int npos = TB * (TT + a.KT - 1) * ((TH - 1) * stride + a.KH) * ((TW - 1) * stride + a.KW);
-    const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
-    const size_t lds = ((size_t)npos * CONV_LDS_STRIDE + 2 * (size_t)BN * CONV_LDS_STRIDE) * 4 + (2 * CONV_BM + 64) * 4;
+    const size_t lds = lds_of(TB);
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv: LDS %zu bytes exceeds 160 KiB", lds);
     if (BN == 128) return launch<2, 2, 2, 2>(a, lds, st);
     if (BN == 64) return launch<2, 2, 2, 1>(a, lds, st);

@@ -359,8 +359,9 @@ int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* ou
 namespace i2v {
 // exported to i2v_embed.hip
 int stats_forward(const float* x, double* sums, int B, long P, int C, hipStream_t st) { return run_stats(x, sums, B, P, C, st); }
-int coef_forward(const double* sums, float* coef, int B, int C, int groups, double count, hipStream_t st) {
-    return run_coef(sums, coef, B, C, groups, count, nullptr, 0, 0, nullptr, nullptr, st);
+int coef_forward(const double* sums, float* coef, int B, int C, int groups, double count, hipStream_t st, const float* gw,
+                 const float* gb) {
+    return run_coef(sums, coef, B, C, groups, count, nullptr, 0, 0, gw, gb, st);
 }
 int resize_forward(const float* img, float* out, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
     const long tot = (long)B * Ho * Wo;

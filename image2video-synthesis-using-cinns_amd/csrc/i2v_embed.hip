@@ -69,6 +69,15 @@ __global__ void mean_from_sums_kernel(const double* __restrict__ sums, float* __
         out[i] = (float)(sums[2 * i] * inv_count);
 }
 
+int norm_act_forward(const float* x, const float* coef, long cstride, const float* res, float* out, int B, long P, int C, bool relu,
+                     hipStream_t st) {
+    const long per = P * (C / 4);
+    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)std::min<long>((per + 255) / 256, 4096), B), dim3(256), 0, st, x,
+                       reinterpret_cast<const float2*>(coef), cstride, res, out, per, C, relu ? 1 : 0);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
 }  // namespace i2v
 
 using namespace i2v;
@@ -144,11 +153,7 @@ int norm_act(const i2v_embedder* e, const NormP& np, const float* x, const float
         cp = reinterpret_cast<const float2*>(coef);
         cstride = C;
     }
-    const long per = P * (C / 4);
-    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)std::min<long>((per + 255) / 256, 4096), B), dim3(256), 0, st, x, cp, cstride, res,
-                       out, per, C, relu ? 1 : 0);
-    I2V_HIP_CHECK(hipGetLastError());
-    return I2V_OK;
+    return norm_act_forward(x, reinterpret_cast<const float*>(cp), cstride, res, out, B, P, C, relu, st);
 }
 
 }  // namespace

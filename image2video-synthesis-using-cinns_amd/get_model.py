@@ -13,15 +13,13 @@ import torch
 
 import i2v_config
 from stage1_VAE.modules import decoder
+from stage1_VAE.modules.resnet3D import Encoder
 from stage2_cINN.modules import INN
 
 
 class Model(torch.nn.Module):
     def __init__(self, model_path, vid_length, transfer=False, embedder=None):
         super().__init__()
-        if transfer:
-            raise NotImplementedError("Model(transfer=True): the 3D-ResNet motion encoder is row N3 of the coverage "
-                                      "contract (SURVEY §8f), not part of the sampling hot path")
         opt = i2v_config.load(os.path.join(model_path, "config_stage2.yaml"))
         path_stage1 = opt.First_stage_model["model_path"] + opt.First_stage_model["model_name"] + "/"
         config = i2v_config.load(path_stage1 + "config_stage1.yaml")
@@ -30,6 +28,12 @@ class Model(torch.nn.Module):
         self.decoder.load_state_dict(torch.load(path_stage1 + opt.First_stage_model["checkpoint_decoder"] + ".pth",
                                                 map_location="cpu")["state_dict"])
         _ = self.decoder.eval()
+
+        if transfer:   # motion encoder of the transfer path (get_model.py:27-31)
+            self.encoder = Encoder(dic=config.Encoder).cuda()
+            self.encoder.load_state_dict(torch.load(path_stage1 + opt.First_stage_model["checkpoint_encoder"] + ".pth.tar",
+                                                    map_location="cpu")["state_dict"])
+            _ = self.encoder.eval()
 
         flow_mid_channels = config.Decoder["z_dim"] * opt.Flow["flow_mid_channels_factor"]
         self.flow = INN.SupervisedTransformer(flow_in_channels=config.Decoder["z_dim"],
@@ -65,3 +69,18 @@ class Model(torch.nn.Module):
         """Input: x_0 (start frame) of shape (BS, C, H, W).  Output as the reference: ``seq[:vid_length]`` --
         a slice over the BATCH dimension (quirk Q3)."""
         return self.synthesize(x_0, cond, residual, embed)[:self.vid_length]
+
+    @torch.no_grad()
+    def transfer(self, seq_query, x_0, embed_query=None, embed=None):
+        """Motion transfer (reference get_model.py:77-103).  seq_query [BS,T,C,H,W]; x_0 [BS',C,H,W] start frames the motion is
+        transferred to.  Returns the un-sliced sequence [BS',T',C,H,W].  ``embed_query`` / ``embed`` optionally replace the
+        conditioning embedder's outputs for seq_query[:, 0] and x_0."""
+        _, z, _ = self.encoder(seq_query[:, 1:].transpose(1, 2))                       # :87 (the MEAN is kept)
+        res, _ = self.flow(z, [seq_query[:, 0].contiguous()], embed=embed_query)       # :90 cINN forward
+        res = res.view(z.size(0), -1).repeat(x_0.size(0), 1).contiguous()
+        z_ref = self.flow(res, [x_0], reverse=True, embed=embed).view(x_0.size(0), -1)  # :93
+        seq_gen = self.decoder(x_0, z_ref)                                             # :96
+        while seq_gen.shape[1] < self.vid_length:                                      # :99-101
+            seq1 = self.decoder(seq_gen[:, -1].contiguous(), z_ref)
+            seq_gen = torch.cat((seq_gen, seq1), dim=1)
+        return seq_gen

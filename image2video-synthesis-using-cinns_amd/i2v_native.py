@@ -37,6 +37,11 @@ class DecCfg(ctypes.Structure):
                 ("upsample_t", c_int32 * 2), ("spectral_norm", c_int32), ("mma", c_int32)]
 
 
+class Enc3dCfg(ctypes.Structure):
+    _fields_ = [("z_dim", c_int32), ("channels", c_int32 * 5), ("stride_s", c_int32 * 4), ("stride_t", c_int32 * 4),
+                ("use_max_pool", c_int32)]
+
+
 _lib = None
 
 # symbol -> (restype, argtypes); also the list the CPU test-suite checks the .so exports
@@ -73,6 +78,12 @@ SYMBOLS = {
     "i2v_embedder_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
     "i2v_embedder_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32, c_int32]),
     "i2v_embedder_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "i2v_encoder3d_create": (c_int32, [POINTER(Enc3dCfg), POINTER(c_void_p)]),
+    "i2v_encoder3d_destroy": (None, [c_void_p]),
+    "i2v_encoder3d_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
+    "i2v_encoder3d_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32, c_int32, c_int32]),
+    "i2v_encoder3d_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_size_t, c_int32, c_void_p]),
     "i2v_dec_create": (c_int32, [POINTER(DecCfg), POINTER(c_void_p)]),
     "i2v_dec_destroy": (None, [c_void_p]),
     "i2v_dec_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
@@ -465,3 +476,39 @@ class NativeEmbedder:
         _check(lib().i2v_embedder_forward(self._h, img.data_ptr(), H, W, out.data_ptr(), ws.data_ptr(), ws.numel(), B, _stream()),
                "i2v_embedder_forward")
         return out
+
+
+class NativeEncoder3D:
+    """Handle for ``i2v_encoder3d_*`` (Encoder.forward, resnet3D.py:138-219)."""
+
+    def __init__(self, z_dim, channels, stride_s, stride_t):
+        cfg = Enc3dCfg(z_dim, (c_int32 * 5)(*channels), (c_int32 * 4)(*stride_s), (c_int32 * 4)(*stride_t), 0)
+        h = c_void_p()
+        _check(lib().i2v_encoder3d_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_encoder3d_create")
+        self._h = h
+        self.z_dim = z_dim
+        self._ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.i2v_encoder3d_destroy(self._h)
+            self._h = None
+
+    def load(self, state_dict):
+        arr, keep = _pack_state_dict(state_dict)
+        _check(lib().i2v_encoder3d_load(self._h, arr, len(arr)), "i2v_encoder3d_load")
+        del keep
+
+    def forward(self, x, eps=None):
+        _require_gpu(x, eps)
+        if x.dim() != 5 or x.shape[1] != 3:
+            raise I2VError(f"encoder: expected x [B,3,T,H,W], got {tuple(x.shape)}")
+        B, _, T, H, W = x.shape
+        ws = self._ws.get(lib().i2v_encoder3d_workspace_bytes(self._h, B, T, H, W), x.device)
+        mu = torch.empty(B, self.z_dim, dtype=torch.float32, device=x.device)
+        logvar = torch.empty_like(mu)
+        sample = torch.empty_like(mu) if eps is not None else None
+        _check(lib().i2v_encoder3d_forward(self._h, x.data_ptr(), T, H, W, eps.data_ptr() if eps is not None else None,
+                                           sample.data_ptr() if sample is not None else None, mu.data_ptr(), logvar.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), B, _stream()), "i2v_encoder3d_forward")
+        return sample, mu, logvar

@@ -24,7 +24,7 @@ Requirements the synthesiser meets (found by running the reference)
 """
 import numpy as np
 
-__all__ = ["flow_state_dict", "decoder_state_dict", "embedder_state_dict", "bench_inputs"]
+__all__ = ["flow_state_dict", "decoder_state_dict", "embedder_state_dict", "encoder3d_state_dict", "bench_inputs"]
 
 
 def _uniform(rng, shape, bound):
@@ -194,6 +194,40 @@ def embedder_state_dict(seed=7, z_dim=64, norm="in"):
             inplanes = planes * 4
     sd["model.fc.sub_layers.0.weight"] = _uniform(rng, (2 * z_dim, 2048, 1, 1), 1.0 / np.sqrt(2048))
     sd["model.fc.sub_layers.0.bias"] = _uniform(rng, (2 * z_dim,), 0.1)
+    return sd
+
+
+def encoder3d_state_dict(seed=7, z_dim=64, channels=(64, 128, 256, 512, 512), stride_s=(1, 2, 2, 2)):
+    """state_dict of the motion ``Encoder`` (stage1_VAE/modules/resnet3D.py:138-219, resnet18 BasicBlocks) as
+    {key: np.ndarray}."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def conv(name, cout, cin, *k):
+        fan_in = cin * int(np.prod(k))
+        sd[name + ".weight"] = _uniform(rng, (cout, cin) + tuple(k), np.sqrt(3.0 / fan_in))
+
+    def gn(name, c):
+        sd[name + ".weight"] = (1.0 + _uniform(rng, (c,), 0.2)).astype(np.float32)
+        sd[name + ".bias"] = _uniform(rng, (c,), 0.2)
+
+    conv("conv1", channels[0], 3, 3, 7, 7)
+    gn("norm1", channels[0])
+    inplanes = channels[0]
+    for L, ch in enumerate(channels[1:]):
+        for i in range(2):
+            p = f"layer.{L}.{i}."
+            conv(p + "conv1", ch, inplanes if i == 0 else ch, 3, 3, 3)
+            gn(p + "bn1", ch)
+            conv(p + "conv2", ch, ch, 3, 3, 3)
+            gn(p + "bn2", ch)
+            if i == 0 and (stride_s[L] != 1 or inplanes != ch):
+                conv(p + "downsample.0", ch, inplanes, 3, 3, 3)
+                gn(p + "downsample.1", ch)
+        inplanes = ch
+    for head in ("conv_mu", "conv_var"):
+        sd[head + ".weight"] = _uniform(rng, (z_dim, channels[-1], 4, 4), 1.0 / np.sqrt(channels[-1] * 16))
+        sd[head + ".bias"] = _uniform(rng, (z_dim,), 0.1)
     return sd
 
 

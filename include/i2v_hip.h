@@ -194,6 +194,28 @@ size_t i2v_embedder_workspace_bytes(const i2v_embedder* e, int32_t batch, int32_
 int i2v_embedder_forward(i2v_embedder* e, const float* img, int32_t h, int32_t w, float* embed, void* workspace,
                          size_t workspace_bytes, int32_t batch, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Motion encoder of the transfer path (row N3): Encoder.forward -- stage1_VAE/modules/resnet3D.py:138-219
+ * (3D ResNet-18, GroupNorm(16), conv_mu / conv_var).  Model.transfer (get_model.py:87) uses mu.
+ * Keys: conv1.weight, norm1.*, layer.{L}.{i}.{conv1,conv2}.weight, .bn{1,2}.*, .downsample.{0.weight,1.*},
+ * conv_mu.*, conv_var.*.  Frames must be powers of two >= 64 and reduce to a [1,4,4] map.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct i2v_encoder3d i2v_encoder3d;
+typedef struct {
+    int32_t z_dim;        /* 64 */
+    int32_t channels[5];  /* e.g. [64,128,256,512,512] */
+    int32_t stride_s[4];  /* e.g. [1,2,2,2] */
+    int32_t stride_t[4];  /* e.g. [1,2,2,2] */
+    int32_t use_max_pool; /* must be 0 (every shipped config) */
+} i2v_encoder3d_cfg;
+int i2v_encoder3d_create(const i2v_encoder3d_cfg* cfg, i2v_encoder3d** out);
+void i2v_encoder3d_destroy(i2v_encoder3d* e);
+int i2v_encoder3d_load(i2v_encoder3d* e, const i2v_tensor* tensors, int32_t n_tensors);
+size_t i2v_encoder3d_workspace_bytes(const i2v_encoder3d* e, int32_t batch, int32_t t, int32_t h, int32_t w);
+/* x [B,3,t,h,w] -> mu [B,z], logvar [B,z]; sample = eps * exp(0.5 logvar) + mu when sample != NULL (eps [B,z]). */
+int i2v_encoder3d_forward(i2v_encoder3d* e, const float* x, int32_t t, int32_t h, int32_t w, const float* eps, float* sample,
+                          float* mu, float* logvar, void* workspace, size_t workspace_bytes, int32_t batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

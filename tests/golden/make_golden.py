@@ -259,8 +259,25 @@ def model_small():
          yq3_shape=np.array(yq3.shape), yq3_t4=yq3[:, ::4].contiguous(), y20_shape=np.array(y20.shape))
 
 
+def encoder3d():
+    # N3: the motion Encoder of the reference (stage1_VAE/modules/resnet3D.py:138-219), BAIR and landscape geometries
+    from stage1_VAE.modules import resnet3D as ref_r3d
+    for name, channels, stride_s, size, nfr in (("enc3d_bair", [64, 128, 256, 512, 512], [1, 2, 2, 2], 64, 16),
+                                                ("enc3d_land", [64, 128, 128, 256, 512], [2, 2, 2, 2], 128, 15)):
+        args = dict(seed=9, z_dim=64, channels=channels, stride_s=stride_s)
+        enc = ref_r3d.Encoder({"res_type_encoder": "resnet18", "use_max_pool": False, "z_dim": 64, "channels": channels,
+                               "stride_s": stride_s, "stride_t": [1, 2, 2, 2], "deterministic": False}).eval()
+        enc.load_state_dict(T(synth.encoder3d_state_dict(**args)))
+        # the clip is regenerated from its seed at test time (CPU generator); a checksum guards against RNG drift
+        x = 2 * torch.rand(2, 3, nfr, size, size, generator=torch.Generator().manual_seed(71)) - 1
+        _, mu, logvar = enc(x)
+        save(name, dict(synth=args, stride_t=[1, 2, 2, 2], x_seed=71, x_shape=list(x.shape)), x_head=x.reshape(-1)[:16],
+             x_sum=np.float64(x.double().sum()), mu=mu, logvar=logvar)
+        print("   ", name, "|mu| mean", float(mu.abs().mean()), "|logvar| mean", float(logvar.abs().mean()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["flow_units", "flow_full", "dec_units", "dec_small", "dec_full", "model_small"]
+    which = sys.argv[1:] or ["flow_units", "flow_full", "dec_units", "dec_small", "dec_full", "model_small", "encoder3d"]
     if "flow_units" in which:
         flow_units()
     if "flow_full" in which:
@@ -275,3 +292,5 @@ if __name__ == "__main__":
         dec_full()
     if "model_small" in which:
         model_small()
+    if "encoder3d" in which:
+        encoder3d()

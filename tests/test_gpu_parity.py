@@ -241,7 +241,7 @@ def test_both_matrix_core_modes_agree():
         assert rel_l2(gen.cuda().eval()(cu(g["img"]), cu(g["z"])).cpu(), g["out"]) < TOL
 
 
-def _write_checkpoints(tmp_path, meta, with_embedder=False):
+def _write_checkpoints(tmp_path, meta, with_embedder=False, with_encoder=False):
     """Checkpoint tree as get_model.Model expects it (get_model.py:15-43): <stage2>/config_stage2.yaml + cINN.pth,
     <stage1>/config_stage1.yaml + best_PFVD_GEN.pth."""
     import yaml
@@ -250,7 +250,9 @@ def _write_checkpoints(tmp_path, meta, with_embedder=False):
     s1.mkdir(parents=True)
     s2.mkdir()
     (s1 / "config_stage1.yaml").write_text(yaml.safe_dump({"Decoder": {
-        "channel_factor": 8, "z_dim": 64, "upsample_s": meta["upsample_s"], "upsample_t": meta["upsample_t"], "spectral_norm": True}}))
+        "channel_factor": 8, "z_dim": 64, "upsample_s": meta["upsample_s"], "upsample_t": meta["upsample_t"], "spectral_norm": True},
+        "Encoder": {"res_type_encoder": "resnet18", "deterministic": False, "use_max_pool": False, "z_dim": 64,
+                    "channels": [64, 128, 256, 512, 512], "stride_t": [1, 2, 2, 2], "stride_s": [1, 2, 2, 2]}}))
     torch.save({"state_dict": T(synth.decoder_state_dict(**meta["synth_dec"]))}, s1 / "best_PFVD_GEN.pth")
     (s2 / "config_stage2.yaml").write_text(yaml.safe_dump({
         "Flow": {"n_flows": 20, "flow_hidden_depth": 2, "flow_mid_channels_factor": 8},
@@ -259,6 +261,8 @@ def _write_checkpoints(tmp_path, meta, with_embedder=False):
                               "model_name": "run", "model_path": str(tmp_path / "stage1") + "/"},
         "Training": {"bs": 50}, "Data": {"img_size": 64}}))
     torch.save({"state_dict": T(synth.flow_state_dict(**meta["synth_flow"]))}, s2 / "cINN.pth")
+    if with_encoder:    # First_stage_model.checkpoint_encoder + '.pth.tar' (get_model.py:29)
+        torch.save({"state_dict": T(synth.encoder3d_state_dict(seed=9))}, s1 / "best_PFVD_ENC.pth.tar")
     if with_embedder:   # Conditioning_Model.model_path + model_name = <tmp>/ae/ (INN.py:37)
         ae = tmp_path / "ae"
         ae.mkdir()
@@ -339,6 +343,47 @@ def test_embedder_vs_oracle(norm, size):
     # sits 2.9e-4 (64^2) / 1.4e-5 (128^2) from its fp64 evaluation.  Gate: 1e-4, or 3x the oracle's own fp32 noise.
     noise = rel_l2(ref32, ref64)
     assert rel_l2(out.cpu(), ref64) < max(TOL, 3 * noise), (rel_l2(out.cpu(), ref64), noise)
+
+
+@pytest.mark.parametrize("name", ["enc3d_bair", "enc3d_land"])
+def test_motion_encoder_vs_golden(name):
+    """Row N3: Encoder.forward (3D ResNet-18) on the HIP path vs the reference module's outputs."""
+    from stage1_VAE.modules.resnet3D import Encoder
+    from test_oracle_golden import golden_clip
+    g, meta = load_golden(name)
+    a = meta["synth"]
+    enc = Encoder({"res_type_encoder": "resnet18", "use_max_pool": False, "z_dim": 64, "channels": a["channels"],
+                   "stride_s": a["stride_s"], "stride_t": meta["stride_t"]})
+    enc.load_state_dict(T(synth.encoder3d_state_dict(**a)))
+    enc = enc.cuda().eval()
+    x = golden_clip(meta, g).cuda()
+    sample, mu, logvar = enc(x)
+    assert rel_l2(mu.cpu(), g["mu"]) < TOL and rel_l2(logvar.cpu(), g["logvar"]) < TOL
+    assert sample.shape == mu.shape and bool(torch.isfinite(sample).all())
+    _, mu2, _ = enc(x.transpose(1, 2).contiguous())   # [B,T,3,H,W] is transposed like the reference does (resnet3D.py:206-207)
+    assert torch.equal(mu2, mu)
+
+
+def test_model_transfer_vs_oracle(tmp_path):
+    """Model.transfer (get_model.py:77-103): encoder -> cINN forward -> cINN inverse on new start frames -> decoder."""
+    from get_model import Model
+    from oracle import decoder_ref, encoder_ref, flow_ref
+    _, meta = load_golden("model_nf8")
+    ckpt = _write_checkpoints(tmp_path, meta, with_encoder=True)
+    model = Model(ckpt, 16, transfer=True)
+    gsd = torch.Generator().manual_seed(5)
+    query = 2 * torch.rand(1, 17, 3, 64, 64, generator=gsd) - 1
+    x0 = 2 * torch.rand(2, 3, 64, 64, generator=gsd) - 1
+    eq, e0 = torch.randn(1, 64, generator=gsd), torch.randn(2, 64, generator=gsd)
+    out = model.transfer(query.cuda(), x0.cuda(), embed_query=eq.cuda(), embed=e0.cuda())
+    esd = T(synth.encoder3d_state_dict(seed=9))
+    fsd = T(synth.flow_state_dict(**meta["synth_flow"]))
+    dsd = decoder_ref.fold_spectral_norm(T(synth.decoder_state_dict(**meta["synth_dec"])))
+    mu, _ = encoder_ref.encoder(esd, query[:, 1:].transpose(1, 2))
+    res, _ = flow_ref.flow_forward(fsd, mu, eq)
+    z_ref = flow_ref.flow_reverse(fsd, res.view(1, -1).repeat(2, 1), e0).view(2, -1)
+    ref = decoder_ref.generator(dsd, x0, z_ref, meta["upsample_s"], meta["upsample_t"], faithful=False)
+    assert out.shape == (2, 16, 3, 64, 64) and rel_l2(out.cpu(), ref) < TOL
 
 
 def test_full_size_properties_bair_b8():

@@ -6,7 +6,7 @@ import torch
 
 import i2v_synth as synth
 from conftest import load_golden, rel_l2
-from oracle import decoder_ref, flow_ref, model_ref
+from oracle import decoder_ref, encoder_ref, flow_ref, model_ref
 
 torch.set_grad_enabled(False)
 TOL = 2e-5  # oracle vs reference: same ATen ops, differences are blocking/rounding only
@@ -129,3 +129,19 @@ def test_model_forward_semantics():
     assert rel_l2(yq3[:, ::4], g["yq3_t4"]) < 5e-5
     y20 = model_ref.model_forward(fsd, dsd, t(g["x1"]), t(g["r1"]), t(g["e1"]), vid_length=20, **kw)
     assert list(y20.shape) == list(g["y20_shape"]) == [1, 32, 3, 64, 64]
+
+
+def golden_clip(meta, g):
+    """Regenerates the encoder fixture's input clip from its seed and checks it against the stored head / checksum."""
+    x = 2 * torch.rand(*meta["x_shape"], generator=torch.Generator().manual_seed(meta["x_seed"])) - 1
+    assert np.array_equal(x.reshape(-1)[:16].numpy(), g["x_head"]) and abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6
+    return x
+
+
+@pytest.mark.parametrize("name", ["enc3d_bair", "enc3d_land"])
+def test_motion_encoder(name):
+    g, meta = load_golden(name)
+    a = meta["synth"]
+    sd = T(synth.encoder3d_state_dict(**a))
+    mu, logvar = encoder_ref.encoder(sd, golden_clip(meta, g), a["channels"], a["stride_s"], meta["stride_t"])
+    assert rel_l2(mu, g["mu"]) < TOL and rel_l2(logvar, g["logvar"]) < TOL
