@@ -386,6 +386,48 @@ def test_model_transfer_vs_oracle(tmp_path):
     assert out.shape == (2, 16, 3, 64, 64) and rel_l2(out.cpu(), ref) < TOL
 
 
+def test_model_control_variant_vs_oracle(tmp_path):
+    """Row N2: endpoint-controlled sampling (Training.control = True): E = 64 + 30, blocks fl % 4 != 0 in mode 'cond',
+    embed_pos one-hots (INN.py:49-57, flow_blocks.py:24) -- Model.forward(x_0, cond=pos) vs the oracle chain."""
+    import yaml
+    from get_model import Model
+    from oracle import decoder_ref, flow_ref
+    _, meta = load_golden("model_nf8")
+    ckpt = _write_checkpoints(tmp_path, meta)
+    cfg = yaml.safe_load(open(ckpt + "config_stage2.yaml"))
+    cfg["Training"]["control"] = True
+    open(ckpt + "config_stage2.yaml", "w").write(yaml.safe_dump(cfg))
+    fargs = dict(seed=7, n_flows=20, embedding_dim=94, control=True)
+    torch.save({"state_dict": T(synth.flow_state_dict(**fargs))}, ckpt + "cINN.pth")
+    model = Model(ckpt, 16)
+    x0, residual, embed = synth.bench_inputs(3, 64, 64)
+    pos = torch.tensor([[0.05, 0.5, 1.0], [0.31, 0.999, 0.1001], [0.7, 0.2, 0.45]])
+    out = model(x0.cuda(), cond=pos, residual=residual.cuda(), embed=embed.cuda())
+    full = torch.cat((embed, flow_ref.embed_pos(pos)), dim=1)
+    z = flow_ref.flow_reverse(T(synth.flow_state_dict(**fargs)), residual, full, control=True).view(3, -1)
+    ref = decoder_ref.generator(decoder_ref.fold_spectral_norm(T(synth.decoder_state_dict(**meta["synth_dec"]))), x0, z,
+                                meta["upsample_s"], meta["upsample_t"], faithful=False)
+    assert out.shape == (3, 16, 3, 64, 64) and rel_l2(out.cpu(), ref) < TOL
+
+
+def test_generate_transfer_cli(tmp_path):
+    from PIL import Image
+    import generate_transfer
+    _, meta = load_golden("model_nf8")
+    ckpt = _write_checkpoints(tmp_path, meta, with_embedder=True, with_encoder=True)
+    rng = np.random.default_rng(1)
+    for v in range(2):
+        d = tmp_path / "clips" / f"v{v}"
+        d.mkdir(parents=True)
+        for i in range(17):
+            Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)).save(d / f"{i:03d}.png")
+    out_dir = tmp_path / "out"
+    generate_transfer.main(["-gpu", os.environ.get("HIP_VISIBLE_DEVICES", "0"), "-dataset", "bair", "-ckpt_path", ckpt, "-seq_length", "17",
+                            "-img_path", str(tmp_path / "clips") + "/", "-out_path", str(out_dir) + "/"])
+    gif = Image.open(out_dir / "transfer_1.gif")
+    assert gif.n_frames == 17 and gif.size == (3 * 64, 64)
+
+
 def test_full_size_properties_bair_b8():
     """BASELINE geometry (nf = 64, 64x64x16) at a batch the oracle cannot finish quickly: size-independent properties.
     Shards of the batch reproduce the rows of the full batch bit-for-bit; output in (-1, 1); finite."""
