@@ -166,12 +166,35 @@ def main():
                 "inv_latency_us": cinn["inv_us"], "fwd_latency_us": cinn["fwd_us"], "batch": nb,
             },
         }
+        result["embedder"] = embedder_latency(cfg, x0_d)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, fsd, dsd)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def embedder_latency(cfg, x0_d):
+    """Row N1 (conditioning ResNet-50, in FRONT of the benchmarked path -- the step consumes a ready embedding):
+    device time of ResnetEncoder.encode(x_0).mode() on the same start frames, reported separately."""
+    import i2v_synth as synth
+    from stage2_cINN.AE.modules.AE import ResnetEncoder
+    enc = ResnetEncoder({"z_dim": cfg["emb"], "deterministic": False, "in_size": cfg["img"], "encoder_type": "resnet50", "norm": "in"})
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.embedder_state_dict(seed=7, z_dim=cfg["emb"]).items()})
+    enc = enc.to(x0_d.device).eval()
+    for _ in range(2):
+        enc.encode(x0_d).mode()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        enc.encode(x0_d).mode()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return {"what": "ResNet-50 conditioning embedder (InstanceNorm variant), same batch; not part of `value`",
+            "ms_per_batch": float(np.median(ts)), "batch": int(x0_d.shape[0])}
 
 
 def roofline(prof, dt, mma, default_workload=False):
