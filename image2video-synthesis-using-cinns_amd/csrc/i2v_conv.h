@@ -68,7 +68,7 @@ struct Conv16Weights {
 // in_hl16: channels-last activations in the hl16 format (4 bytes per element, Cin % 8 == 0); out: fp32 channels-last.
 // T,H,W = OUTPUT geometry (for pack_tdup weights the input tensor has T/2 frames).
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st, int ablate = 0, double* stats = nullptr);
+                   int H, int W, int epi, hipStream_t st, double* stats = nullptr);
 // true when conv16_forward can accumulate per-(sample, channel) sum / sum-of-squares of its output in the epilogue
 bool conv16_can_fuse_stats(int T, int H, int W);
 

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
                     __syncthreads();
                     if (st + 1 < nst) C16_LOAD_OPS(o0, tapo[(st + 1) * TPS], wnext, 0)
                 }
+                // (s_setprio around the MFMA block and dropping these scheduling fences were measured: no effect)
                 __builtin_amdgcn_sched_barrier(0);
                 if (q & 1) C16_MFMA(o1) else C16_MFMA(o0)
                 __builtin_amdgcn_sched_barrier(0);
@@ -454,7 +455,7 @@ bool conv16_can_fuse_stats(int T, int H, int W) {
 }
 
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st, int ablate, double* stats) {
+                   int H, int W, int epi, hipStream_t st, double* stats) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv16: weights not packed");
     I2V_REQUIRE(wts.Cin % 8 == 0, I2V_E_INVALID, "conv16: Cin %d must be a multiple of 8", wts.Cin);
     Conv16Args a{};
@@ -503,7 +504,6 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
-    (void)ablate;
     if (BN == 128) return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
     if (BN == 64) return launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
     return launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);

@@ -351,7 +351,7 @@ int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* ou
     // 18 instead of 27 taps in temporal-duplication mode
     const double fl = 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0;
     ProfScope ps(d, st, fl, 3.0 * fl * (w.tdup ? 18.0 / 27.0 : 1.0));
-    return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, 0, stats);
+    return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats);
 }
 
 }  // namespace

@@ -1,4 +1,4 @@
-// Stand-alone ablation benchmark of the split-fp16 conv kernel on one layer shape (default: g_3.conv_0 of the BAIR
+// Stand-alone benchmark of the split-fp16 conv kernel on one layer shape (default: g_3.conv_0 of the BAIR
 // decoder: [B,16,64,64,256] -> 128).  Build: hipcc -O3 --offload-arch=gfx950 -DI2V_ABLATE -I<csrc> tools/conv16_bench.hip
 //   <csrc>/i2v_conv16.hip <csrc>/i2v_common.hip -o conv16_bench
 #include <cstdio>
@@ -25,22 +25,18 @@ int main(int argc, char** argv) {
     hipMalloc(&dout, npos * Cout * 4);
     hipMemcpy(din, in.data(), in.size() * 2, hipMemcpyHostToDevice);
     const double flops = 2.0 * npos * Cin * Cout * 27.0;
-    int variants[] = {0};
-    for (int abl : variants) {
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int it = 0; it < 2; ++it)
-            if (conv16_forward(cw, din, dout, nullptr, 1, 1, B, T, H, W, 0, nullptr, abl)) { printf("err %s\n", i2v_last_error()); return 1; }
-        hipDeviceSynchronize();
-        hipEventRecord(e0);
-        const int n = 5;
-        for (int it = 0; it < n; ++it) conv16_forward(cw, din, dout, nullptr, 1, 1, B, T, H, W, 0, nullptr, abl);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        ms /= n;
-        printf("ablate %2d [%s%s%s%s%s]: %8.3f ms  %7.1f TFLOP/s-equivalent\n", abl, abl & 1 ? "noMFMA " : "", abl & 2 ? "noLDSread " : "",
-               abl & 4 ? "noWeights " : "", abl & 8 ? "noInputStage " : "", abl & 16 ? "noBarrier " : "", ms, flops / ms / 1e9);
-    }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int it = 0; it < 2; ++it)
+        if (conv16_forward(cw, din, dout, nullptr, 1, 1, B, T, H, W, 0, nullptr)) { printf("err %s\n", i2v_last_error()); return 1; }
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    const int n = 5;
+    for (int it = 0; it < n; ++it) conv16_forward(cw, din, dout, nullptr, 1, 1, B, T, H, W, 0, nullptr);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    ms /= n;
+    printf("[B=%d,16,64,64,%d] -> %d: %8.3f ms  %7.1f TFLOP/s algorithmic\n", B, Cin, Cout, ms, flops / ms / 1e9);
     return 0;
 }
