@@ -23,6 +23,7 @@
 // MFMAs per wave run, with ONE barrier per tap placed between the two k-steps (it publishes the next tap's weights).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "i2v_conv.h"
 
@@ -76,10 +77,12 @@ __device__ __forceinline__ int brick_index(int row, int TH, int TW, int patch) {
 // TPS = taps per pipeline stage: the narrower the channel tile, the more taps share one weight buffer / barrier
 // (BN x TPS = 128 rows per buffer for every variant).
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
-__global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void conv_mfma_f16x3_kernel(Conv16Args a) {
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N;              // 512 (2 waves per SIMD) or 1024 (4 per SIMD)
+    constexpr int NSLOT = C16_SLOTS * 512 / NTHR;            // prefetched 16-byte input pieces per thread
     constexpr int C16_BN = 32 * WN * WAVES_N;
     constexpr int WBUF = TPS * C16_BN * C16_ROW;  // bytes per weight buffer
-    static_assert(32 * WM * WAVES_M == C16_BM && WAVES_M * WAVES_N == 8, "tile");
+    static_assert(32 * WM * WAVES_M == C16_BM && (WAVES_M * WAVES_N == 8 || WAVES_M * WAVES_N == 16), "tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
         taplist[0] = cnt;
     }
 
-    for (int p0 = tid; p0 < NPOS; p0 += 512) {
+    for (int p0 = tid; p0 < NPOS; p0 += NTHR) {
         int p = p0;
         const int iw = p % HW; p /= HW;
         const int ih = p % HH; p /= HH;
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
             for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
     constexpr int WF4 = TPS * C16_BN * 8;      // 16-byte pieces per stage of weights (TPS slabs)
-    constexpr int WLD = WF4 / 512;
-    static_assert(WF4 % 512 == 0 && WLD <= 2, "weight pieces per thread");
+    constexpr int WLD = WF4 / NTHR;
+    static_assert(WF4 % NTHR == 0 && WLD >= 1 && WLD <= 2, "weight pieces per thread");
     const long slab = (long)a.CoutPad * 128;  // bytes per (tap, chunk)
     __syncthreads();
     const int ntv = taplist[0];
@@ -184,16 +187,16 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     // latency per chunk instead of one per piece) and the NEXT chunk's pieces are requested a few taps before the
     // current chunk ends, so that latency hides behind MFMA work.
     const int ngrp = a.Cin >> 3;
-    float4 vin[C16_SLOTS];
+    float4 vin[NSLOT];
 #define C16_REQUEST_INPUT(ch_)                                                                                      \
     {                                                                                                                \
-        int gp_[C16_SLOTS];                                                                                          \
-        _Pragma("unroll") for (int u = 0; u < C16_SLOTS; ++u) {                                                      \
-            const int idx = tid + u * 512;                                                                           \
+        int gp_[NSLOT];                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < NSLOT; ++u) {                                                          \
+            const int idx = tid + u * NTHR;                                                                          \
             gp_[u] = gpos[idx < NPOS * 8 ? (idx >> 3) : 0];                                                          \
         }                                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < C16_SLOTS; ++u) {                                                      \
-            const int idx = tid + u * 512;                                                                           \
+        _Pragma("unroll") for (int u = 0; u < NSLOT; ++u) {                                                          \
+            const int idx = tid + u * NTHR;                                                                          \
             const int q = idx & 7;                                                                                   \
             const bool ok = idx < NPOS * 8 && gp_[u] >= 0 && (ch_) * 4 + (q >> 1) < ngrp;                            \
             const long off = ok ? (long)gp_[u] * in_row + (long)(ch_) * 128 + q * 16 : 0;                            \
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     int wtis[WLD], wsrc[WLD], wdst[WLD];
 #pragma unroll
     for (int u = 0; u < WLD; ++u) {
-        const int f = tid + u * 512;
+        const int f = tid + u * NTHR;
         const int tis = f / (C16_BN * 8), fr = f % (C16_BN * 8);
         wtis[u] = tis;
         wsrc[u] = fr * 16;
@@ -248,11 +251,11 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < C16_SLOTS; ++u) {
-            const int idx = tid + u * 512;
+        for (int u = 0; u < NSLOT; ++u) {
+            const int idx = tid + u * NTHR;
             if (idx < NPOS * 8) *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + (idx & 7) * 16) = vin[u];
         }
-        for (int idx = tid + C16_SLOTS * 512; idx < NPOS * 8; idx += 512) {  // oversized halo bricks only
+        for (int idx = tid + NSLOT * NTHR; idx < NPOS * 8; idx += NTHR) {  // oversized halo bricks only
             const int q = idx & 7;
             const int gp = gpos[idx >> 3];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -260,56 +263,56 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_kernel(Conv16Args a) {
                 v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)ch * 128 + q * 16);
             *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;
         }
-        // weights: stage 0 straight to LDS, stage 1 into registers (branch-free, always in registers)
+        // weights: stage 0 straight to LDS, stages 1 and 2 into the two register sets (branch-free, always in registers)
         const char* wbase = a.wp + (long)par * a.wset_stride + (long)ch * slab + (long)n0 * 128;
-        float4 wreg[WLD];
+        float4 wra[WLD], wrb[WLD];
 #pragma unroll
-        for (int u = 0; u < WLD; ++u) wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < WLD; ++u) wra[u] = wrb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define C16_REQUEST_W(WR, stg)                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < WLD; ++u)                                                                  \
+        WR[u] = *reinterpret_cast<const float4*>(wbase + (long)tapw[(stg) * TPS + wtis[u]] * wtap_stride + wsrc[u]);
         if (nst > 0) {
 #pragma unroll
             for (int u = 0; u < WLD; ++u)
                 *reinterpret_cast<float4*>(w_lds + wdst[u]) =
                     *reinterpret_cast<const float4*>(wbase + (long)tapw[wtis[u]] * wtap_stride + wsrc[u]);
         }
-        if (nst > 1) {
-#pragma unroll
-            for (int u = 0; u < WLD; ++u)
-                wreg[u] = *reinterpret_cast<const float4*>(wbase + (long)tapw[TPS + wtis[u]] * wtap_stride + wsrc[u]);
-        }
+        if (nst > 1) { C16_REQUEST_W(wra, 1) }
+        if (nst > 2) { C16_REQUEST_W(wrb, 2) }
         __syncthreads();
         if (nst > 0) C16_LOAD_OPS(o0, tapo[0], w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
-        for (int st = 0; st < nst; ++st) {
-            const char* wb = w_lds + (st & 1) * WBUF;
-            char* wnext = w_lds + ((st + 1) & 1) * WBUF;
-            // park the weights of stage st+1 (requested one stage ago) in the other buffer -- its last readers finished
-            // before the previous barrier -- and request stage st+2 into the same registers
-            if (st + 1 < nst) {
-#pragma unroll
-                for (int u = 0; u < WLD; ++u) *reinterpret_cast<float4*>(wnext + wdst[u]) = wreg[u];
-            }
-            if (st + 2 < nst) {
-#pragma unroll
-                for (int u = 0; u < WLD; ++u)
-                    wreg[u] = *reinterpret_cast<const float4*>(wbase + (long)tapw[(st + 2) * TPS + wtis[u]] * wtap_stride + wsrc[u]);
-            }
-            if (st == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)
-            // 2*TPS k-steps: the operands of k-step q+1 are read from LDS while k-step q's MFMAs run; the stage's single
-            // barrier sits in front of the last k-step and publishes the next stage's weights
-#pragma unroll
-            for (int q = 0; q < 2 * TPS; ++q) {
-                if (q + 1 < 2 * TPS) {
-                    const int tq = (q + 1) >> 1, sq = (q + 1) & 1;
-                    if ((q + 1) & 1) C16_LOAD_OPS(o1, tapo[st * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)
-                    else C16_LOAD_OPS(o0, tapo[st * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)
-                } else {
-                    __syncthreads();
-                    if (st + 1 < nst) C16_LOAD_OPS(o0, tapo[(st + 1) * TPS], wnext, 0)
-                }
-                // (s_setprio around the MFMA block and dropping these scheduling fences were measured: no effect)
-                __builtin_amdgcn_sched_barrier(0);
-                if (q & 1) C16_MFMA(o1) else C16_MFMA(o0)
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        // One pipeline stage = TPS taps.  WR holds the weights of stage st_+1, requested TWO stages ago (an L2/MALL miss on
+        // a slab that every workgroup wants at the same moment costs more than one stage): park them in the other LDS buffer
+        // -- its last readers finished before the previous barrier -- and request stage st_+3 into the same registers.
+        // Then 2*TPS k-steps: the operands of k-step q+1 are read from LDS while k-step q's MFMAs run; the stage's single
+        // barrier sits in front of the last k-step and publishes the next stage's weights.
+        // (s_setprio around the MFMA block and dropping the scheduling fences were measured: no effect.)
+#define C16_STAGE(st_, WR)                                                                                           \
+    {                                                                                                                \
+        const char* wb = w_lds + ((st_) & 1) * WBUF;                                                                 \
+        char* wnext = w_lds + (((st_) + 1) & 1) * WBUF;                                                              \
+        if ((st_) + 1 < nst) {                                                                                       \
+            _Pragma("unroll") for (int u = 0; u < WLD; ++u) *reinterpret_cast<float4*>(wnext + wdst[u]) = WR[u];     \
+        }                                                                                                            \
+        if ((st_) + 3 < nst) { C16_REQUEST_W(WR, (st_) + 3) }                                                        \
+        if ((st_) == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)                                        \
+        _Pragma("unroll") for (int q = 0; q < 2 * TPS; ++q) {                                                        \
+            if (q + 1 < 2 * TPS) {                                                                                   \
+                const int tq = (q + 1) >> 1, sq = (q + 1) & 1;                                                       \
+                if ((q + 1) & 1) C16_LOAD_OPS(o1, tapo[(st_) * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)     \
+                else C16_LOAD_OPS(o0, tapo[(st_) * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)                 \
+            } else {                                                                                                 \
+                __syncthreads();                                                                                     \
+                if ((st_) + 1 < nst) C16_LOAD_OPS(o0, tapo[((st_) + 1) * TPS], wnext, 0)                             \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            if (q & 1) C16_MFMA(o1) else C16_MFMA(o0)                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+    }
+        for (int st = 0; st < nst; st += 2) {
+            C16_STAGE(st, wra)
+            if (st + 1 < nst) C16_STAGE(st + 1, wrb)
         }
     }
 
@@ -444,7 +447,7 @@ static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t 
                                           160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblk, a.tdup ? 2 : 1), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(nblk, a.tdup ? 2 : 1), dim3(64 * WAVES_M * WAVES_N), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -504,6 +507,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
+    // (a 16-wave variant <8,2,1,2,1> -- 4 waves per SIMD, wave tile 32x64, 128 VGPRs -- was measured 5 % slower)
     if (BN == 128) return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
     if (BN == 64) return launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
     return launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);
