@@ -1,5 +1,5 @@
 // Stand-alone benchmark of the split-fp16 conv kernel on one layer shape (default: g_3.conv_0 of the BAIR
-// decoder: [B,16,64,64,256] -> 128).  Build: hipcc -O3 --offload-arch=gfx950 -DI2V_ABLATE -I<csrc> tools/conv16_bench.hip
+// decoder: [B,16,64,64,256] -> 128).  Build: hipcc -O3 --offload-arch=gfx950 -I<csrc> tools/conv16_bench.hip
 //   <csrc>/i2v_conv16.hip <csrc>/i2v_common.hip -o conv16_bench
 #include <cstdio>
 #include <cstdlib>

@@ -12,15 +12,18 @@
 // Operand format "hl16" (HBM and LDS): per position, per group of 8 channels: 8 x fp16 hi (16 B) | 8 x fp16 lo (16 B),
 // i.e. 4 bytes per element like fp32; one ds_read_b128 yields one MFMA operand (lane (i, kg): row i, k = 8 kg + j).
 // Activations are produced in this format by the modulate kernel (the split is done once per element, not per tap);
-// weights are split on the host at load time.
+// weights are split on the host at load time and stored in MFMA-fragment order (see Conv16Weights::pack).
 //
 // Tiling: 512 threads = 8 wavefronts (2 per SIMD) per workgroup, 256 output positions (TB x TT x TH x TW brick) x BN
 // output channels (128/64/32), wave tile up to 64 x 64.  Per 32-channel K chunk the input halo brick is staged once in
 // LDS (rows padded 128 -> 144 B, MFMA rows assigned to 4x4 (h,w) patches: conflict-free ds_read_b128) and reused by all
-// taps; the next chunk's rows are requested from HBM a few taps ahead.  The [BN][32] weight slab of each tap is
-// double-buffered in LDS and requested one full tap ahead.  The tap loop is software-pipelined: the operands of the
-// next k-step (second half of this tap / first half of the next tap) are read from LDS while the current k-step's 12
-// MFMAs per wave run, with ONE barrier per tap placed between the two k-steps (it publishes the next tap's weights).
+// taps; the next chunk's rows are requested from HBM a few taps ahead.
+// The WEIGHT operands never touch LDS: every wave loads the B fragments of its own output columns straight from
+// L2 / the vector L1 into registers (fragment-major packing: one fully coalesced 1 KB load per operand), PFD taps ahead.
+// With the input tile read-only for a whole chunk this leaves NO barrier inside the tap loop -- the eight waves run
+// free and de-phase, so one wave's LDS reads / address arithmetic hide behind its SIMD neighbour's MFMAs.  (The previous
+// design double-buffered each tap's weight slab in LDS behind one barrier per tap: every barrier re-aligned the waves,
+// and their common non-MFMA phases left the matrix pipe 35 % idle -- profiles/r01_e_conv16_pmc.json.)
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -34,12 +37,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int C16_BM = 256, C16_KC = 32;
 constexpr int C16_ROW = 144;  // bytes per staged row: 32 channels x 4 B + 16 B pad
-constexpr int C16_SLOTS = 12; // prefetched 16-byte input pieces per thread and chunk (768 halo rows); larger bricks
-                              // stage the remainder synchronously
+constexpr int C16_SLOTS = 10; // prefetched 16-byte input pieces per thread and chunk (640 halo rows: the 6 x 10 x 10
+                              // halo of a 4 x 8 x 8 brick); larger bricks stage the remainder synchronously
+constexpr int C16_FRAG = 4096; // bytes of one (tap, chunk, 32-column block) of weights: 4 fragments x 64 lanes x 16 B
 
 struct Conv16Args {
     const char* in;   // hl16 channels-last [B][T][H][W][Cin]
-    const char* wp;   // hl16 weights [tap][chunk][CoutPad][128 B]
+    const char* wp;   // hl16 weights [tap][chunk][CoutPad/32][kstep 2][hi|lo][lane 64][8 fp16]
     const float* bias;
     const float* res;
     float* out;       // fp32 channels-last [B][T][H][W][Cout]
@@ -47,7 +51,7 @@ struct Conv16Args {
     int B, T, H, W, Cin, Cout, CoutPad, nchunk;  // T,H,W: geometry of the INPUT tensor
     int tdup;            // 1: temporal-duplication mode -- the output has 2T frames, grid.y = output frame parity
     long wset_stride;    // bytes between the two parity weight sets (tdup)
-    int KT, KH, KW, tap_base, ztap;  // ztap: index of the all-zero weight slab (stage padding)
+    int KT, KH, KW, tap_base;
     int TB, TT, TH, TW, nbB, nbT, nbH, nbW;
     int HWp;   // halo row pitch in positions (>= TW + KW - 1; 12 for 8-wide bricks: conflict-free 4x4 patches)
     int patch; // 1: MFMA rows are assigned to brick positions in 4x4 (h,w) patches per ds_read_b128 lane group
@@ -74,15 +78,22 @@ __device__ __forceinline__ int brick_index(int row, int TH, int TW, int patch) {
     return (plane * TH + py * 4 + (q >> 2)) * TW + px * 4 + (q & 3);
 }
 
-// TPS = taps per pipeline stage: the narrower the channel tile, the more taps share one weight buffer / barrier
-// (BN x TPS = 128 rows per buffer for every variant).
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
+// Position of a pipeline stage (= one tap of one 32-channel chunk) in the (chunk, dt, dh, dw) iteration space.  All fields
+// are workgroup-uniform (scalar registers).
+struct C16Cursor { int ch, si, dt, dh, dw; };
+__device__ __forceinline__ void c16_next(C16Cursor& c, int ntv, int dt_lo, int KH, int KW) {
+    if (++c.si == ntv) { c.si = 0; ++c.ch; c.dt = dt_lo; c.dh = 0; c.dw = 0; }
+    else if (++c.dw == KW) { c.dw = 0; if (++c.dh == KH) { c.dh = 0; ++c.dt; } }
+}
+
+// PFD = how many stages ahead a wave requests its weight fragments (the narrower the wave tile, the shorter a stage).
+template <int WAVES_M, int WAVES_N, int WM, int WN, int PFD>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void conv_mfma_f16x3_kernel(Conv16Args a) {
-    constexpr int NTHR = 64 * WAVES_M * WAVES_N;              // 512 (2 waves per SIMD) or 1024 (4 per SIMD)
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int NSLOT = C16_SLOTS * 512 / NTHR;            // prefetched 16-byte input pieces per thread
     constexpr int C16_BN = 32 * WN * WAVES_N;
-    constexpr int WBUF = TPS * C16_BN * C16_ROW;  // bytes per weight buffer
-    static_assert(32 * WM * WAVES_M == C16_BM && (WAVES_M * WAVES_N == 8 || WAVES_M * WAVES_N == 16), "tile");
+    constexpr int NSET = PFD + 1;                             // register sets of weight fragments (ring)
+    static_assert(32 * WM * WAVES_M == C16_BM && WAVES_M * WAVES_N == 8, "tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,15 +107,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     const int par = a.tdup ? (int)blockIdx.y : 0;
     const int pt = a.tdup ? 1 - par : a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
     const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.HWp;
-    const int NPOS = a.TB * HT * HH * HW;
-    const int ntaps = a.KT * a.KH * a.KW;
+    const int NPOS = a.TB * HT * HH * HW;  // rows of the LDS tile (row pitch HW >= RW: pad columns are never touched)
+    const int RW = a.TW + a.KW - 1;
+    const int NREAL = a.TB * HT * HH * RW;  // halo rows that exist
 
     char* in_lds = smem;
-    char* w_lds = smem + NPOS * C16_ROW;
-    int* rowpos = reinterpret_cast<int*>(w_lds + 2 * WBUF);
+    int* rowpos = reinterpret_cast<int*>(smem + NPOS * C16_ROW);
     int* rowres = rowpos + C16_BM;
-    int* taplist = rowres + C16_BM;  // [0] = padded tap count, [1..32] weight-slab index, [33..64] LDS byte offset of the tap
-    int* gpos = taplist + 72;  // [NPOS] linear input position of every staged halo row, -1 = zero padding
+    int* gpos = rowres + C16_BM;  // [NREAL] linear input position of every staged halo row, -1 = zero padding
+    int* lrow = gpos + NREAL;     // [NREAL] its row in the LDS tile
 
     const int nNt = a.CoutPad / C16_BN;
     const int ntile = blockIdx.x % nNt;
@@ -126,36 +137,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         rowpos[tid] = ok ? ((b * To + to) * a.H + h) * a.W + w : -1;
         rowres[tid] = ok ? ((b * (To / a.rt) + to / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs) + w / a.rs : 0;
     }
-    if (tid == 0) {
-        int cnt = 0;
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KH * a.KW);
-            const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
-            if (hi < 0 || lo >= a.T) continue;  // the whole brick meets zero padding only
-            taplist[1 + cnt] = a.tap_base + tap;
-            taplist[33 + cnt] = ((dt * HH + dh) * HW + dw) * C16_ROW;
-            ++cnt;
-        }
-        while (cnt % TPS) {  // pad the stage with the all-zero weight slab
-            taplist[1 + cnt] = a.ztap;
-            taplist[33 + cnt] = 0;
-            ++cnt;
-        }
-        taplist[0] = cnt;
+    // temporal taps whose whole brick meets zero padding only are skipped: the valid dt form one interval
+    int dt_lo = 0, dt_n = 0;
+    for (int dt = 0; dt < a.KT; ++dt) {
+        const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
+        if (hi < 0 || lo >= a.T) continue;
+        if (dt_n == 0) dt_lo = dt;
+        ++dt_n;
     }
+    const int ntv = dt_n * a.KH * a.KW;  // stages (taps) per chunk
+    const int total = ntv * a.nchunk;
 
-    for (int p0 = tid; p0 < NPOS; p0 += NTHR) {
+    for (int p0 = tid; p0 < NREAL; p0 += NTHR) {
         int p = p0;
-        const int iw = p % HW; p /= HW;
+        const int iw = p % RW; p /= RW;
         const int ih = p % HH; p /= HH;
         const int it = p % HT; p /= HT;
         const int b = b0 + p, t = t0 + it - pt, h = h0 + ih - ph, w = w0 + iw - pw;
-        const bool ok = b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W &&
-                        iw < a.TW + a.KW - 1;
+        const bool ok = b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
         gpos[p0] = ok ? ((b * a.T + t) * a.H + h) * a.W + w : -1;
+        lrow[p0] = ((p * HT + it) * HH + ih) * HW + iw;
     }
 
-    int aoff[WM], boff[WN];
+    int aoff[WM];
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm) {
         int m = brick_index(wave_m * (32 * WM) + 32 * wm + l31, a.TH, a.TW, a.patch);
@@ -164,8 +168,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         const int it = m % a.TT; m /= a.TT;
         aoff[wm] = (((m * HT + it) * HH + ih) * HW + iw) * C16_ROW + kg * 32;
     }
-#pragma unroll
-    for (int wn = 0; wn < WN; ++wn) boff[wn] = (wave_n * (32 * WN) + 32 * wn + l31) * C16_ROW + kg * 32;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -175,143 +177,130 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
-    constexpr int WF4 = TPS * C16_BN * 8;      // 16-byte pieces per stage of weights (TPS slabs)
-    constexpr int WLD = WF4 / NTHR;
-    static_assert(WF4 % NTHR == 0 && WLD >= 1 && WLD <= 2, "weight pieces per thread");
-    const long slab = (long)a.CoutPad * 128;  // bytes per (tap, chunk)
     __syncthreads();
-    const int ntv = taplist[0];
     const long in_row = (long)a.Cin * 4;
 
     // Input staging: all (<= C16_SLOTS) 16-byte pieces of a thread are requested back to back (one exposed memory
     // latency per chunk instead of one per piece) and the NEXT chunk's pieces are requested a few taps before the
-    // current chunk ends, so that latency hides behind MFMA work.
+    // current chunk ends, so that latency hides behind MFMA work.  Branch-free clamped loads: a predicated load would be
+    // followed by an immediate s_waitcnt vmcnt(0).
     const int ngrp = a.Cin >> 3;
-    float4 vin[NSLOT];
+    float4 vin[NSLOT] = {};
 #define C16_REQUEST_INPUT(ch_)                                                                                      \
-    {                                                                                                                \
+    if (!(I2V_ABLATE & 4)) {                                                                                         \
         int gp_[NSLOT];                                                                                              \
-        _Pragma("unroll") for (int u = 0; u < NSLOT; ++u) {                                                          \
-            const int idx = tid + u * NTHR;                                                                          \
-            gp_[u] = gpos[idx < NPOS * 8 ? (idx >> 3) : 0];                                                          \
+        _Pragma("unroll") for (int u_ = 0; u_ < NSLOT; ++u_) {                                                       \
+            const int idx = tid + u_ * NTHR;                                                                         \
+            gp_[u_] = gpos[idx < NREAL * 8 ? (idx >> 3) : 0];                                                        \
         }                                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < NSLOT; ++u) {                                                          \
-            const int idx = tid + u * NTHR;                                                                          \
+        _Pragma("unroll") for (int u_ = 0; u_ < NSLOT; ++u_) {                                                       \
+            const int idx = tid + u_ * NTHR;                                                                         \
             const int q = idx & 7;                                                                                   \
-            const bool ok = idx < NPOS * 8 && gp_[u] >= 0 && (ch_) * 4 + (q >> 1) < ngrp;                            \
-            const long off = ok ? (long)gp_[u] * in_row + (long)(ch_) * 128 + q * 16 : 0;                            \
+            const bool ok = idx < NREAL * 8 && gp_[u_] >= 0 && (ch_) * 4 + (q >> 1) < ngrp;                          \
+            const long off = ok ? (long)gp_[u_] * in_row + (long)(ch_) * 128 + q * 16 : 0;                           \
             const float4 v = *reinterpret_cast<const float4*>(a.in + off);                                           \
-            vin[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+            vin[u_] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
         }                                                                                                            \
     }
-    struct Ops { half8 ah[WM], al[WM], bh[WN], bl[WN]; };
-    Ops o0, o1;
-#define C16_LOAD_OPS(o, aoffs, wbuf, koff)                                                                            \
-    {                                                                                                                \
+    // A operands (activations) of one k-step (16 channels): hi and lo fragment per 32-row tile, from LDS
+    struct AOps { half8 h[WM], l[WM]; };
+    AOps a0 = {}, a1 = {};
+#ifndef I2V_ABLATE
+#define I2V_ABLATE 0  // development builds of tools/conv16_bench: 1 = no LDS operand reads, 2 = no weight loads,
+#endif                //   4 = no input staging, 8 = no MFMAs (results are garbage; timing only)
+#define C16_LOAD_A(o, toff)                                                                                          \
+    if (!(I2V_ABLATE & 1)) {                                                                                         \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
-            const char* p_ = in_lds + aoff[wm] + (aoffs) + (koff);                                                   \
-            (o).ah[wm] = *reinterpret_cast<const half8*>(p_);                                                        \
-            (o).al[wm] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
-        }                                                                                                            \
-        _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) {                                                          \
-            const char* p_ = (wbuf) + boff[wn] + (koff);                                                             \
-            (o).bh[wn] = *reinterpret_cast<const half8*>(p_);                                                        \
-            (o).bl[wn] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
+            const char* p_ = in_lds + aoff[wm] + (toff);                                                             \
+            (o).h[wm] = *reinterpret_cast<const half8*>(p_);                                                         \
+            (o).l[wm] = *reinterpret_cast<const half8*>(p_ + 16);                                                    \
         }                                                                                                            \
     }
+    // B operands (weights) of one stage: [column block][k-step x (hi, lo)], straight from global memory
+    half8 bset[NSET][WN][4] = {};
+    const long slab = (long)(a.CoutPad / 32) * C16_FRAG;  // bytes per (tap, chunk)
+    const char* wlane = a.wp + (long)par * a.wset_stride + (long)(n0 / 32 + wave_n * WN) * C16_FRAG + lane * 16;
+#define C16_LOAD_B(SET, c_)                                                                                          \
+    if (!(I2V_ABLATE & 2)) {                                                                                         \
+        const char* p_ = wlane +                                                                                     \
+            (long)((a.tap_base + ((c_).dt * a.KH + (c_).dh) * a.KW + (c_).dw) * a.nchunk + (c_).ch) * slab;          \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) /* order of use */ \
+            bset[SET][wn][f] = *reinterpret_cast<const half8*>(p_ + wn * C16_FRAG + f * 1024);                       \
+    }
+#define C16_TOFF(c_) ((((c_).dt * HH + (c_).dh) * HW + (c_).dw) * C16_ROW)
     // three terms, tiles interleaved so that consecutive MFMAs never chain on the same accumulator
-#define C16_MFMA(o)                                                                                                  \
-    {                                                                                                                \
+#define C16_MFMA(o, SET, ks)                                                                                         \
+    if (!(I2V_ABLATE & 8)) {                                                                                         \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
-            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).h[wm], bset[SET][wn][2 * (ks)], acc[wm][wn], 0, 0, 0);     \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
-            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bl[wn], acc[wm][wn], 0, 0, 0);      \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).h[wm], bset[SET][wn][2 * (ks) + 1], acc[wm][wn], 0, 0, 0); \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
-            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).l[wm], bset[SET][wn][2 * (ks)], acc[wm][wn], 0, 0, 0);     \
     }
-    C16_REQUEST_INPUT(0)
-    const int nst = ntv / TPS;  // stages per chunk
-    constexpr int PF = TPS >= 4 ? 1 : 4 / TPS;
-    const int pf_stage = nst > PF ? nst - PF : 0;
-    const int* tapw = taplist + 1;
-    const int* tapo = taplist + 33;
-    // per-thread weight piece geometry (constant over the kernel): piece f of a stage = tap f / (BN*8) of the stage,
-    // 16-byte piece f % (BN*8) of that tap's [BN][128 B] slab
-    int wtis[WLD], wsrc[WLD], wdst[WLD];
-#pragma unroll
-    for (int u = 0; u < WLD; ++u) {
-        const int f = tid + u * NTHR;
-        const int tis = f / (C16_BN * 8), fr = f % (C16_BN * 8);
-        wtis[u] = tis;
-        wsrc[u] = fr * 16;
-        wdst[u] = tis * (C16_BN * C16_ROW) + (fr >> 3) * C16_ROW + (fr & 7) * 16;
-    }
-    const long wtap_stride = (long)a.nchunk * slab;
 
-    for (int ch = 0; ch < a.nchunk; ++ch) {
-        __syncthreads();
+    C16Cursor cc{0, 0, dt_lo, 0, 0};  // the stage being computed
+    C16Cursor cb = cc;                // the stage whose weights are requested next
+    C16_REQUEST_INPUT(0)
+    // Every load of the steady state is UNCONDITIONAL (cursors clamp at the last stage instead): the s_waitcnt counters
+    // retire in order, and after a conditional load the compiler has to assume the shortest queue, which turns the wait
+    // for the current operands into a wait for the prefetches just issued.
+    int nreq = 0;  // stages whose weights have been requested
 #pragma unroll
-        for (int u = 0; u < NSLOT; ++u) {
-            const int idx = tid + u * NTHR;
-            if (idx < NPOS * 8) *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + (idx & 7) * 16) = vin[u];
-        }
-        for (int idx = tid + NSLOT * NTHR; idx < NPOS * 8; idx += NTHR) {  // oversized halo bricks only
-            const int q = idx & 7;
-            const int gp = gpos[idx >> 3];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gp >= 0 && ch * 4 + (q >> 1) < ngrp)
-                v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)ch * 128 + q * 16);
-            *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;
-        }
-        // weights: stage 0 straight to LDS, stages 1 and 2 into the two register sets (branch-free, always in registers)
-        const char* wbase = a.wp + (long)par * a.wset_stride + (long)ch * slab + (long)n0 * 128;
-        float4 wra[WLD], wrb[WLD];
-#pragma unroll
-        for (int u = 0; u < WLD; ++u) wra[u] = wrb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#define C16_REQUEST_W(WR, stg)                                                                                       \
-    _Pragma("unroll") for (int u = 0; u < WLD; ++u)                                                                  \
-        WR[u] = *reinterpret_cast<const float4*>(wbase + (long)tapw[(stg) * TPS + wtis[u]] * wtap_stride + wsrc[u]);
-        if (nst > 0) {
-#pragma unroll
-            for (int u = 0; u < WLD; ++u)
-                *reinterpret_cast<float4*>(w_lds + wdst[u]) =
-                    *reinterpret_cast<const float4*>(wbase + (long)tapw[wtis[u]] * wtap_stride + wsrc[u]);
-        }
-        { const int r1_ = nst > 1 ? 1 : 0, r2_ = nst > 2 ? 2 : nst - 1; C16_REQUEST_W(wra, r1_) C16_REQUEST_W(wrb, r2_) }
-        __syncthreads();
-        if (nst > 0) C16_LOAD_OPS(o0, tapo[0], w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
-        // One pipeline stage = TPS taps.  WR holds the weights of stage st_+1, requested TWO stages ago (an L2/MALL miss on
-        // a slab that every workgroup wants at the same moment costs more than one stage): park them in the other LDS buffer
-        // -- its last readers finished before the previous barrier -- and request stage st_+3 into the same registers.
-        // Then 2*TPS k-steps: the operands of k-step q+1 are read from LDS while k-step q's MFMAs run; the stage's single
-        // barrier sits in front of the last k-step and publishes the next stage's weights.
-        // (s_setprio around the MFMA block and dropping the scheduling fences were measured: no effect.)
-#define C16_STAGE(st_, WR)                                                                                           \
-    {                                                                                                                \
-        const char* wb = w_lds + ((st_) & 1) * WBUF;                                                                 \
-        char* wnext = w_lds + (((st_) + 1) & 1) * WBUF;                                                              \
-        /* unconditional (after the last stage: a harmless re-park / re-request of the last slab): the vmcnt queue    \
-           retires in order, and behind a conditional load the compiler must assume the shortest queue */           \
-        _Pragma("unroll") for (int u = 0; u < WLD; ++u) *reinterpret_cast<float4*>(wnext + wdst[u]) = WR[u];         \
-        { const int rq_ = (st_) + 3 < nst ? (st_) + 3 : nst - 1; C16_REQUEST_W(WR, rq_) }                            \
-        if ((st_) == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)                                        \
-        _Pragma("unroll") for (int q = 0; q < 2 * TPS; ++q) {                                                        \
-            if (q + 1 < 2 * TPS) {                                                                                   \
-                const int tq = (q + 1) >> 1, sq = (q + 1) & 1;                                                       \
-                if ((q + 1) & 1) C16_LOAD_OPS(o1, tapo[(st_) * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)     \
-                else C16_LOAD_OPS(o0, tapo[(st_) * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)                 \
-            } else {                                                                                                 \
-                __syncthreads();                                                                                     \
-                if ((st_) + 1 < nst) C16_LOAD_OPS(o0, tapo[((st_) + 1) * TPS], wnext, 0)                             \
-            }                                                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-            if (q & 1) C16_MFMA(o1) else C16_MFMA(o0)                                                                \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-        }                                                                                                            \
+    for (int u = 0; u < PFD; ++u) {
+        C16_LOAD_B(u, cb)
+        if (++nreq < total) c16_next(cb, ntv, dt_lo, a.KH, a.KW);
     }
-        for (int st = 0; st < nst; st += 2) {
-            C16_STAGE(st, wra)
-            if (st + 1 < nst) C16_STAGE(st + 1, wrb)
+    const int pf_stage = ntv > 4 ? ntv - 4 : 0;  // stage of a chunk in which the next chunk's input rows are requested
+
+#define C16_STAGE(u)                                                                                                 \
+    {                                                                                                                \
+        if (cc.si == 0 && !(I2V_ABLATE & 4)) { /* new chunk: replace the input tile (the only barriers of the loop) */ \
+            __syncthreads();                                                                                         \
+            _Pragma("unroll") for (int v = 0; v < NSLOT; ++v) {                                                      \
+                const int idx = tid + v * NTHR;                                                                      \
+                if (idx < NREAL * 8) *reinterpret_cast<float4*>(in_lds + lrow[idx >> 3] * C16_ROW + (idx & 7) * 16) = vin[v]; \
+            }                                                                                                        \
+            for (int idx = tid + NSLOT * NTHR; idx < NREAL * 8; idx += NTHR) { /* oversized halo bricks only */      \
+                const int q = idx & 7;                                                                               \
+                const int gp = gpos[idx >> 3];                                                                       \
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+                if (gp >= 0 && cc.ch * 4 + (q >> 1) < ngrp)                                                          \
+                    v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)cc.ch * 128 + q * 16);     \
+                *reinterpret_cast<float4*>(in_lds + lrow[idx >> 3] * C16_ROW + q * 16) = v;                          \
+            }                                                                                                        \
+            __syncthreads();                                                                                         \
+            C16_LOAD_A(a0, C16_TOFF(cc)) /* first k-step of the chunk: the only exposed LDS read */                  \
+        }                                                                                                            \
+        /* weights of stage s + PFD into the register set that stage s - 1 just released */                         \
+        C16_LOAD_B(((u) + PFD) % NSET, cb)                                                                           \
+        if (++nreq < total) c16_next(cb, ntv, dt_lo, a.KH, a.KW);                                                    \
+        if (cc.si == pf_stage && cc.ch + 1 < a.nchunk) C16_REQUEST_INPUT(cc.ch + 1)                                  \
+        C16_LOAD_A(a1, C16_TOFF(cc) + 64)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        C16_MFMA(a0, u, 0)                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        c16_next(cc, ntv, dt_lo, a.KH, a.KW);                                                                        \
+        /* next tap's first k-step (after the last tap of a chunk this reads a stale row: reloaded after re-staging) */ \
+        C16_LOAD_A(a0, C16_TOFF(cc))                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        C16_MFMA(a1, u, 1)                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+    int s0 = 0;
+    for (; s0 + NSET <= total; s0 += NSET) {
+        C16_STAGE(0)
+        C16_STAGE(1)
+        if constexpr (NSET > 2) C16_STAGE(2)
+        if constexpr (NSET > 3) C16_STAGE(3)
+    }
+    if (s0 < total) {
+        C16_STAGE(0)
+        if (s0 + 1 < total) {
+            C16_STAGE(1)
+            if constexpr (NSET > 3) {
+                if (s0 + 2 < total) C16_STAGE(2)
+            }
         }
     }
 
@@ -357,6 +346,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     }
 }
 
+// Fragment-major weight layout: [tap][chunk][column block of 32][k-step 2][hi | lo][lane = kg*32 + column][8 fp16]:
+// lane (column n, kg) of the wave that owns the column block reads the 8 channels 16*kstep + 8*kg + j of its row as ONE
+// 16-byte piece, and the 64 lanes of a load cover 1 KB contiguously.
+static inline size_t c16_widx(int tap, int chunk, int n, int c_in_chunk, int lo, int nchunk, int cout_pad) {
+    const int nblk = n >> 5, l31 = n & 31, ks = c_in_chunk >> 4, kg = (c_in_chunk >> 3) & 1, j = c_in_chunk & 7;
+    return ((((size_t)tap * nchunk + chunk) * (cout_pad / 32) + nblk) * 4 + (ks * 2 + lo)) * 512 + (kg * 32 + l31) * 8 + j;
+}
+
 int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, int kh, int kw, double scale) {
     Cin = cin; Cout = cout; KT = kt; KH = kh; KW = kw;
     CoutPad = (cout + 31) / 32 * 32;
@@ -373,17 +370,15 @@ int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int
         wexp = std::max(-40, std::min(40, wexp));
     }
     const double pre = std::ldexp(1.0, wexp);
-    std::vector<_Float16> p((size_t)(ntaps + 1) * nchunk * CoutPad * 64, (_Float16)0.f);  // + one all-zero tap
+    std::vector<_Float16> p((size_t)ntaps * nchunk * CoutPad * 64, (_Float16)0.f);
     for (int n = 0; n < cout; ++n)
         for (int c = 0; c < cin; ++c)
             for (int tap = 0; tap < ntaps; ++tap) {
                 const float v = (float)((double)w_src[((size_t)n * cin + c) * ntaps + tap] * scale * pre);
                 const _Float16 hi = (_Float16)v;
                 const _Float16 lo = (_Float16)(v - (float)hi);
-                const int chunk = c / C16_KC, g = (c % C16_KC) / 8, j = c % 8;
-                _Float16* row = &p[(((size_t)tap * nchunk + chunk) * CoutPad + n) * 64];
-                row[g * 16 + j] = hi;
-                row[g * 16 + 8 + j] = lo;
+                p[c16_widx(tap, c / C16_KC, n, c % C16_KC, 0, nchunk, CoutPad)] = hi;
+                p[c16_widx(tap, c / C16_KC, n, c % C16_KC, 1, nchunk, CoutPad)] = lo;
             }
     int rc = w.upload(p.data(), p.size() * 2);
     if (rc) return rc;
@@ -404,7 +399,6 @@ int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
                 dst[9 + hw] = (float)(par == 0 ? w1 + w2v : w2v);
             }
     // both sets share one power-of-two pre-scale: pack them as one [2*cout] tensor, then split the buffer
-    Conv16Weights tmp;
     Cin = cin; Cout = cout; KT = 2; KH = 3; KW = 3; tdup = true;
     CoutPad = (cout + 31) / 32 * 32;
     if (CoutPad > 64 && CoutPad % 128) CoutPad = (CoutPad + 127) / 128 * 128;
@@ -415,7 +409,7 @@ int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
     wexp = 0;
     if (wmax > 0.0 && std::isfinite(wmax)) wexp = std::max(-40, std::min(40, (int)std::floor(std::log2(16384.0 / wmax))));
     const double pre = std::ldexp(1.0, wexp);
-    const size_t set_halfs = (size_t)(ntaps + 1) * nchunk * CoutPad * 64;
+    const size_t set_halfs = (size_t)ntaps * nchunk * CoutPad * 64;
     std::vector<_Float16> p(2 * set_halfs, (_Float16)0.f);
     for (int par = 0; par < 2; ++par)
         for (int n = 0; n < cout; ++n)
@@ -424,10 +418,8 @@ int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
                     const float v = (float)((double)w2[(((size_t)par * cout + n) * cin + c) * 18 + tap] * scale * pre);
                     const _Float16 hi = (_Float16)v;
                     const _Float16 lo = (_Float16)(v - (float)hi);
-                    const int chunk = c / C16_KC, g = (c % C16_KC) / 8, j = c % 8;
-                    _Float16* row = &p[par * set_halfs + (((size_t)tap * nchunk + chunk) * CoutPad + n) * 64];
-                    row[g * 16 + j] = hi;
-                    row[g * 16 + 8 + j] = lo;
+                    p[par * set_halfs + c16_widx(tap, c / C16_KC, n, c % C16_KC, 0, nchunk, CoutPad)] = hi;
+                    p[par * set_halfs + c16_widx(tap, c / C16_KC, n, c % C16_KC, 1, nchunk, CoutPad)] = lo;
                 }
     set_bytes = (long)set_halfs * 2;
     int rc = w.upload(p.data(), p.size() * 2);
@@ -437,9 +429,9 @@ int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
     return I2V_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int PFD>
 static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
-    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS>;
+    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, PFD>;
     static bool attr_set = false;
     if (!attr_set) {
         I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -464,7 +456,6 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     a.in = static_cast<const char*>(in_hl16); a.wp = wts.w.as<char>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
     a.B = B; a.T = T; a.H = H; a.W = W; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
     a.KT = wts.KT; a.KH = wts.KH; a.KW = wts.KW; a.tap_base = 0;
-    a.ztap = wts.KT * wts.KH * wts.KW;
     a.tdup = wts.tdup ? 1 : 0;
     a.wset_stride = wts.set_bytes;
     if (wts.tdup) {  // T is the OUTPUT frame count; the (half-rate) input has T / 2 frames
@@ -497,19 +488,20 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
         int hp = a.HWp;
         while (hp % 16 != 4 && hp % 16 != 12) ++hp;
         const size_t rows = (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * hp;
-        const size_t need = rows * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + rows * 4;
+        const size_t need = rows * C16_ROW + 2 * C16_BM * 4 + rows * 8;
         if (need <= 160 * 1024) a.HWp = hp;
     }
     const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * a.HWp;
     const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
-    const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + (size_t)npos * 4;
+    const size_t lds = (size_t)npos * C16_ROW + 2 * C16_BM * 4 + (size_t)npos * 8;  // (tables sized for npos >= NREAL rows)
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
-    // (a 16-wave variant <8,2,1,2,1> -- 4 waves per SIMD, wave tile 32x64, 128 VGPRs -- was measured 5 % slower)
+    // weight prefetch distance: one 64x64-tile stage is 24 MFMAs (768 cycles) per wave, narrower tiles need more stages
+    // (a 16-wave variant -- 4 waves per SIMD, wave tile 32x64, 128 VGPRs -- of the LDS-weights design was 5 % slower)
     if (BN == 128) return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
     if (BN == 64) return launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
-    return launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);
+    return launch16<8, 1, 1, 1, 3>(a, (unsigned)nblk, lds, st);
 }
 
 }  // namespace i2v
