@@ -166,6 +166,18 @@ def main():
                 "inv_latency_us": cinn["inv_us"], "fwd_latency_us": cinn["fwd_us"], "batch": nb,
             },
         }
+        if gen.mma == 1 and result["roofline"]:
+            # the data-sheet peak assumes 2.4 GHz; with live operands the matrix cores sustain less (power management).
+            # An MFMA-only loop of the conv kernel's shape, measured here on this box, gives the sustained rate.
+            sustained = i2v_native.probe_mfma_f16(dev)
+            r = result["roofline"]
+            r["sustained_mfma"] = {
+                "what": "MFMA-only loop (12 v_mfma_f32_32x32x16_f16 per k-step on 4 accumulators, 2 waves/SIMD, live "
+                        "pseudo-random register operands, no memory traffic), measured on this GPU after the timed steps",
+                "peak_live_operands": sustained, "unit": "TFLOP/s (fp16 MFMA FLOPs executed)",
+                "frac_of_data_sheet_peak": sustained / PEAK_F16_MFMA_TFLOPS,
+                "conv_kernel_issue_frac_of_sustained": r["mfma_issue_frac"] * PEAK_F16_MFMA_TFLOPS / sustained,
+            }
         result["embedder"] = embedder_latency(cfg, x0_d)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, fsd, dsd)

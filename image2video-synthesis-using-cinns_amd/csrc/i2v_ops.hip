@@ -71,6 +71,47 @@ struct i2v_mlp {
     std::vector<DevBuf> W, b;  // depth + 2 layers, torch layout [out][in]
 };
 
+// ---- measurement helper: sustained rate of the fp16 matrix cores with LIVE operands --------------------------------
+// bench.py prices the split-fp16 conv kernel against MI355X_MICROARCH.md's dense peak (2.5 PFLOP/s at 2.4 GHz).  That
+// clock is not sustained once the operands toggle (power management): this loop -- the conv kernel's MFMA skeleton, 12
+// v_mfma_f32_32x32x16_f16 per k-step on 4 accumulators, 2 waves per SIMD, pseudo-random register operands, no memory
+// traffic at all -- measures what the chip sustains, so the report can state both fractions.
+typedef _Float16 probe_half8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(512, 2) void mfma_probe_kernel(float* out, int iters) {
+    const unsigned tid = threadIdx.x + blockIdx.x * 512u;
+    probe_half8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned ha = (tid * 2654435761u + (unsigned)(i * 8 + j) * 40503u) >> 7;
+            const unsigned hb = (tid * 2246822519u + (unsigned)(i * 8 + j) * 3266489917u) >> 9;
+            // hi-like operands O(1), lo-like operands O(2^-11): the magnitudes the split-fp16 path feeds
+            a[i][j] = (_Float16)(((float)(ha & 2047) * (1.f / 1024.f) - 1.f) * ((i & 1) ? 4.8e-4f : 1.f));
+            b[i][j] = (_Float16)(((float)(hb & 2047) * (1.f / 1024.f) - 1.f) * ((i & 1) ? 4.8e-4f : 1.f));
+        }
+    probe_f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + t) & 3], b[(i + 2 * t + 1) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[tid] = s;
+}
+
 extern "C" {
 
 int i2v_mlp_create(int32_t dim, int32_t hidden_dim, int32_t depth, int32_t out_dim, i2v_mlp** out) {
@@ -166,6 +207,15 @@ int i2v_actnorm_logdet(const float* scale, int32_t channels, float hw, float* ou
     hipLaunchKernelGGL(actnorm_logdet_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), scale, channels, hw, out,
                        batch);
     I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+int i2v_probe_mfma_f16(int32_t workgroups, int32_t iters, float* scratch, double* flops, void* stream) {
+    I2V_REQUIRE(workgroups > 0 && iters > 0 && scratch && flops, I2V_E_INVALID, "i2v_probe_mfma_f16: bad argument");
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3((unsigned)workgroups), dim3(512), 0, static_cast<hipStream_t>(stream), scratch,
+                       iters);
+    I2V_HIP_CHECK(hipGetLastError());
+    *flops = (double)workgroups * 8.0 * (double)iters * 12.0 * (2.0 * 32 * 32 * 16);
     return I2V_OK;
 }
 

@@ -65,6 +65,7 @@ SYMBOLS = {
                                  c_float, c_void_p]),
     "i2v_row_mean_std": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "i2v_actnorm_logdet": (c_int32, [c_void_p, c_int32, c_float, c_void_p, c_int32, c_void_p]),
+    "i2v_probe_mfma_f16": (c_int32, [c_int32, c_int32, c_void_p, POINTER(c_double), c_void_p]),
     "i2v_gblock_create": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "i2v_gblock_destroy": (None, [c_void_p]),
     "i2v_gblock_load": (c_int32, [c_void_p, POINTER(_Tensor), c_int32]),
@@ -349,6 +350,27 @@ def actnorm_logdet(scale, hw, batch):
     _check(lib().i2v_actnorm_logdet(scale.data_ptr(), scale.numel(), float(hw), out.data_ptr(), batch, _stream()),
            "i2v_actnorm_logdet")
     return out
+
+
+def probe_mfma_f16(device, workgroups=2048, iters=4096, reps=3):
+    """Sustained fp16 matrix-core rate with live operands (TFLOP/s of v_mfma_f32_32x32x16_f16 actually executed by an
+    MFMA-only loop of the conv kernel's shape; measurement helper for bench.py).  Median of ``reps`` event-timed launches
+    after one warm-up launch of the same length (so the clock has settled)."""
+    scratch = torch.empty(workgroups * 512, dtype=torch.float32, device=device)
+    flops = c_double()
+    rates = []
+    with torch.cuda.device(scratch.device):
+        for r in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _check(lib().i2v_probe_mfma_f16(workgroups, iters, scratch.data_ptr(), ctypes.byref(flops), _stream()),
+                   "i2v_probe_mfma_f16")
+            e1.record()
+            e1.synchronize()
+            if r:
+                rates.append(flops.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    rates.sort()
+    return rates[len(rates) // 2]
 
 
 def inv_lrelu(x, alpha, reverse):

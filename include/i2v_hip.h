@@ -114,6 +114,14 @@ int i2v_row_mean_std(const float* x, int32_t rows, int32_t n, float* mean, float
 /* out[b] = hw * sum_c log|scale[c]| for b < batch (ActNorm log-det, modules.py:86-88). */
 int i2v_actnorm_logdet(const float* scale, int32_t channels, float hw, float* out, int32_t batch, void* stream);
 
+/* Measurement helper (no reference counterpart; used by bench.py only): enqueues an MFMA-only loop -- `workgroups` x 512
+ * threads, `iters` k-steps of 12 v_mfma_f32_32x32x16_f16 per wavefront on live pseudo-random register operands, no
+ * memory traffic -- and returns the fp16 MFMA FLOPs it executes in *flops.  Timed by the caller with events on `stream`,
+ * it gives the matrix-core rate the chip SUSTAINS under power management, next to the data-sheet peak.
+ * scratch: device buffer of workgroups * 512 floats. */
+int i2v_probe_mfma_f16(int32_t workgroups, int32_t iters, float* scratch, double* flops, void* stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * Stage-1 decoder: Generator (stage1_VAE/modules/decoder.py:55-120)
  * ---------------------------------------------------------------------------------------- */

@@ -205,6 +205,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     // A operands (activations) of one k-step (16 channels): hi and lo fragment per 32-row tile, from LDS
     struct AOps { half8 h[WM], l[WM]; };
     AOps a0 = {}, a1 = {};
+#ifdef I2V_ABLATE_NONZERO  // ablation with live (pseudo-random, lane-dependent) operands instead of zeros: MFMA power
+#define C16_RND(i_) ((_Float16)((float)((((unsigned)tid * 2654435761u + (unsigned)(i_) * 40503u) >> 7) & 2047) * (1.f / 1024.f) - 1.f))
+    _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int j = 0; j < 8; ++j) {
+        a0.h[wm][j] = C16_RND(wm * 8 + j); a0.l[wm][j] = C16_RND(100 + wm * 8 + j) * (_Float16)4.8e-4f;
+        a1.h[wm][j] = C16_RND(200 + wm * 8 + j); a1.l[wm][j] = C16_RND(300 + wm * 8 + j) * (_Float16)4.8e-4f;
+    }
+#endif
 #ifndef I2V_ABLATE
 #define I2V_ABLATE 0  // development builds of tools/conv16_bench: 1 = no LDS operand reads, 2 = no weight loads,
 #endif                //   4 = no input staging, 8 = no MFMAs (results are garbage; timing only)
@@ -218,6 +225,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     }
     // B operands (weights) of one stage: [column block][k-step x (hi, lo)], straight from global memory
     half8 bset[NSET][WN][4] = {};
+#ifdef I2V_ABLATE_NONZERO
+    _Pragma("unroll") for (int e = 0; e < NSET; ++e) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)
+        _Pragma("unroll") for (int f = 0; f < 4; ++f) _Pragma("unroll") for (int j = 0; j < 8; ++j)
+            bset[e][wn][f][j] = C16_RND(1000 + ((e * WN + wn) * 4 + f) * 8 + j) * (_Float16)((f & 1) ? 0.01f : 20.f);
+#endif
     const long slab = (long)(a.CoutPad / 32) * C16_FRAG;  // bytes per (tap, chunk)
     const char* wlane = a.wp + (long)par * a.wset_stride + (long)(n0 / 32 + wave_n * WN) * C16_FRAG + lane * 16;
 #define C16_LOAD_B(SET, c_)                                                                                          \
