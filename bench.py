@@ -225,12 +225,12 @@ def roofline(prof, dt, mma, default_workload=False):
         kernel = "conv_mfma_f32_kernel (3x3x3 Conv3d implicit GEMM, v_mfma_f32_32x32x2_f32)"
         peak = PEAK_FP32_MFMA_TFLOPS
     # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
-    # rocprofv3 --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/r01_c_pmc_hbm_traffic.json).
+    # rocprofv3 --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/r01_h_pmc_hbm_traffic.json).
     # bench.py cannot read PMCs itself: the figure is valid for the default workload (bair64, batch 64, mma = 1) only.
     traffic = None
     if mma == 1 and default_workload:
         try:
-            with open(os.path.join(REPO, "profiles", "r01_c_pmc_hbm_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r01_h_pmc_hbm_traffic.json")) as f:
                 traffic = json.load(f)["dominant_kernel"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None

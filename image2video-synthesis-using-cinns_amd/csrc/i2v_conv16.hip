@@ -45,7 +45,7 @@ struct Conv16Args {
     float* out;       // fp32 channels-last [B][T][H][W][Cout]
     double* stats;    // optional [B][Cout][2]: per-(sample, channel) sum / sum of squares of the stored values (TB == 1)
     int B, T, H, W, Cin, Cout, CoutPad, nchunk;  // T,H,W: geometry of the INPUT tensor
-    int tdup;            // 1: temporal-duplication mode -- the output has 2T frames, grid.y = output frame parity
+    int tdup;            // 1: temporal-duplication mode -- the output has 2T frames, two tiles (frame parities) per brick
     long wset_stride;    // bytes between the two parity weight sets (tdup)
     int KT, KH, KW, tap_base, ztap;  // ztap: index of the all-zero weight slab (stage padding)
     int TB, TT, TH, TW, nbB, nbT, nbH, nbW;
@@ -93,7 +93,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     // Temporal-duplication mode (conv_0 behind a x2 nearest up-sampling in time): the virtual input satisfies
     // a[2i] == a[2i+1], so even output frames see (a[i-1], a[i], a[i]) and odd ones (a[i], a[i], a[i+1]): a 2-tap
     // temporal kernel on the HALF-rate tensor with pre-summed weights (W0, W1+W2) resp. (W0+W1, W2).
-    const int par = a.tdup ? (int)blockIdx.y : 0;
+    // Tile order and the XCDs.  Workgroup b runs on XCD b % 8, each XCD with its own L2.  Bricks are numbered w-fastest
+    // (8 bricks per row at 64 x 64), so the plain order gives XCD x the bricks of ONE w-column: its 32 concurrent
+    // workgroups cover all h-rows and t-slabs of that column and share their h- and t-halos in L2 (measured: 1.8x the
+    // algorithmic input bytes; giving each XCD a contiguous tile range instead shares w/h but not t and reads MORE, and
+    // it makes every XCD stream all N-tiles' weights instead of a quarter of them).  Only the two frame parities of a
+    // temporal-duplication brick -- same input, different weights -- need placing: consecutive slots of the same XCD.
+    const unsigned nb_ = gridDim.x;  // tiles (x 2 parities in tdup mode)
+    const bool pair_ = a.tdup && (nb_ & 15) == 0;
+    const int par = !a.tdup ? 0 : pair_ ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x >= (nb_ >> 1));
+    const int tile_id = !a.tdup ? (int)blockIdx.x
+                        : pair_ ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)(blockIdx.x % (nb_ >> 1));
     const int pt = a.tdup ? 1 - par : a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
     const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.HWp;
     const int NPOS = a.TB * HT * HH * HW;
@@ -107,8 +117,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     int* gpos = taplist + 72;  // [NPOS] linear input position of every staged halo row, -1 = zero padding
 
     const int nNt = a.CoutPad / C16_BN;
-    const int ntile = blockIdx.x % nNt;
-    int brick = blockIdx.x / nNt;
+    const int ntile = tile_id % nNt;
+    int brick = tile_id / nNt;
     const int bw = brick % a.nbW; brick /= a.nbW;
     const int bh = brick % a.nbH; brick /= a.nbH;
     const int bt = brick % a.nbT; brick /= a.nbT;
@@ -446,7 +456,7 @@ static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t 
                                           160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblk, a.tdup ? 2 : 1), dim3(64 * WAVES_M * WAVES_N), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(64 * WAVES_M * WAVES_N), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -505,7 +515,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + (size_t)npos * 4;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
-    I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
+    I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
     // (a 16-wave variant <8,2,1,2,1> -- 4 waves per SIMD, wave tile 32x64, 128 VGPRs -- was measured 5 % slower)
     if (BN == 128) return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
     if (BN == 64) return launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
