@@ -110,11 +110,86 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
     __syncthreads();
     const int ntv = taplist[0];
 
+    // Input staging is software-pipelined over the K chunks: the first NSLOT 16-byte pieces of a thread (all of them for
+    // 1x1x1 convs and for the usual 3x3x3 bricks) and the first tap's weight slab of chunk ch+1 are REQUESTED while chunk
+    // ch is being multiplied and written to LDS at the next chunk boundary, so a chunk no longer starts with an exposed
+    // HBM round trip (it used to: the 1x1(x1) convs -- the decoder's learned shortcuts, two thirds of the ResNet-50
+    // embedder -- spent most of their time there).  Piece geometry is decoded once, not per chunk.  All loads are
+    // unconditional with clamped addresses (a conditional load forces the compiler to wait for it at once).
+    constexpr int NSLOT = 6;
+    const int q4 = (tid & 3) * 4;  // channel offset of this thread's pieces inside a chunk (256 % 4 == 0)
+    long sl_off[NSLOT]; // element offset of (row, channel 0) in the input tensor, -1: padding / not a piece
+    int sl_cb[2];       // coef path: b * CinAct of the first two pieces (1x1x1 bricks have <= 2 per thread)
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) {
+        const int idx = tid + u * 256;
+        int p = idx >> 2;
+        const int iw = p % HW; p /= HW;
+        const int ih = p % HH; p /= HH;
+        const int it = p % HT; p /= HT;
+        const int b = b0 + p, t = t0 * sT + it - pt, h = h0 * sS + ih - ph, w = w0 * sS + iw - pw;
+        const bool ok = idx < NPOS * 4 && b < a.B && (unsigned)t < (unsigned)Tin && (unsigned)h < (unsigned)Hin &&
+                        (unsigned)w < (unsigned)Win;
+        sl_off[u] = ok ? ((((long)b * Tin + t) * Hin + h) * Win + w) * a.CinAct : -1;
+        if (u < 2) sl_cb[u] = ok ? b * a.CinAct : 0;
+    }
+    float4 pin[NSLOT], pc00, pc01, pc10, pc11, pwr0, pwr1;  // (named, not arrays: arrays defined under a branch go to scratch)
+    static_assert(WLD <= 2, "weight pieces per thread");
+#define CONV_REQUEST(chn_)                                                                                           \
+    {                                                                                                                \
+        const int c_ = (chn_) * CONV_KC + q4;                                                                        \
+        const bool cok_ = c_ < a.CinAct;                                                                             \
+        _Pragma("unroll") for (int u = 0; u < NSLOT; ++u) {                                                          \
+            const bool ok_ = sl_off[u] >= 0 && cok_;                                                                 \
+            const float4 v_ = *reinterpret_cast<const float4*>(a.in + (ok_ ? sl_off[u] + c_ : 0));                  \
+            pin[u] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+        }                                                                                                            \
+        {   /* coefficient pairs of the first two pieces (a.coef == null: re-reads the input base, unused) */        \
+            const float* cf_ = a.coef ? a.coef : a.in;                                                               \
+            const long o0_ = (a.coef && sl_off[0] >= 0 && cok_) ? ((long)sl_cb[0] + c_) * 2 : 0;                     \
+            const long o1_ = (a.coef && sl_off[1] >= 0 && cok_) ? ((long)sl_cb[1] + c_) * 2 : 0;                     \
+            pc00 = *reinterpret_cast<const float4*>(cf_ + o0_);                                                      \
+            pc01 = *reinterpret_cast<const float4*>(cf_ + o0_ + 4);                                                  \
+            pc10 = *reinterpret_cast<const float4*>(cf_ + o1_);                                                      \
+            pc11 = *reinterpret_cast<const float4*>(cf_ + o1_ + 4);                                                  \
+        }                                                                                                            \
+        const float* wsrc_ = a.wp + ((long)taplist[1] * a.nchunk + (chn_)) * slab + (long)n0 * CONV_KC;              \
+        pwr0 = *reinterpret_cast<const float4*>(wsrc_ + (tid < WF4 ? tid : 0) * 4);                                  \
+        pwr1 = *reinterpret_cast<const float4*>(wsrc_ + (WLD > 1 ? tid + 256 : 0) * 4);                              \
+    }
+    pwr0 = pwr1 = pc00 = pc01 = pc10 = pc11 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) pin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ntv > 0) CONV_REQUEST(0)  // (taplist[1] is only defined when a tap survives)
+
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();
-        // ---- stage the input halo brick for channels [16 ch, 16 ch + 16)
+        // ---- the input halo brick for channels [16 ch, 16 ch + 16): prefetched pieces, then the rest synchronously
         const int c0 = ch * CONV_KC;
-        for (int idx = tid; idx < NPOS * 4; idx += 256) {
+        if (ntv > 0) {
+#pragma unroll
+            for (int u = 0; u < NSLOT; ++u) {
+                const int idx = tid + u * 256;
+                float4 v = pin[u];
+                if (a.coef && sl_off[u] >= 0 && c0 + q4 < a.CinAct) {
+                    // normalisation folded into the load: norm(x)*g + beta == x*A + B per (sample, channel)
+                    float4 ab0, ab1;
+                    if (u == 0) { ab0 = pc00; ab1 = pc01; }
+                    else if (u == 1) { ab0 = pc10; ab1 = pc11; }
+                    else {
+                        const int b = (int)(sl_off[u] / ((long)a.CinAct * Win * Hin * Tin));
+                        ab0 = *reinterpret_cast<const float4*>(a.coef + ((long)b * a.CinAct + c0 + q4) * 2);
+                        ab1 = *reinterpret_cast<const float4*>(a.coef + ((long)b * a.CinAct + c0 + q4) * 2 + 4);
+                    }
+                    v.x = fmaf(v.x, ab0.x, ab0.y); v.y = fmaf(v.y, ab0.z, ab0.w);
+                    v.z = fmaf(v.z, ab1.x, ab1.y); v.w = fmaf(v.w, ab1.z, ab1.w);
+                }
+                if (idx < NPOS * 4) *reinterpret_cast<float4*>(in_lds + (idx >> 2) * LS + q4) = v;
+            }
+            if (tid < WF4) *reinterpret_cast<float4*>(w_lds + (tid >> 2) * LS + 4 * (tid & 3)) = pwr0;
+            if (WLD > 1) *reinterpret_cast<float4*>(w_lds + ((tid + 256) >> 2) * LS + 4 * (tid & 3)) = pwr1;
+        }
+        for (int idx = tid + NSLOT * 256; idx < NPOS * 4; idx += 256) {  // bricks with a large halo only
             const int q = idx & 3;
             int p = idx >> 2;
             const int iw = p % HW; p /= HW;
@@ -126,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
             if (b < a.B && (unsigned)t < (unsigned)Tin && (unsigned)h < (unsigned)Hin && (unsigned)w < (unsigned)Win &&
                 c < a.CinAct) {
                 v = *reinterpret_cast<const float4*>(a.in + ((((long)b * Tin + t) * Hin + h) * Win + w) * a.CinAct + c);
-                if (a.coef) {  // normalisation folded into the load: norm(x)*g + beta == x*A + B per (sample, channel)
+                if (a.coef) {
                     const float4 ab0 = *reinterpret_cast<const float4*>(a.coef + ((long)b * a.CinAct + c) * 2);
                     const float4 ab1 = *reinterpret_cast<const float4*>(a.coef + ((long)b * a.CinAct + c) * 2 + 4);
                     v.x = fmaf(v.x, ab0.x, ab0.y); v.y = fmaf(v.y, ab0.z, ab0.w);
@@ -135,52 +210,54 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
             }
             *reinterpret_cast<float4*>(in_lds + (idx >> 2) * LS + 4 * q) = v;
         }
-        if (ntv > 0) {
-            const float* src = a.wp + ((long)taplist[1] * a.nchunk + ch) * slab + (long)n0 * CONV_KC;
-#pragma unroll
-            for (int u = 0; u < WLD; ++u) {
-                const int f = tid + u * 256;
-                if (f < WF4) *reinterpret_cast<float4*>(w_lds + (f >> 2) * LS + 4 * (f & 3)) =
-                    *reinterpret_cast<const float4*>(src + f * 4);
-            }
-        }
+        if (ntv > 0) { const int chn = ch + 1 < a.nchunk ? ch + 1 : ch; CONV_REQUEST(chn) }
         __syncthreads();
+        // one tap of one chunk: 2 groups x 4 k-slots, one ds_read_b128 per operand feeds four MFMAs
+#define CONV_TAP(tapoff_, wb_)                                                                                       \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                  \
+        float4 av[WM], bv[WN];                                                                                       \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
+            av[wm] = *reinterpret_cast<const float4*>(in_lds + aoff[wm] + (tapoff_) + 8 * g);                        \
+        _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)                                                            \
+            bv[wn] = *reinterpret_cast<const float4*>((wb_) + boff[wn] + 8 * g);                                     \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                              \
+            _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                      \
+                const float as = s == 0 ? av[wm].x : s == 1 ? av[wm].y : s == 2 ? av[wm].z : av[wm].w;               \
+                _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) {                                                  \
+                    const float bs = s == 0 ? bv[wn].x : s == 1 ? bv[wn].y : s == 2 ? bv[wn].z : bv[wn].w;           \
+                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs, acc[wm][wn], 0, 0, 0);                \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+        if (ntv == 1) {
+            // 1x1(x1) convs and single surviving taps: the slab is already in buffer 0 and nothing follows it -- no tap
+            // prefetch, no trailing barrier (the next chunk's leading barrier orders the LDS reuse); the next chunk's
+            // requests issued above overlap these MFMAs
+            const int tap = taplist[1];
+            const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KW * a.KH);
+            CONV_TAP(((dt * HH + dh) * HW + dw) * LS, w_lds)
+            continue;
+        }
         for (int ti = 0; ti < ntv; ++ti) {
             const int tap = taplist[1 + ti];
+            // next tap's weight slab: requested before this tap's MFMAs, parked in the other LDS buffer after them
+            // (unconditional -- after the last tap the slab is simply re-read -- so that it stays in registers)
             float4 wreg[WLD];
-            const bool more = ti + 1 < ntv;
-            if (more) {
-                const float* src = a.wp + ((long)taplist[2 + ti] * a.nchunk + ch) * slab + (long)n0 * CONV_KC;
+            {
+                const int tnext = ti + 1 < ntv ? taplist[2 + ti] : tap;
+                const float* src = a.wp + ((long)tnext * a.nchunk + ch) * slab + (long)n0 * CONV_KC;
 #pragma unroll
                 for (int u = 0; u < WLD; ++u) {
                     const int f = tid + u * 256;
-                    if (f < WF4) wreg[u] = *reinterpret_cast<const float4*>(src + f * 4);
+                    wreg[u] = *reinterpret_cast<const float4*>(src + (f < WF4 ? f : 0) * 4);
                 }
             }
             const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KW * a.KH);
             const int tapoff = ((dt * HH + dh) * HW + dw) * LS;
             const float* wb = w_lds + (ti & 1) * (BN * LS);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                float4 av[WM], bv[WN];
-#pragma unroll
-                for (int wm = 0; wm < WM; ++wm) av[wm] = *reinterpret_cast<const float4*>(in_lds + aoff[wm] + tapoff + 8 * g);
-#pragma unroll
-                for (int wn = 0; wn < WN; ++wn) bv[wn] = *reinterpret_cast<const float4*>(wb + boff[wn] + 8 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                    for (int wm = 0; wm < WM; ++wm) {
-                        const float as = s == 0 ? av[wm].x : s == 1 ? av[wm].y : s == 2 ? av[wm].z : av[wm].w;
-#pragma unroll
-                        for (int wn = 0; wn < WN; ++wn) {
-                            const float bs = s == 0 ? bv[wn].x : s == 1 ? bv[wn].y : s == 2 ? bv[wn].z : bv[wn].w;
-                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs, acc[wm][wn], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            if (more) {
+            CONV_TAP(tapoff, wb)
+            {
                 float* wd = w_lds + ((ti + 1) & 1) * (BN * LS);
 #pragma unroll
                 for (int u = 0; u < WLD; ++u) {
@@ -296,7 +373,14 @@ int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* ou
     I2V_REQUIRE(TB * TT * TH * TW == CONV_BM && T % TT == 0 && H % TH == 0 && W % TW == 0, I2V_E_INVALID,
                 "conv: cannot tile [T=%d,H=%d,W=%d] into bricks of %d positions (dims must be powers of two)", T, H, W,
                 CONV_BM);
-    const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
+    // channel tile: the widest that divides CoutPad -- unless that leaves most of the 256 CUs without a workgroup (small
+    // feature maps x many channels: the ResNet embedder's and the encoder's late stages, the first decoder levels), where
+    // a narrower tile trades re-staged input for 2-4x more workgroups
+    int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
+    {
+        const long bricks = (long)((B + TB - 1) / TB) * (T / TT) * (H / TH) * (W / TW);
+        while (BN > 32 && bricks * (a.CoutPad / BN) < 512) BN /= 2;
+    }
     const int pos1 = ((TT - 1) * stride_t + a.KT) * ((TH - 1) * stride + a.KH) * ((TW - 1) * stride + a.KW);  // halo rows per sample
     auto lds_of = [&](int tb) {
         return ((size_t)tb * pos1 * CONV_LDS_STRIDE + 2 * (size_t)BN * CONV_LDS_STRIDE) * 4 + (2 * CONV_BM + 160) * 4;

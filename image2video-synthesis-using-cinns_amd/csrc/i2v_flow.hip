@@ -136,14 +136,20 @@ struct i2v_flow {
     std::vector<float> an_logdet;
     std::vector<int> step_cond;  // 1: first layer sees only the embedding (mode 'cond')
     size_t param_bytes = 0;
-    // graph cache
+    // graph cache: one instantiated chain per direction (motion transfer alternates forward and inverse passes)
     hipStream_t cap_stream = nullptr;
-    hipGraphExec_t gexec = nullptr;
-    int g_reverse = -1, g_B = -1;
-    void* g_ws = nullptr;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    int g_B[2] = {-1, -1};
+    void* g_ws[2] = {nullptr, nullptr};
+    void drop_graphs() {
+        for (auto& g : gexec) {
+            if (g) (void)hipGraphExecDestroy(g);
+            g = nullptr;
+        }
+    }
 
     ~i2v_flow() {
-        if (gexec) (void)hipGraphExecDestroy(gexec);
+        drop_graphs();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
     }
 };
@@ -311,8 +317,9 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
         I2V_HIP_CHECK(hipGetLastError());
     }
     if (f->cfg.use_graph) {
-        if (!(f->gexec && f->g_reverse == (int)reverse && f->g_B == B && f->g_ws == workspace)) {
-            if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
+        const int d = reverse ? 1 : 0;
+        if (!(f->gexec[d] && f->g_B[d] == B && f->g_ws[d] == workspace)) {
+            if (f->gexec[d]) { (void)hipGraphExecDestroy(f->gexec[d]); f->gexec[d] = nullptr; }
             if (!f->cap_stream) I2V_HIP_CHECK(hipStreamCreateWithFlags(&f->cap_stream, hipStreamNonBlocking));
             hipGraph_t graph = nullptr;
             I2V_HIP_CHECK(hipStreamBeginCapture(f->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -320,14 +327,13 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
             hipError_t e = hipStreamEndCapture(f->cap_stream, &graph);
             if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             I2V_HIP_CHECK(e);
-            e = hipGraphInstantiate(&f->gexec, graph, nullptr, nullptr, 0);
+            e = hipGraphInstantiate(&f->gexec[d], graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             I2V_HIP_CHECK(e);
-            f->g_reverse = reverse;
-            f->g_B = B;
-            f->g_ws = workspace;
+            f->g_B[d] = B;
+            f->g_ws[d] = workspace;
         }
-        I2V_HIP_CHECK(hipGraphLaunch(f->gexec, st));
+        I2V_HIP_CHECK(hipGraphLaunch(f->gexec[d], st));
     } else {
         int rc = enqueue_chain(f, reverse, ws, B, st);
         if (rc) return rc;
@@ -458,7 +464,7 @@ int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
     if ((rc = f->shuf_b.upload(sb.data(), sb.size() * 4))) return rc;
     f->param_bytes = pbytes;
     f->loaded = true;
-    if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
+    f->drop_graphs();
     return I2V_OK;
 }
 
