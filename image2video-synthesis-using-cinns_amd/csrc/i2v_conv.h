@@ -50,6 +50,12 @@ int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* ou
                  int B, int T, int H, int W, int epi, hipStream_t st, const float* coef = nullptr, int stride = 1,
                  int stride_t = 1);
 
+// ---- 1x1(x1) convs / Linear layers as a plain pipelined GEMM (i2v_pointwise.hip); conv_forward dispatches to it
+bool pointwise_supported(const ConvWeights& wts, const float* res, int rt, int rs, int epi, int stride, int stride_t);
+// M = rows (B*T*H*W), P = positions per sample (row / P selects the coef row)
+int pointwise_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, long M, long P,
+                      int epi, hipStream_t st, const float* coef);
+
 // ---- split-fp16 path (i2v_conv16.hip): operands carried as (fp16 hi, fp16 lo = x - hi) pairs, 3 fp16 MFMAs per product
 struct Conv16Weights {
     DevBuf w;      // [tap][chunk32][CoutPad][4 groups x (8 hi | 8 lo) fp16] = 128 B per (n, chunk)

@@ -18,6 +18,8 @@
 //   * taps that can only see zero padding for the whole brick (T == 1 layers) are skipped;
 //   * epilogue: + bias, + residual read through the nearest-upsample index map (decoder.py:102-114 folded into
 //     the index math), optional leaky_relu(0.2), or tanh + [B][T][3][H][W] store for conv_img.
+#include <cstdlib>
+
 #include "i2v_conv.h"
 
 namespace i2v {
@@ -352,6 +354,8 @@ int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* ou
                 "conv: the on-load affine is only valid without padding (1x1x1 kernels)");
     I2V_REQUIRE(stride == 1 || stride == 2, I2V_E_INVALID, "conv: stride %d", stride);
     I2V_REQUIRE(wts.KT * wts.KH * wts.KW <= 150, I2V_E_INVALID, "conv: kernel too large");
+    if (pointwise_supported(wts, res, rt, rs, epi, stride, stride_t) && !getenv("I2V_NO_POINTWISE"))
+        return pointwise_forward(wts, in, cin_act, out, res, (long)B * T * H * W, (long)T * H * W, epi, st, coef);
     ConvArgs a{};
     a.coef = coef;
     a.sS = stride;
