@@ -45,16 +45,26 @@ struct TailArgs {
     float an_logdet;       // sum log|scale| of that ActNorm (forward only)
     int do_lrelu;
     int do_swap;
+    // first layer of the NEXT half-step, fused in (its K = 32 inputs are the state channels this launch just produced):
+    // h0[n][b] = lrelu_0.01(pre[n][b] + sum_k W0x[n][k] * x[b][k])
+    int l1;            // 0: none, 1: K = 32, 2: K = 0 (mode 'cond': the first layer sees only the embedding)
+    int N2;            // rows of that layer (2H <= 64 * TAIL_WAVES)
+    const float* W0x;  // [N2][32] state part of the first layer's weights
+    const float* pre;  // [B][pre_stride] embedding part + bias (transposed pre-GEMM output), offset to this half-step's rows
+    long pre_stride;
+    float* h0;         // [N2][Bp]
 };
 
 constexpr int TAIL_WAVES = 16;
 
 __global__ __launch_bounds__(64 * TAIL_WAVES) void flow_tail_kernel(TailArgs a) {
     __shared__ float part[TAIL_WAVES][64];
+    __shared__ __attribute__((aligned(16))) float xs[64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
-    // everything wave 0 needs later is requested before the reduction so the latencies overlap
+    // everything needed later is requested before the reduction so the latencies overlap: wave 0's state / per-channel
+    // parameters, and every thread's row of the next first layer
     float x = 0.f, b3 = 0.f, anl = 0.f, ans = 1.f;
     int sidx = lane;
     if (w == 0) {
@@ -62,6 +72,18 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void flow_tail_kernel(TailArgs a) 
         if (a.h) b3 = a.b3[lane];
         if (a.an_loc) { anl = a.an_loc[lane]; ans = a.an_scale[lane]; }
         if (a.shuf) sidx = a.shuf[lane];
+    }
+    const int n1 = threadIdx.x;
+    const bool l1 = a.l1 != 0 && n1 < a.N2;
+    float4 w0[8];
+    float pre = 0.f;
+    {
+        // W0x is stored [q = k / 4][n][4]: for a fixed q the 64 lanes of a wave read 1 KB contiguously
+        const float* wr = a.W0x + (l1 && a.l1 == 1 ? (long)n1 * 4 : 0);  // (clamped: unconditional loads stay in registers)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            w0[q] = a.l1 ? *reinterpret_cast<const float4*>(wr + (long)q * a.N2 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l1) pre = a.pre[(long)b * a.pre_stride + n1];
     }
     if (a.h) {
         // last Linear: lane = (net, c); the waves split K = H, all of a wave's loads are in flight together
@@ -82,35 +104,72 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void flow_tail_kernel(TailArgs a) 
         part[w][lane] = acc;
     }
     __syncthreads();
-    if (w != 0) return;
-    if (a.h) {
-        float st = b3;
+    if (w == 0) {
+        if (a.h) {
+            float st = b3;
 #pragma unroll
-        for (int q = 0; q < TAIL_WAVES; ++q) st += part[q][lane];
-        // lanes 0..31 hold s[c], lanes 32..63 hold t[c]; the transformed half is x[32..63]
-        const float s = __shfl(st, lane & 31);
-        if (lane >= 32) x = a.reverse ? (x - st) * expf(-s) : fmaf(x, expf(s), st);
-        if (a.logdet && !a.reverse) {
-            float r = lane < 32 ? st : 0.f;  // log-det of the coupling: sum over the 32 channels of s
+            for (int q = 0; q < TAIL_WAVES; ++q) st += part[q][lane];
+            // lanes 0..31 hold s[c], lanes 32..63 hold t[c]; the transformed half is x[32..63]
+            const float s = __shfl(st, lane & 31);
+            if (lane >= 32) x = a.reverse ? (x - st) * expf(-s) : fmaf(x, expf(s), st);
+            if (a.logdet && !a.reverse) {
+                float r = lane < 32 ? st : 0.f;  // log-det of the coupling: sum over the 32 channels of s
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off);
-            if (lane == 0) a.logdet[b] += r;
+                for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off);
+                if (lane == 0) a.logdet[b] += r;
+            }
         }
-    }
-    if (!a.reverse) {
-        if (a.shuf) x = __shfl(x, sidx);                    // Shuffle.forward: x[:, idx]
-        if (a.an_loc) {                                     // ActNorm.forward: scale * (x + loc)
-            x = ans * (x + anl);
-            if (a.logdet && lane == 0) a.logdet[b] += a.an_logdet;
+        if (!a.reverse) {
+            if (a.shuf) x = __shfl(x, sidx);                    // Shuffle.forward: x[:, idx]
+            if (a.an_loc) {                                     // ActNorm.forward: scale * (x + loc)
+                x = ans * (x + anl);
+                if (a.logdet && lane == 0) a.logdet[b] += a.an_logdet;
+            }
+            if (a.do_lrelu) x = x * (x >= 0.f ? 1.0f : 0.9f);   // InvLeakyRelu.forward (log-det reported as 0, quirk Q2)
+        } else {
+            if (a.do_lrelu) x = x / (x >= 0.f ? 1.0f : 0.9f);   // InvLeakyRelu.reverse
+            if (a.an_loc) x = x / ans - anl;                    // ActNorm.reverse
+            if (a.shuf) x = __shfl(x, sidx);                    // Shuffle.reverse: x[:, argsort(idx)]
         }
-        if (a.do_lrelu) x = x * (x >= 0.f ? 1.0f : 0.9f);   // InvLeakyRelu.forward (log-det reported as 0, quirk Q2)
-    } else {
-        if (a.do_lrelu) x = x / (x >= 0.f ? 1.0f : 0.9f);   // InvLeakyRelu.reverse
-        if (a.an_loc) x = x / ans - anl;                    // ActNorm.reverse
-        if (a.shuf) x = __shfl(x, sidx);                    // Shuffle.reverse: x[:, argsort(idx)]
+        if (a.do_swap) x = __shfl(x, lane ^ 32);                // chunk / cat[::-1], flow_blocks.py:86,99
+        a.x[(long)b * 64 + lane] = x;
+        xs[lane] = x;
     }
-    if (a.do_swap) x = __shfl(x, lane ^ 32);                // chunk / cat[::-1], flow_blocks.py:86,99
-    a.x[(long)b * 64 + lane] = x;
+    if (!a.l1) return;  // (uniform)
+    __syncthreads();
+    if (l1) {
+        // next half-step's first Linear (modules.py:17: nn.LeakyReLU() slope 0.01): thread = output row, K = the 32 state
+        // channels just written (broadcast LDS reads); one launch of the chain saved per half-step
+        float acc = pre;
+        if (a.l1 == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 xv = *reinterpret_cast<const float4*>(&xs[4 * q]);
+                acc = fmaf(w0[q].x, xv.x, acc); acc = fmaf(w0[q].y, xv.y, acc);
+                acc = fmaf(w0[q].z, xv.z, acc); acc = fmaf(w0[q].w, xv.w, acc);
+            }
+        }
+        a.h0[(long)n1 * a.Bp + b] = acc >= 0.f ? acc : 0.01f * acc;
+    }
+}
+
+// pre-GEMM output [R][B] -> [B][R] (R = all first-layer rows of the pass), so that the sample-per-workgroup tail kernel reads
+// its column as contiguous rows; 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void flow_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int B) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, b = b0 + tx;
+        tile[ty + 8 * j][tx] = (r < R && b < B) ? in[(long)r * B + b] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = b0 + ty + 8 * j, r = r0 + tx;
+        if (r < R && b < B) out[(long)b * R + r] = tile[tx][ty + 8 * j];
+    }
 }
 
 // ingest / egress between caller tensors and the workspace-resident state (a hipMemcpyAsync costs ~12 us each here)
@@ -132,7 +191,7 @@ struct i2v_flow {
     bool loaded = false;
     int S = 0;      // half-steps = 2 * n_flows
     int H = 0, E = 0, ld0 = 0, depth = 0;
-    DevBuf W0, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;
+    DevBuf W0, W0x, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;  // W0x: [S][8][2H][4] state part of W0
     std::vector<float> an_logdet;
     std::vector<int> step_cond;  // 1: first layer sees only the embedding (mode 'cond')
     size_t param_bytes = 0;
@@ -157,7 +216,7 @@ struct i2v_flow {
 namespace {
 
 struct WsLayout {
-    size_t x, embed, logdet, pre, hA, hB, total;
+    size_t x, embed, logdet, pre, preT, hA, hB, total;
 };
 
 WsLayout ws_layout(const i2v_flow* f, int B) {
@@ -168,6 +227,7 @@ WsLayout ws_layout(const i2v_flow* f, int B) {
     L.embed = take((size_t)B * f->E * 4);
     L.logdet = take((size_t)B * 4);
     L.pre = take((size_t)f->S * 2 * f->H * B * 4);
+    L.preT = take((size_t)f->S * 2 * f->H * B * 4);
     const size_t Bp = (size_t)(B + 63) / 64 * 64;  // hidden activations are [2H][Bp]
     L.hA = take((size_t)2 * f->H * Bp * 4);
     L.hB = take((size_t)2 * f->H * Bp * 4);
@@ -182,6 +242,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
     const float* embed = reinterpret_cast<const float*>(ws + L.embed);
     float* logdet = reinterpret_cast<float*>(ws + L.logdet);
     float* pre = reinterpret_cast<float*>(ws + L.pre);
+    float* preT = reinterpret_cast<float*>(ws + L.preT);
     float* hA = reinterpret_cast<float*>(ws + L.hA);
     float* hB = reinterpret_cast<float*>(ws + L.hB);
     const int H = f->H, N2 = 2 * f->H, S = f->S;
@@ -209,9 +270,20 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         a.slope = 1.0f;
         int rc = launch_linear<8, 8>(a, st);
         if (rc) return rc;
+        hipLaunchKernelGGL(flow_transpose_kernel, dim3((S * N2 + 31) / 32, (B + 31) / 32), dim3(256), 0, st, pre, preT, S * N2, B);
+        I2V_HIP_CHECK(hipGetLastError());
     }
-    auto tail = [&](const float* h, int step, int shuf_block, int an_block, bool lrelu, bool swap) -> int {
+    // next_step: half-step whose first layer is evaluated at the end of this launch (-1: none)
+    auto tail = [&](const float* h, int step, int shuf_block, int an_block, bool lrelu, bool swap, int next_step) -> int {
         TailArgs t{};
+        if (next_step >= 0) {
+            t.l1 = f->step_cond[next_step] ? 2 : 1;
+            t.N2 = N2;
+            t.W0x = f->W0x.as<float>() + (size_t)next_step * N2 * 32;
+            t.pre = preT + (size_t)next_step * N2;
+            t.pre_stride = (long)S * N2;
+            t.h0 = hA;  // (may alias h: a workgroup only touches column b of either, reads before it writes)
+        }
         t.h = h;
         t.W3T = h ? f->W3T.as<float>() + (size_t)step * H * 64 : nullptr;
         t.b3 = h ? f->b3.as<float>() + (size_t)step * 64 : nullptr;
@@ -234,8 +306,13 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
     const int nf = f->cfg.n_flows;
     // ops in front of the first half-step
     int rc;
-    if (!reverse) rc = tail(nullptr, 0, -1, an ? 0 : -1, act, false);
-    else rc = tail(nullptr, 0, sh ? nf - 1 : -1, -1, false, false);
+    auto step_of = [&](int it) {  // forward visits (fl, i) = (0,0),(0,1),(1,0)...; reverse visits (nf-1,1),(nf-1,0),(nf-2,1)...
+        const int fl = reverse ? nf - 1 - it / 2 : it / 2;
+        const int i = reverse ? 1 - it % 2 : it % 2;
+        return fl * 2 + i;
+    };
+    if (!reverse) rc = tail(nullptr, 0, -1, an ? 0 : -1, act, false, step_of(0));
+    else rc = tail(nullptr, 0, sh ? nf - 1 : -1, -1, false, false, step_of(0));
     if (rc) return rc;
 
     for (int it = 0; it < S; ++it) {
@@ -243,25 +320,8 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         const int fl = reverse ? nf - 1 - it / 2 : it / 2;
         const int i = reverse ? 1 - it % 2 : it % 2;
         const int step = fl * 2 + i;
-        // layer 0: K = 32 state channels (+ the precomputed embedding part as a per-(n,b) bias)
-        LinArgs a{};
-        a.W = f->W0.as<float>() + (size_t)step * N2 * f->ld0;
-        a.ldw = f->ld0;
-        a.K = f->step_cond[step] ? 0 : 32;
-        a.in = x;
-        a.in_sk = 1;
-        a.in_sb = 64;
-        a.in_group_stride = 0;
-        a.group_rows = N2;
-        a.bias_vec = nullptr;
-        a.bias_mat = pre + (size_t)step * N2 * B;
-        a.out = hA;
-        a.out_sn = Bp;
-        a.out_sb = 1;
-        a.N = N2;
-        a.B = B;
-        a.slope = 0.01f;  // nn.LeakyReLU() default, modules.py:17
-        if ((rc = launch_linear<4, 8>(a, st))) return rc;
+        // layer 0 (K = 32 state channels + the precomputed embedding part as a per-(n,b) bias) was evaluated into hA by the
+        // previous launch of the chain (flow_tail_kernel)
         float* cur = hA;
         float* nxt = hB;
         for (int d = 0; d < f->depth; ++d) {
@@ -297,7 +357,7 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
                 if (fl - 1 >= 0 && sh) shuf_block = fl - 1;
             }
         }
-        if ((rc = tail(cur, step, shuf_block, an_block, lrelu, swap))) return rc;
+        if ((rc = tail(cur, step, shuf_block, an_block, lrelu, swap, it + 1 < S ? step_of(it + 1) : -1))) return rc;
     }
     return I2V_OK;
 }
@@ -451,8 +511,14 @@ int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
             }
         }
     }
+    std::vector<float> W0x((size_t)S * N2 * 32);
+    for (int st = 0; st < S; ++st)
+        for (int n = 0; n < N2; ++n)
+            for (int k = 0; k < 32; ++k)
+                W0x[(((size_t)st * 8 + k / 4) * N2 + n) * 4 + k % 4] = W0[((size_t)st * N2 + n) * ld0 + k];
     int rc;
     if ((rc = f->W0.upload(W0.data(), W0.size() * 4))) return rc;
+    if ((rc = f->W0x.upload(W0x.data(), W0x.size() * 4))) return rc;
     if ((rc = f->b0.upload(b0.data(), b0.size() * 4))) return rc;
     if ((rc = f->Wmid.upload(Wmid.data(), Wmid.size() * 4))) return rc;
     if ((rc = f->bmid.upload(bmid.data(), bmid.size() * 4))) return rc;
