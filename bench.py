@@ -159,7 +159,7 @@ def main():
                        "global_batch": total, "frames_per_step": frames_per_step, "parallelism": f"batch-shard x{world}"},
             "roofline": roofline(prof, dt, gen.mma, args.config == "bair64" and per_gpu == 64 and args.vid_length == 16),
             "roofline_cinn": {
-                "kernel": "cINN inverse pass (flow_linear_kernel + flow_tail_kernel chain)",
+                "kernel": "cINN inverse pass (flow_pre_kernel, then the flow_hidden_kernel / flow_tail_kernel chain)",
                 "bound": "hbm", "bytes_per_pass": cinn_bytes,
                 "achieved": cinn_bytes / (cinn["inv_us"] * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": cinn_bytes / (cinn["inv_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS,

@@ -153,22 +153,55 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void flow_tail_kernel(TailArgs a) 
     }
 }
 
-// pre-GEMM output [R][B] -> [B][R] (R = all first-layer rows of the pass), so that the sample-per-workgroup tail kernel reads
-// its column as contiguous rows; 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void flow_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int B) {
-    __shared__ float tile[32][33];
-    const int r0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+// Embedding part of ALL first layers of a pass, off the dependent chain: preT[b][r] = b0[r] + sum_k W0[r][32 + k] * embed[b][k]
+// for the R = S * 2H rows, written sample-major so that the sample-per-workgroup tail kernel reads its rows contiguously.
+// lane = row: a wavefront keeps 64 weight rows in registers (W0e is stored [r / 64][k / 4][r % 64][4]: every load of a
+// wave is 1 KB contiguous) and sweeps the samples, whose embeddings are broadcast from LDS; stores are coalesced.
+constexpr int PRE_EMAX = 128;  // embedding_dim <= 128 (64 BAIR, 128 others, 94 endpoint control)
+constexpr int PRE_SC = 16;     // samples per workgroup (blockIdx.y): enough waves to fill the chip at B = 64
+__global__ __launch_bounds__(256) void flow_pre_kernel(const float* __restrict__ W0e, const float* __restrict__ b0,
+                                                       const float* __restrict__ embed, float* __restrict__ preT, int R, int E,
+                                                       int Epad, int B) {
+    __shared__ __attribute__((aligned(16))) float es[PRE_SC * PRE_EMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int blk = blockIdx.x * 4 + w;  // 64-row block of this wave
+    const int r = blk * 64 + lane;
+    const bool rok = r < R;
+    const int nq = Epad >> 2;
+    const int bb = blockIdx.y * PRE_SC, nb = min(PRE_SC, B - bb);
+    float4 wv[PRE_EMAX / 4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = r0 + ty + 8 * j, b = b0 + tx;
-        tile[ty + 8 * j][tx] = (r < R && b < B) ? in[(long)r * B + b] : 0.f;
+    for (int q = 0; q < PRE_EMAX / 4; ++q)
+        wv[q] = (q < nq && blk * 64 < R) ? *reinterpret_cast<const float4*>(W0e + (((long)blk * nq + q) * 64 + lane) * 4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bias = rok ? b0[r] : 0.f;
+    for (int i = threadIdx.x; i < PRE_SC * Epad; i += 256) {
+        const int b = i / Epad, k = i - b * Epad;
+        es[i] = (b < nb && k < E) ? embed[(long)(bb + b) * E + k] : 0.f;
     }
     __syncthreads();
+    for (int b = 0; b < PRE_SC; b += 4) {  // four samples at a time: independent accumulation chains
+        float a0 = bias, a1 = bias, a2 = bias, a3 = bias;
+        const float* e0 = &es[b * Epad];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = b0 + ty + 8 * j, r = r0 + tx;
-        if (r < R && b < B) out[(long)b * R + r] = tile[tx][ty + 8 * j];
+        for (int q = 0; q < PRE_EMAX / 4; ++q) {
+            if (q < nq) {  // uniform
+                const float4 x0 = *reinterpret_cast<const float4*>(e0 + 4 * q);
+                const float4 x1 = *reinterpret_cast<const float4*>(e0 + Epad + 4 * q);
+                const float4 x2 = *reinterpret_cast<const float4*>(e0 + 2 * Epad + 4 * q);
+                const float4 x3 = *reinterpret_cast<const float4*>(e0 + 3 * Epad + 4 * q);
+                a0 = fmaf(wv[q].x, x0.x, a0); a1 = fmaf(wv[q].x, x1.x, a1); a2 = fmaf(wv[q].x, x2.x, a2); a3 = fmaf(wv[q].x, x3.x, a3);
+                a0 = fmaf(wv[q].y, x0.y, a0); a1 = fmaf(wv[q].y, x1.y, a1); a2 = fmaf(wv[q].y, x2.y, a2); a3 = fmaf(wv[q].y, x3.y, a3);
+                a0 = fmaf(wv[q].z, x0.z, a0); a1 = fmaf(wv[q].z, x1.z, a1); a2 = fmaf(wv[q].z, x2.z, a2); a3 = fmaf(wv[q].z, x3.z, a3);
+                a0 = fmaf(wv[q].w, x0.w, a0); a1 = fmaf(wv[q].w, x1.w, a1); a2 = fmaf(wv[q].w, x2.w, a2); a3 = fmaf(wv[q].w, x3.w, a3);
+            }
+        }
+        if (rok) {
+            if (b + 0 < nb) preT[(long)(bb + b + 0) * R + r] = a0;
+            if (b + 1 < nb) preT[(long)(bb + b + 1) * R + r] = a1;
+            if (b + 2 < nb) preT[(long)(bb + b + 2) * R + r] = a2;
+            if (b + 3 < nb) preT[(long)(bb + b + 3) * R + r] = a3;
+        }
     }
 }
 
@@ -191,7 +224,7 @@ struct i2v_flow {
     bool loaded = false;
     int S = 0;      // half-steps = 2 * n_flows
     int H = 0, E = 0, ld0 = 0, depth = 0;
-    DevBuf W0, W0x, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;  // W0x: [S][8][2H][4] state part of W0
+    DevBuf W0, W0x, W0e, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;  // W0x: [S][8][2H][4] state part of W0
     std::vector<float> an_logdet;
     std::vector<int> step_cond;  // 1: first layer sees only the embedding (mode 'cond')
     size_t param_bytes = 0;
@@ -216,7 +249,7 @@ struct i2v_flow {
 namespace {
 
 struct WsLayout {
-    size_t x, embed, logdet, pre, preT, hA, hB, total;
+    size_t x, embed, logdet, preT, hA, hB, total;
 };
 
 WsLayout ws_layout(const i2v_flow* f, int B) {
@@ -226,7 +259,6 @@ WsLayout ws_layout(const i2v_flow* f, int B) {
     L.x = take((size_t)B * 64 * 4);
     L.embed = take((size_t)B * f->E * 4);
     L.logdet = take((size_t)B * 4);
-    L.pre = take((size_t)f->S * 2 * f->H * B * 4);
     L.preT = take((size_t)f->S * 2 * f->H * B * 4);
     const size_t Bp = (size_t)(B + 63) / 64 * 64;  // hidden activations are [2H][Bp]
     L.hA = take((size_t)2 * f->H * Bp * 4);
@@ -241,7 +273,6 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
     float* x = reinterpret_cast<float*>(ws + L.x);
     const float* embed = reinterpret_cast<const float*>(ws + L.embed);
     float* logdet = reinterpret_cast<float*>(ws + L.logdet);
-    float* pre = reinterpret_cast<float*>(ws + L.pre);
     float* preT = reinterpret_cast<float*>(ws + L.preT);
     float* hA = reinterpret_cast<float*>(ws + L.hA);
     float* hB = reinterpret_cast<float*>(ws + L.hB);
@@ -250,27 +281,10 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
     const bool act = f->cfg.activation != 0, an = !f->cfg.skip_actnorm, sh = !f->cfg.skip_shuffle;
 
     if (!reverse) I2V_HIP_CHECK(hipMemsetAsync(logdet, 0, (size_t)B * 4, st));
-    {   // embedding part of every first layer, all half-steps at once: pre[s][n][b] = b0 + W0[:, 32:] . embed
-        LinArgs a{};
-        a.W = f->W0.as<float>() + 32;
-        a.ldw = f->ld0;
-        a.K = f->E;
-        a.in = embed;
-        a.in_sk = 1;
-        a.in_sb = f->E;
-        a.in_group_stride = 0;
-        a.group_rows = S * N2;
-        a.bias_vec = f->b0.as<float>();
-        a.bias_mat = nullptr;
-        a.out = pre;
-        a.out_sn = B;
-        a.out_sb = 1;
-        a.N = S * N2;
-        a.B = B;
-        a.slope = 1.0f;
-        int rc = launch_linear<8, 8>(a, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(flow_transpose_kernel, dim3((S * N2 + 31) / 32, (B + 31) / 32), dim3(256), 0, st, pre, preT, S * N2, B);
+    {   // embedding part of every first layer, all half-steps at once: preT[b][s][n] = b0 + W0[:, 32:] . embed
+        const int R = S * N2, Epad = (f->E + 3) / 4 * 4;
+        hipLaunchKernelGGL(flow_pre_kernel, dim3((R + 255) / 256, (B + PRE_SC - 1) / PRE_SC), dim3(256), 0, st, f->W0e.as<float>(), f->b0.as<float>(), embed,
+                           preT, R, f->E, Epad, B);
         I2V_HIP_CHECK(hipGetLastError());
     }
     // next_step: half-step whose first layer is evaluated at the end of this launch (-1: none)
@@ -418,7 +432,7 @@ int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out) {
                 "i2v_flow_create: in_channels must be 64 (lane <-> channel mapping), got %d", cfg->in_channels);
     I2V_REQUIRE(cfg->hidden_dim >= 64 && cfg->hidden_dim % 64 == 0 && cfg->hidden_dim <= LIN_MAXK, I2V_E_INVALID,
                 "i2v_flow_create: hidden_dim must be a multiple of 64 in [64, %d], got %d", LIN_MAXK, cfg->hidden_dim);
-    I2V_REQUIRE(cfg->embedding_dim > 0 && cfg->embedding_dim <= LIN_MAXK && cfg->hidden_depth >= 0 && cfg->n_flows > 0, I2V_E_INVALID,
+    I2V_REQUIRE(cfg->embedding_dim > 0 && cfg->embedding_dim <= PRE_EMAX && cfg->hidden_depth >= 0 && cfg->n_flows > 0, I2V_E_INVALID,
                 "i2v_flow_create: bad embedding_dim/hidden_depth/n_flows");
     int ndev = 0;
     I2V_HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -516,9 +530,16 @@ int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
         for (int n = 0; n < N2; ++n)
             for (int k = 0; k < 32; ++k)
                 W0x[(((size_t)st * 8 + k / 4) * N2 + n) * 4 + k % 4] = W0[((size_t)st * N2 + n) * ld0 + k];
+    // embedding part of W0 for flow_pre_kernel: [r / 64][k / 4][r % 64][4], k zero-padded to a multiple of 4
+    const int Epad = (E + 3) / 4 * 4;
+    const size_t R = (size_t)S * N2, Rblk = (R + 63) / 64;
+    std::vector<float> W0e(Rblk * Epad * 64, 0.f);
+    for (size_t r = 0; r < R; ++r)
+        for (int k = 0; k < E; ++k) W0e[(((r / 64) * (Epad / 4) + k / 4) * 64 + r % 64) * 4 + k % 4] = W0[r * ld0 + 32 + k];
     int rc;
     if ((rc = f->W0.upload(W0.data(), W0.size() * 4))) return rc;
     if ((rc = f->W0x.upload(W0x.data(), W0x.size() * 4))) return rc;
+    if ((rc = f->W0e.upload(W0e.data(), W0e.size() * 4))) return rc;
     if ((rc = f->b0.upload(b0.data(), b0.size() * 4))) return rc;
     if ((rc = f->Wmid.upload(Wmid.data(), Wmid.size() * 4))) return rc;
     if ((rc = f->bmid.upload(bmid.data(), bmid.size() * 4))) return rc;
