@@ -13,14 +13,18 @@
 //                the s- and t-net of a half-step are stored back to back so one launch covers both.
 //   W3T          [H][64]      last layer transposed: lane == (net, channel), coalesced
 //
-// Kernels
-//   flow_linear_kernel : out[n][b] = act(bias + sum_k W[n][k] * in[k][b]); N split over workgroups, K over the
-//                        waves of a workgroup (LDS reduce).  Used for the embedding pre-GEMM of all 80 first
-//                        layers (one launch, off the dependent chain), and for layers 0..2 of every half-step.
+//   W0x / W0e    state part [S][8][2H][4] and embedding part [R/64][E/4][64][4] of the first layers: every wave load 1 KB
+//
+// Kernels (121 launches per pass, replayed from one hipGraph per direction)
+//   flow_pre_kernel    : embedding part of all 80 first layers at once, off the dependent chain, sample-major output
+//   flow_hidden_kernel : (i2v_linear.h) hidden Linear + LeakyReLU, s- and t-net in one launch; rows split over
+//                        workgroups, K over the waves of a workgroup (LDS reduce), float4 = 4 samples per lane
 //   flow_tail_kernel   : one workgroup per sample: last Linear (H -> 32, s and t), affine coupling
 //                        x*exp(s)+t / (x-t)*exp(-s) (flow_blocks.py:91,103), log-det = sum_c s by a wavefront
 //                        shuffle reduction (:93), then the elementwise ops between two half-steps (Shuffle gather
-//                        as a lane permute :152-154, ActNorm modules.py:80/100, InvLeakyRelu :180-187, half swap).
+//                        as a lane permute :152-154, ActNorm modules.py:80/100, InvLeakyRelu :180-187, half swap),
+//                        then the NEXT half-step's first Linear (K = the 32 state channels just produced).
+//   (flow_linear_kernel in i2v_linear.h serves the stand-alone MLP / Linear entry points.)
 #include "i2v_common.h"
 #include "i2v_linear.h"
 
