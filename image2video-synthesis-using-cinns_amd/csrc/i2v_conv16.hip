@@ -331,7 +331,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         const int n = n0 + wave_n * (32 * WN) + 32 * wn + l31;
         const bool ncol = n < a.Cout;
         const float bias = (a.bias && ncol) ? a.bias[n] : 0.f;
-        float ssum = 0.f, ssq = 0.f;
+        // per-lane partial statistics in fp64: the totals must not depend on how many rows a wave tile holds, or a shard
+        // of the batch (which may pick a narrower tile) would not reproduce the full batch bit for bit
+        double ssum = 0.0, ssq = 0.0;
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
 #pragma unroll
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                 if (p < 0 || !ncol) continue;
                 float v = fmaf(acc[wm][wn][r], a.oscale, bias);
                 if (a.res) v += a.res[(long)rowres[m] * a.Cout + n];
-                ssum += v;
-                ssq = fmaf(v, v, ssq);
+                ssum += (double)v;
+                ssq = fma((double)v, (double)v, ssq);
                 if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
                 if (a.epi & EPI_FRAMES) {
                     const int bt_ = p / HWo, hw = p - bt_ * HWo;
@@ -360,8 +362,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
             ssq += __shfl_xor(ssq, 32);
             if (kg == 0 && ncol) {
                 double* dst = a.stats + ((long)b0 * a.Cout + n) * 2;
-                atomicAdd(dst, (double)ssum);
-                atomicAdd(dst + 1, (double)ssq);
+                atomicAdd(dst, ssum);
+                atomicAdd(dst + 1, ssq);
             }
         }
     }
@@ -511,7 +513,13 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
         if (need <= 160 * 1024) a.HWp = hp;
     }
     const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * a.HWp;
-    const int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
+    // channel tile: the widest that divides CoutPad, narrowed while the launch would leave most CUs without a workgroup
+    // (head_0: 64 samples x 4 x 4 positions = 4 bricks x 8 tiles of 128 channels, each streaming 9 x 1024 channels of K)
+    int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
+    {
+        const long bricks = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.tdup ? 2 : 1);
+        while (BN > 32 && bricks * (a.CoutPad / BN) < 256) BN /= 2;
+    }
     const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + (size_t)npos * 4;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
