@@ -354,7 +354,7 @@ int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* ou
                 "conv: the on-load affine is only valid without padding (1x1x1 kernels)");
     I2V_REQUIRE(stride == 1 || stride == 2, I2V_E_INVALID, "conv: stride %d", stride);
     I2V_REQUIRE(wts.KT * wts.KH * wts.KW <= 150, I2V_E_INVALID, "conv: kernel too large");
-    if (pointwise_supported(wts, res, rt, rs, epi, stride, stride_t) && !getenv("I2V_NO_POINTWISE"))
+    if (pointwise_supported(wts, res, rt, rs, epi, stride, stride_t))
         return pointwise_forward(wts, in, cin_act, out, res, (long)B * T * H * W, (long)T * H * W, epi, st, coef);
     ConvArgs a{};
     a.coef = coef;
