@@ -1,0 +1,861 @@
+// 3x3x3 Conv3d (and the 3x3 SPADE Conv2d) as an implicit GEMM on the gfx950 fp16 matrix cores with fp32-class accuracy.
+//
+// gfx950 has no TF32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the fp16/bf16 rate.  This kernel keeps
+// the reference's fp32 numerics to ~2^-22 per product while using v_mfma_f32_32x32x16_f16 ("split-fp16"): every fp32
+// operand x is carried as the pair (hi, lo) = (fp16(x), fp16(x - hi)), so x = hi + lo up to 2^-22 |x|, and
+//     x * w  =  hi_x hi_w  +  hi_x lo_w  +  lo_x hi_w  +  O(2^-22 |x w|)
+// costs three fp16 MFMAs into ONE fp32 accumulator (fp16 x fp16 products are exact in fp32; the matrix core honours fp16
+// subnormals -- tools/mfma_denorm_test.hip -- so small lo parts keep an absolute precision of 2^-25).  Weights are
+// pre-scaled by a per-layer power of two so that their lo parts stay in the normal fp16 range; the epilogue undoes it
+// exactly.  Effective peak = 2.5 PFLOP/s / 3.
+//
+// Operand format "hl16" (HBM and LDS): per position, per group of 8 channels: 8 x fp16 hi (16 B) | 8 x fp16 lo (16 B),
+// i.e. 4 bytes per element like fp32; one ds_read_b128 yields one MFMA operand (lane (i, kg): row i, k = 8 kg + j).
+// Activations are produced in this format by the modulate kernel (the split is done once per element, not per tap);
+// weights are split on the host at load time.
+//
+// Tiling: 512 threads = 8 wavefronts (2 per SIMD) per workgroup, 256 output positions (TB x TT x TH x TW brick) x BN
+// output channels (128/64/32), wave tile up to 64 x 64.  Per 32-channel K chunk the input halo brick is staged once in
+// LDS (rows padded 128 -> 144 B, MFMA rows assigned to 4x4 (h,w) patches: conflict-free ds_read_b128) and reused by all
+// taps; the next chunk's rows are requested from HBM a few taps ahead.  The [BN][32] weight slab of each tap is
+// double-buffered in LDS and requested one full tap ahead.  The tap loop is software-pipelined: the operands of the
+// next k-step (second half of this tap / first half of the next tap) are read from LDS while the current k-step's 12
+// MFMAs per wave run, with ONE barrier per tap placed between the two k-steps (it publishes the next tap's weights).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "i2v_conv.h"
+
+namespace i2v {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int C16_BM = 256, C16_KC = 32;
+constexpr int C16_ROW = 144;  // bytes per staged row: 32 channels x 4 B + 16 B pad
+constexpr int C16_SLOTS = 12; // prefetched 16-byte input pieces per thread and chunk (768 halo rows); larger bricks
+                              // stage the remainder synchronously
+
+struct Conv16Args {
+    const char* in;   // hl16 channels-last [B][T][H][W][Cin]
+    const char* wp;   // hl16 weights [tap][chunk][CoutPad][128 B]
+    const float* bias;
+    const float* res;
+    float* out;       // fp32 channels-last [B][T][H][W][Cout]
+    double* stats;    // optional [B][Cout][2]: per-(sample, channel) sum / sum of squares of the stored values (TB == 1)
+    int B, T, H, W, Cin, Cout, CoutPad, nchunk;  // T,H,W: geometry of the INPUT tensor
+    int tdup;            // 1: temporal-duplication mode -- the output has 2T frames, two tiles (frame parities) per brick
+    long wset_stride;    // bytes between the two parity weight sets (tdup)
+    int KT, KH, KW, tap_base, ztap;  // ztap: index of the all-zero weight slab (stage padding)
+    int TB, TT, TH, TW, nbB, nbT, nbH, nbW;
+    int HWp;   // halo row pitch in positions (>= TW + KW - 1; 12 for 8-wide bricks: conflict-free 4x4 patches)
+    int patch; // 1: MFMA rows are assigned to brick positions in 4x4 (h,w) patches per ds_read_b128 lane group
+    int rt, rs, epi;
+    float oscale;  // 2^-s: undoes the power-of-two pre-scaling of the weights
+};
+
+// MFMA tile row (0..255 within the workgroup tile) -> linear brick index m = ((ib*TT + it)*TH + ih)*TW + iw.
+// ds_read_b128 services a wave in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with `patch` every
+// group reads one 4x4 (h,w) patch, whose 16 rows (pitch 12 positions x 144 B) fall on 16 distinct bank quads.
+__device__ __forceinline__ int brick_index(int row, int TH, int TW, int patch) {
+    if (!patch) return row;
+    const int i = row & 31, tile = row >> 5;
+    int grp, q;
+    if (i < 4) { grp = 0; q = i; }
+    else if (i < 12) { grp = 1; q = i - 4; }
+    else if (i < 16) { grp = 0; q = i - 8; }
+    else if (i < 20) { grp = 1; q = i - 8; }
+    else if (i < 28) { grp = 0; q = i - 12; }
+    else { grp = 1; q = i - 16; }
+    const int pidx = tile * 2 + grp;           // 4x4 patch number inside the workgroup tile (TH, TW multiples of 4)
+    const int pw = TW >> 2, ph = TH >> 2;
+    const int px = pidx % pw, py = (pidx / pw) % ph, plane = pidx / (pw * ph);
+    return (plane * TH + py * 4 + (q >> 2)) * TW + px * 4 + (q & 3);
+}
+
+// TPS = taps per pipeline stage: the narrower the channel tile, the more taps share one weight buffer / barrier
+// (BN x TPS = 128 rows per buffer for every variant).
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void conv_mfma_f16x3_kernel(Conv16Args a) {
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N;              // 512 (2 waves per SIMD) or 1024 (4 per SIMD)
+    constexpr int NSLOT = C16_SLOTS * 512 / NTHR;            // prefetched 16-byte input pieces per thread
+    constexpr int C16_BN = 32 * WN * WAVES_N;
+    constexpr int WBUF = TPS * C16_BN * C16_ROW;  // bytes per weight buffer
+    static_assert(32 * WM * WAVES_M == C16_BM && (WAVES_M * WAVES_N == 8 || WAVES_M * WAVES_N == 16), "tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int kg = lane >> 5, l31 = lane & 31;
+
+    // Temporal-duplication mode (conv_0 behind a x2 nearest up-sampling in time): the virtual input satisfies
+    // a[2i] == a[2i+1], so even output frames see (a[i-1], a[i], a[i]) and odd ones (a[i], a[i], a[i+1]): a 2-tap
+    // temporal kernel on the HALF-rate tensor with pre-summed weights (W0, W1+W2) resp. (W0+W1, W2).
+    // Tile order and the XCDs.  Workgroup b runs on XCD b % 8, each XCD with its own L2.  Bricks are numbered w-fastest
+    // (8 bricks per row at 64 x 64), so the plain order gives XCD x the bricks of ONE w-column: its 32 concurrent
+    // workgroups cover all h-rows and t-slabs of that column and share their h- and t-halos in L2 (measured: 1.8x the
+    // algorithmic input bytes; giving each XCD a contiguous tile range instead shares w/h but not t and reads MORE, and
+    // it makes every XCD stream all N-tiles' weights instead of a quarter of them).  Only the two frame parities of a
+    // temporal-duplication brick -- same input, different weights -- need placing: consecutive slots of the same XCD.
+    const unsigned nb_ = gridDim.x;  // tiles (x 2 parities in tdup mode)
+    const bool pair_ = a.tdup && (nb_ & 15) == 0;
+    const int par = !a.tdup ? 0 : pair_ ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x >= (nb_ >> 1));
+    const int tile_id = !a.tdup ? (int)blockIdx.x
+                        : pair_ ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)(blockIdx.x % (nb_ >> 1));
+    const int pt = a.tdup ? 1 - par : a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
+    const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.HWp;
+    const int NPOS = a.TB * HT * HH * HW;
+    const int ntaps = a.KT * a.KH * a.KW;
+
+    char* in_lds = smem;
+    char* w_lds = smem + NPOS * C16_ROW;
+    int* rowpos = reinterpret_cast<int*>(w_lds + 2 * WBUF);
+    int* rowres = rowpos + C16_BM;
+    int* taplist = rowres + C16_BM;  // [0] = padded tap count, [1..32] weight-slab index, [33..64] LDS byte offset of the tap
+    int* gpos = taplist + 72;  // [NPOS] linear input position of every staged halo row, -1 = zero padding
+
+    const int nNt = a.CoutPad / C16_BN;
+    const int ntile = tile_id % nNt;
+    int brick = tile_id / nNt;
+    const int bw = brick % a.nbW; brick /= a.nbW;
+    const int bh = brick % a.nbH; brick /= a.nbH;
+    const int bt = brick % a.nbT; brick /= a.nbT;
+    const int b0 = brick * a.TB, t0 = bt * a.TT, h0 = bh * a.TH, w0 = bw * a.TW;
+    const int n0 = ntile * C16_BN;
+
+    if (tid < C16_BM) {
+        int m = brick_index(tid, a.TH, a.TW, a.patch);
+        const int iw = m % a.TW; m /= a.TW;
+        const int ih = m % a.TH; m /= a.TH;
+        const int it = m % a.TT; m /= a.TT;
+        const int b = b0 + m, t = t0 + it, h = h0 + ih, w = w0 + iw;
+        const bool ok = b < a.B;
+        const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + par : t;  // output frame
+        rowpos[tid] = ok ? ((b * To + to) * a.H + h) * a.W + w : -1;
+        rowres[tid] = ok ? ((b * (To / a.rt) + to / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs) + w / a.rs : 0;
+    }
+    if (tid == 0) {
+        int cnt = 0;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KH * a.KW);
+            const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
+            if (hi < 0 || lo >= a.T) continue;  // the whole brick meets zero padding only
+            taplist[1 + cnt] = a.tap_base + tap;
+            taplist[33 + cnt] = ((dt * HH + dh) * HW + dw) * C16_ROW;
+            ++cnt;
+        }
+        while (cnt % TPS) {  // pad the stage with the all-zero weight slab
+            taplist[1 + cnt] = a.ztap;
+            taplist[33 + cnt] = 0;
+            ++cnt;
+        }
+        taplist[0] = cnt;
+    }
+
+    for (int p0 = tid; p0 < NPOS; p0 += NTHR) {
+        int p = p0;
+        const int iw = p % HW; p /= HW;
+        const int ih = p % HH; p /= HH;
+        const int it = p % HT; p /= HT;
+        const int b = b0 + p, t = t0 + it - pt, h = h0 + ih - ph, w = w0 + iw - pw;
+        const bool ok = b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W &&
+                        iw < a.TW + a.KW - 1;
+        gpos[p0] = ok ? ((b * a.T + t) * a.H + h) * a.W + w : -1;
+    }
+
+    int aoff[WM], boff[WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm) {
+        int m = brick_index(wave_m * (32 * WM) + 32 * wm + l31, a.TH, a.TW, a.patch);
+        const int iw = m % a.TW; m /= a.TW;
+        const int ih = m % a.TH; m /= a.TH;
+        const int it = m % a.TT; m /= a.TT;
+        aoff[wm] = (((m * HT + it) * HH + ih) * HW + iw) * C16_ROW + kg * 32;
+    }
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) boff[wn] = (wave_n * (32 * WN) + 32 * wn + l31) * C16_ROW + kg * 32;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+
+    constexpr int WF4 = TPS * C16_BN * 8;      // 16-byte pieces per stage of weights (TPS slabs)
+    constexpr int WLD = WF4 / NTHR;
+    static_assert(WF4 % NTHR == 0 && WLD >= 1 && WLD <= 2, "weight pieces per thread");
+    const long slab = (long)a.CoutPad * 128;  // bytes per (tap, chunk)
+    __syncthreads();
+    const int ntv = taplist[0];
+    const long in_row = (long)a.Cin * 4;
+
+    // Input staging: all (<= C16_SLOTS) 16-byte pieces of a thread are requested back to back (one exposed memory
+    // latency per chunk instead of one per piece) and the NEXT chunk's pieces are requested a few taps before the
+    // current chunk ends, so that latency hides behind MFMA work.
+    const int ngrp = a.Cin >> 3;
+    float4 vin[NSLOT];
+#define C16_REQUEST_INPUT(ch_)                                                                                      \
+    {                                                                                                                \
+        int gp_[NSLOT];                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < NSLOT; ++u) {                                                          \
+            const int idx = tid + u * NTHR;                                                                          \
+            gp_[u] = gpos[idx < NPOS * 8 ? (idx >> 3) : 0];                                                          \
+        }                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < NSLOT; ++u) {                                                          \
+            const int idx = tid + u * NTHR;                                                                          \
+            const int q = idx & 7;                                                                                   \
+            const bool ok = idx < NPOS * 8 && gp_[u] >= 0 && (ch_) * 4 + (q >> 1) < ngrp;                            \
+            const long off = ok ? (long)gp_[u] * in_row + (long)(ch_) * 128 + q * 16 : 0;                            \
+            const float4 v = *reinterpret_cast<const float4*>(a.in + off);                                           \
+            vin[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+        }                                                                                                            \
+    }
+    struct Ops { half8 ah[WM], al[WM], bh[WN], bl[WN]; };
+    Ops o0, o1;
+#define C16_LOAD_OPS(o, aoffs, wbuf, koff)                                                                            \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+            const char* p_ = in_lds + aoff[wm] + (aoffs) + (koff);                                                   \
+            (o).ah[wm] = *reinterpret_cast<const half8*>(p_);                                                        \
+            (o).al[wm] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
+        }                                                                                                            \
+        _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) {                                                          \
+            const char* p_ = (wbuf) + boff[wn] + (koff);                                                             \
+            (o).bh[wn] = *reinterpret_cast<const half8*>(p_);                                                        \
+            (o).bl[wn] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
+        }                                                                                                            \
+    }
+    // three terms, tiles interleaved so that consecutive MFMAs never chain on the same accumulator
+#define C16_MFMA(o)                                                                                                  \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bl[wn], acc[wm][wn], 0, 0, 0);      \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+    }
+    C16_REQUEST_INPUT(0)
+    const int nst = ntv / TPS;  // stages per chunk
+    constexpr int PF = TPS >= 4 ? 1 : 4 / TPS;
+    const int pf_stage = nst > PF ? nst - PF : 0;
+    const int* tapw = taplist + 1;
+    const int* tapo = taplist + 33;
+    // per-thread weight piece geometry (constant over the kernel): piece f of a stage = tap f / (BN*8) of the stage,
+    // 16-byte piece f % (BN*8) of that tap's [BN][128 B] slab
+    int wtis[WLD], wsrc[WLD], wdst[WLD];
+#pragma unroll
+    for (int u = 0; u < WLD; ++u) {
+        const int f = tid + u * NTHR;
+        const int tis = f / (C16_BN * 8), fr = f % (C16_BN * 8);
+        wtis[u] = tis;
+        wsrc[u] = fr * 16;
+        wdst[u] = tis * (C16_BN * C16_ROW) + (fr >> 3) * C16_ROW + (fr & 7) * 16;
+    }
+    const long wtap_stride = (long)a.nchunk * slab;
+
+    for (int ch = 0; ch < a.nchunk; ++ch) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NSLOT; ++u) {
+            const int idx = tid + u * NTHR;
+            if (idx < NPOS * 8) *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + (idx & 7) * 16) = vin[u];
+        }
+        for (int idx = tid + NSLOT * NTHR; idx < NPOS * 8; idx += NTHR) {  // oversized halo bricks only
+            const int q = idx & 7;
+            const int gp = gpos[idx >> 3];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gp >= 0 && ch * 4 + (q >> 1) < ngrp)
+                v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)ch * 128 + q * 16);
+            *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;
+        }
+        // weights: stage 0 straight to LDS, stages 1 and 2 into the two register sets (branch-free, always in registers)
+        const char* wbase = a.wp + (long)par * a.wset_stride + (long)ch * slab + (long)n0 * 128;
+        float4 wra[WLD], wrb[WLD];
+#pragma unroll
+        for (int u = 0; u < WLD; ++u) wra[u] = wrb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define C16_REQUEST_W(WR, stg)                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < WLD; ++u)                                                                  \
+        WR[u] = *reinterpret_cast<const float4*>(wbase + (long)tapw[(stg) * TPS + wtis[u]] * wtap_stride + wsrc[u]);
+        if (nst > 0) {
+#pragma unroll
+            for (int u = 0; u < WLD; ++u)
+                *reinterpret_cast<float4*>(w_lds + wdst[u]) =
+                    *reinterpret_cast<const float4*>(wbase + (long)tapw[wtis[u]] * wtap_stride + wsrc[u]);
+        }
+        { const int r1_ = nst > 1 ? 1 : 0, r2_ = nst > 2 ? 2 : nst - 1; C16_REQUEST_W(wra, r1_) C16_REQUEST_W(wrb, r2_) }
+        __syncthreads();
+        if (nst > 0) C16_LOAD_OPS(o0, tapo[0], w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
+        // One pipeline stage = TPS taps.  WR holds the weights of stage st_+1, requested TWO stages ago (an L2/MALL miss on
+        // a slab that every workgroup wants at the same moment costs more than one stage): park them in the other LDS buffer
+        // -- its last readers finished before the previous barrier -- and request stage st_+3 into the same registers.
+        // Then 2*TPS k-steps: the operands of k-step q+1 are read from LDS while k-step q's MFMAs run; the stage's single
+        // barrier sits in front of the last k-step and publishes the next stage's weights.
+        // (s_setprio around the MFMA block and dropping the scheduling fences were measured: no effect.)
+#define C16_STAGE(st_, WR)                                                                                           \
+    {                                                                                                                \
+        const char* wb = w_lds + ((st_) & 1) * WBUF;                                                                 \
+        char* wnext = w_lds + (((st_) + 1) & 1) * WBUF;                                                              \
+        /* unconditional (after the last stage: a harmless re-park / re-request of the last slab): the vmcnt queue    \
+           retires in order, and behind a conditional load the compiler must assume the shortest queue */           \
+        _Pragma("unroll") for (int u = 0; u < WLD; ++u) *reinterpret_cast<float4*>(wnext + wdst[u]) = WR[u];         \
+        { const int rq_ = (st_) + 3 < nst ? (st_) + 3 : nst - 1; C16_REQUEST_W(WR, rq_) }                            \
+        if ((st_) == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)                                        \
+        _Pragma("unroll") for (int q = 0; q < 2 * TPS; ++q) {                                                        \
+            if (q + 1 < 2 * TPS) {                                                                                   \
+                const int tq = (q + 1) >> 1, sq = (q + 1) & 1;                                                       \
+                if ((q + 1) & 1) C16_LOAD_OPS(o1, tapo[(st_) * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)     \
+                else C16_LOAD_OPS(o0, tapo[(st_) * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)                 \
+            } else {                                                                                                 \
+                __syncthreads();                                                                                     \
+                if ((st_) + 1 < nst) C16_LOAD_OPS(o0, tapo[((st_) + 1) * TPS], wnext, 0)                             \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            if (q & 1) C16_MFMA(o1) else C16_MFMA(o0)                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+    }
+        for (int st = 0; st < nst; st += 2) {
+            C16_STAGE(st, wra)
+            if (st + 1 < nst) C16_STAGE(st + 1, wrb)
+        }
+    }
+
+    const int HWo = a.H * a.W;
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const int n = n0 + wave_n * (32 * WN) + 32 * wn + l31;
+        const bool ncol = n < a.Cout;
+        const float bias = (a.bias && ncol) ? a.bias[n] : 0.f;
+        // per-lane partial statistics in fp64: the totals must not depend on how many rows a wave tile holds, or a shard
+        // of the batch (which may pick a narrower tile) would not reproduce the full batch bit for bit
+        double ssum = 0.0, ssq = 0.0;
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wave_m * (32 * WM) + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int p = rowpos[m];
+                if (p < 0 || !ncol) continue;
+                float v = fmaf(acc[wm][wn][r], a.oscale, bias);
+                if (a.res) v += a.res[(long)rowres[m] * a.Cout + n];
+                ssum += (double)v;
+                ssq = fma((double)v, (double)v, ssq);
+                if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
+                if (a.epi & EPI_FRAMES) {
+                    const int bt_ = p / HWo, hw = p - bt_ * HWo;
+                    a.out[((long)bt_ * a.Cout + n) * HWo + hw] = tanhf(v);
+                } else {
+                    a.out[(long)p * a.Cout + n] = v;
+                }
+            }
+        }
+        if (a.stats) {
+            // fused normalisation statistics (InstanceNorm of conv_0's output / GroupNorm of the block output): the
+            // workgroup tile lies inside one sample; lanes l and l^32 hold the same column -> wavefront shuffle, then one
+            // fp64 atomic pair per (wave, column)
+            ssum += __shfl_xor(ssum, 32);
+            ssq += __shfl_xor(ssq, 32);
+            if (kg == 0 && ncol) {
+                double* dst = a.stats + ((long)b0 * a.Cout + n) * 2;
+                atomicAdd(dst, ssum);
+                atomicAdd(dst + 1, ssq);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant for the 128-channel tile (EXPERIMENT, selected by I2V_CONV16_WS): waves 0-3 are CONSUMERS
+// (one per SIMD; wave tile 64 rows x 128 columns: 12 LDS operand reads per 24 MFMAs instead of 8 per 12; they never
+// touch global memory or write LDS in the main loop), waves 4-7 are PRODUCERS (all global -> LDS traffic: the input halo
+// tile of every chunk and the double-buffered per-tap weight slabs, requested three stages ahead).  One s_barrier per
+// stage, placed between the two k-steps exactly as in the symmetric kernel; producers reach it early.
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void conv_mfma_f16x3_ws_kernel(Conv16Args a) {
+    constexpr int WM = 2, WN = 4, C16_BN = 128, NTHR = 512, NPROD = 256;
+    constexpr int WBUF = C16_BN * C16_ROW;
+    constexpr int PSLOT = 24;  // prefetched 16-byte input pieces per producer thread (768 halo rows)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = lane >> 5, l31 = lane & 31;
+    const bool producer = wave >= 4;
+    const int wave_m = wave & 3;
+
+    const unsigned nb_ = gridDim.x;
+    const bool pair_ = a.tdup && (nb_ & 15) == 0;
+    const int par = !a.tdup ? 0 : pair_ ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x >= (nb_ >> 1));
+    const int tile_id = !a.tdup ? (int)blockIdx.x
+                        : pair_ ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)(blockIdx.x % (nb_ >> 1));
+    const int pt = a.tdup ? 1 - par : a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
+    const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.HWp;
+    const int NPOS = a.TB * HT * HH * HW;
+    const int ntaps = a.KT * a.KH * a.KW;
+
+    char* in_lds = smem;
+    char* w_lds = smem + NPOS * C16_ROW;
+    int* rowpos = reinterpret_cast<int*>(w_lds + 2 * WBUF);
+    int* rowres = rowpos + C16_BM;
+    int* taplist = rowres + C16_BM;
+    int* gpos = taplist + 72;
+
+    const int nNt = a.CoutPad / C16_BN;
+    const int ntile = tile_id % nNt;
+    int brick = tile_id / nNt;
+    const int bw = brick % a.nbW; brick /= a.nbW;
+    const int bh = brick % a.nbH; brick /= a.nbH;
+    const int bt = brick % a.nbT; brick /= a.nbT;
+    const int b0 = brick * a.TB, t0 = bt * a.TT, h0 = bh * a.TH, w0 = bw * a.TW;
+    const int n0 = ntile * C16_BN;
+
+    if (tid < C16_BM) {
+        int m = brick_index(tid, a.TH, a.TW, a.patch);
+        const int iw = m % a.TW; m /= a.TW;
+        const int ih = m % a.TH; m /= a.TH;
+        const int it = m % a.TT; m /= a.TT;
+        const int b = b0 + m, t = t0 + it, h = h0 + ih, w = w0 + iw;
+        const bool ok = b < a.B;
+        const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + par : t;
+        rowpos[tid] = ok ? ((b * To + to) * a.H + h) * a.W + w : -1;
+        rowres[tid] = ok ? ((b * (To / a.rt) + to / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs) + w / a.rs : 0;
+    }
+    if (tid == 0) {
+        int cnt = 0;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int dw = tap % a.KW, dh = (tap / a.KW) % a.KH, dt = tap / (a.KH * a.KW);
+            const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
+            if (hi < 0 || lo >= a.T) continue;
+            taplist[1 + cnt] = a.tap_base + tap;
+            taplist[33 + cnt] = ((dt * HH + dh) * HW + dw) * C16_ROW;
+            ++cnt;
+        }
+        taplist[0] = cnt;
+    }
+    for (int p0 = tid; p0 < NPOS; p0 += NTHR) {
+        int p = p0;
+        const int iw = p % HW; p /= HW;
+        const int ih = p % HH; p /= HH;
+        const int it = p % HT; p /= HT;
+        const int b = b0 + p, t = t0 + it - pt, h = h0 + ih - ph, w = w0 + iw - pw;
+        const bool ok = b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W &&
+                        iw < a.TW + a.KW - 1;
+        gpos[p0] = ok ? ((b * a.T + t) * a.H + h) * a.W + w : -1;
+    }
+    __syncthreads();
+    const int nst = taplist[0];
+    const int total = nst * a.nchunk;
+    const int* tapw = taplist + 1;
+    const int* tapo = taplist + 33;
+    const long slab = (long)a.CoutPad * 128;
+    const long wtap_stride = (long)a.nchunk * slab;
+    const long in_row = (long)a.Cin * 4;
+    const int ngrp = a.Cin >> 3;
+// LDS traffic done -> barrier (no vmcnt wait: the producers' prefetches stay in flight across it)
+// (0xC07F = lgkmcnt(0) only; the builtin -- unlike inline asm -- keeps the compiler's own counter bookkeeping exact)
+#define C16_WS_BARRIER() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
+
+    if (producer) {
+        const int ptid = tid - NPROD;
+        float4 vin[PSLOT];
+#define C16_WS_REQUEST_INPUT(ch_)                                                                                    \
+    {                                                                                                                \
+        int gp_[PSLOT];                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < PSLOT; ++u) {                                                          \
+            const int idx = ptid + u * NPROD;                                                                        \
+            gp_[u] = gpos[idx < NPOS * 8 ? (idx >> 3) : 0];                                                          \
+        }                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < PSLOT; ++u) {                                                          \
+            const int idx = ptid + u * NPROD;                                                                        \
+            const int q = idx & 7;                                                                                   \
+            const bool ok = idx < NPOS * 8 && gp_[u] >= 0 && (ch_) * 4 + (q >> 1) < ngrp;                            \
+            const long off = ok ? (long)gp_[u] * in_row + (long)(ch_) * 128 + q * 16 : 0;                            \
+            const float4 v = *reinterpret_cast<const float4*>(a.in + off);                                           \
+            vin[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+        }                                                                                                            \
+    }
+        // Weight slabs: 1024 x 16 B per stage.  Producer wave pw owns the stages s with s % 4 == pw: it requests the whole
+        // slab of stage s (16 pieces per lane, 1 KB contiguous per load) FOUR stages ahead and parks it during stage s - 1.
+        // Its own vmcnt queue then holds nothing younger than that request when the park waits for it -- a prefetch
+        // distance the compiler's conservative s_waitcnt placement cannot shorten (it did in the symmetric kernel).
+        const int pw = wave - 4;
+        const char* wbase0 = a.wp + (long)par * a.wset_stride + (long)n0 * 128;
+        // (sixteen named registers: as an array the slab lands in scratch memory)
+#define C16_WS_FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define C16_WS_DECL(u) float4 wr##u;
+        C16_WS_FOR16(C16_WS_DECL)
+// weights of flat stage g_ (clamped): tap g_ % nst of chunk g_ / nst
+#define C16_WS_REQUEST_W(g_)                                                                                         \
+    {                                                                                                                \
+        const int gc_ = (g_) < total ? (g_) : total - 1;                                                             \
+        const int ch_ = gc_ / nst, st_ = gc_ - ch_ * nst;                                                            \
+        const char* src_ = wbase0 + (long)ch_ * slab + (long)tapw[st_] * wtap_stride + lane * 16;                    \
+        C16_WS_FOR16(C16_WS_LD)                                                                                      \
+    }
+#define C16_WS_LD(u) wr##u = *reinterpret_cast<const float4*>(src_ + (u) * 1024);
+// piece f = u * 64 + lane of the [128][128 B] slab -> row f / 8, 16-byte column f % 8 of the padded LDS slab
+#define C16_WS_PARK_W(buf_) { char* pb_ = (buf_) + (lane >> 3) * C16_ROW + (lane & 7) * 16; C16_WS_FOR16(C16_WS_ST) }
+#define C16_WS_ST(u) *reinterpret_cast<float4*>(pb_ + (u) * 8 * C16_ROW) = wr##u;
+        C16_WS_REQUEST_INPUT(0)
+        {   // stage 0 straight to buffer 0 (all producer waves, 4 pieces per thread)
+            const char* src = wbase0 + (long)tapw[0] * wtap_stride;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = ptid + u * NPROD;
+                *reinterpret_cast<float4*>(w_lds + (f >> 3) * C16_ROW + (f & 7) * 16) = *reinterpret_cast<const float4*>(src + f * 16);
+            }
+        }
+        const int pf_stage = nst > 4 ? nst - 4 : 0;
+        int ch = 0, st = 0;
+// what every producer wave does in every stage, around its (optional) weight turn
+#define C16_WS_STAGE_PRE()                                                                                           \
+    if (st == 0) {                                                                                                   \
+        /* chunk start: the consumers read neither the tile nor a slab between the previous mid-stage barrier and B1 */ \
+        _Pragma("unroll") for (int u = 0; u < PSLOT; ++u) {                                                          \
+            const int idx = ptid + u * NPROD;                                                                        \
+            if (idx < NPOS * 8) *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + (idx & 7) * 16) = vin[u]; \
+        }                                                                                                            \
+        for (int idx = ptid + PSLOT * NPROD; idx < NPOS * 8; idx += NPROD) { /* oversized halo bricks only */        \
+            const int q = idx & 7;                                                                                   \
+            const int gp = gpos[idx >> 3];                                                                           \
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+            if (gp >= 0 && ch * 4 + (q >> 1) < ngrp)                                                                 \
+                v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)ch * 128 + q * 16);            \
+            *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;                                  \
+        }                                                                                                            \
+        C16_WS_BARRIER() /* B1: tile (and this chunk's first slab) are in LDS */                                     \
+    }
+#define C16_WS_STAGE_POST()                                                                                          \
+    {                                                                                                                \
+        if (st == pf_stage && ch + 1 < a.nchunk) C16_WS_REQUEST_INPUT(ch + 1)                                        \
+        C16_WS_BARRIER() /* mid-stage barrier */                                                                     \
+        if (++st == nst) { st = 0; ++ch; }                                                                           \
+    }
+        // my turns: the stages gt with (gt + 1) % 4 == pw and gt + 1 < total publish the slab of stage gt + 1
+        int gt = (pw + 3) & 3;
+        C16_WS_REQUEST_W(gt + 1)
+        int g = 0;
+        for (; gt + 1 < total; gt += 4) {
+            for (; g < gt; ++g) {
+                C16_WS_STAGE_PRE()
+                C16_WS_STAGE_POST()
+            }
+            C16_WS_STAGE_PRE()
+            C16_WS_PARK_W(w_lds + ((gt + 1) & 1) * WBUF)
+            C16_WS_REQUEST_W(gt + 5)
+            C16_WS_STAGE_POST()
+            ++g;
+        }
+        for (; g < total; ++g) {
+            C16_WS_STAGE_PRE()
+            C16_WS_STAGE_POST()
+        }
+        return;
+    }
+
+    // ---- consumers
+    int aoff[WM], boff[WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm) {
+        int m = brick_index(wave_m * (32 * WM) + 32 * wm + l31, a.TH, a.TW, a.patch);
+        const int iw = m % a.TW; m /= a.TW;
+        const int ih = m % a.TH; m /= a.TH;
+        const int it = m % a.TT; m /= a.TT;
+        aoff[wm] = (((m * HT + it) * HH + ih) * HW + iw) * C16_ROW + kg * 32;
+    }
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) boff[wn] = (32 * wn + l31) * C16_ROW + kg * 32;
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+    // operands: (ah, al, bh) double-buffered, bl single (its next value is read from LDS between the hl and lh MFMA groups,
+    // when the hl group has consumed it): 80 instead of 96 registers next to the 128 accumulators
+    struct P { half8 ah[WM], al[WM], bh[WN]; };
+    P p0, p1;
+    half8 bl[WN];
+#define C16_WS_LOAD_P(p, toff, wbuf, koff)                                                                           \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+            const char* q_ = in_lds + aoff[wm] + (toff) + (koff);                                                    \
+            (p).ah[wm] = *reinterpret_cast<const half8*>(q_);                                                        \
+            (p).al[wm] = *reinterpret_cast<const half8*>(q_ + 16);                                                   \
+        }                                                                                                            \
+        _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)                                                            \
+            (p).bh[wn] = *reinterpret_cast<const half8*>((wbuf) + boff[wn] + (koff));                                \
+    }
+#define C16_WS_LOAD_BL(wbuf, koff)                                                                                   \
+    _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) bl[wn] = *reinterpret_cast<const half8*>((wbuf) + boff[wn] + (koff) + 16);
+#define C16_WS_HH_HL(p)                                                                                              \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((p).ah[wm], (p).bh[wn], acc[wm][wn], 0, 0, 0);      \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((p).ah[wm], bl[wn], acc[wm][wn], 0, 0, 0);          \
+    }
+#define C16_WS_LH(p)                                                                                                 \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((p).al[wm], (p).bh[wn], acc[wm][wn], 0, 0, 0);      \
+    }
+    {
+        int g = 0;
+        for (int ch = 0; ch < a.nchunk; ++ch) {
+            C16_WS_BARRIER()  // B1
+            // tap offsets are fetched from the LDS table two stages ahead, never right before their use
+            int toff = tapo[0], toff_next = tapo[nst > 1 ? 1 : 0];
+            C16_WS_LOAD_P(p0, toff, w_lds + (g & 1) * WBUF, 0)
+            C16_WS_LOAD_BL(w_lds + (g & 1) * WBUF, 0)
+            for (int st = 0; st < nst; ++st, ++g) {
+                const char* wb = w_lds + (g & 1) * WBUF;
+                const char* wnext = w_lds + ((g + 1) & 1) * WBUF;
+                // after the last tap of a chunk the (unconditional) prefetch re-reads this tap's rows from a buffer in flux:
+                // dead values, reloaded after B1
+                const int toff_nn = tapo[st + 2 < nst ? st + 2 : nst - 1];
+                // k-step 0 (operands in p0 / bl); k-step 1's operands are read meanwhile
+                C16_WS_LOAD_P(p1, toff, wb, 64)
+                __builtin_amdgcn_sched_barrier(0);
+                C16_WS_HH_HL(p0)
+                __builtin_amdgcn_sched_barrier(0);
+                C16_WS_LOAD_BL(wb, 64)
+                __builtin_amdgcn_sched_barrier(0);
+                C16_WS_LH(p0)
+                __builtin_amdgcn_sched_barrier(0);
+                C16_WS_BARRIER()  // all LDS reads of this stage are done; the next stage's slab is published
+                // k-step 1 (p1 / bl); the next stage's first k-step is read meanwhile
+                C16_WS_LOAD_P(p0, toff_next, wnext, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                C16_WS_HH_HL(p1)
+                __builtin_amdgcn_sched_barrier(0);
+                C16_WS_LOAD_BL(wnext, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                C16_WS_LH(p1)
+                __builtin_amdgcn_sched_barrier(0);
+                toff = toff_next;
+                toff_next = toff_nn;
+            }
+        }
+    }
+
+    const int HWo = a.H * a.W;
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const int n = n0 + 32 * wn + l31;
+        const bool ncol = n < a.Cout;
+        const float bias = (a.bias && ncol) ? a.bias[n] : 0.f;
+        double ssum = 0.0, ssq = 0.0;
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wave_m * (32 * WM) + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int p = rowpos[m];
+                if (p < 0 || !ncol) continue;
+                float v = fmaf(acc[wm][wn][r], a.oscale, bias);
+                if (a.res) v += a.res[(long)rowres[m] * a.Cout + n];
+                ssum += (double)v;
+                ssq = fma((double)v, (double)v, ssq);
+                if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
+                if (a.epi & EPI_FRAMES) {
+                    const int bt_ = p / HWo, hw = p - bt_ * HWo;
+                    a.out[((long)bt_ * a.Cout + n) * HWo + hw] = tanhf(v);
+                } else {
+                    a.out[(long)p * a.Cout + n] = v;
+                }
+            }
+        }
+        if (a.stats) {
+            ssum += __shfl_xor(ssum, 32);
+            ssq += __shfl_xor(ssq, 32);
+            if (kg == 0 && ncol) {
+                double* dst = a.stats + ((long)b0 * a.Cout + n) * 2;
+                atomicAdd(dst, ssum);
+                atomicAdd(dst + 1, ssq);
+            }
+        }
+    }
+}
+
+int Conv16Weights::pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, int kh, int kw, double scale) {
+    Cin = cin; Cout = cout; KT = kt; KH = kh; KW = kw;
+    CoutPad = (cout + 31) / 32 * 32;
+    if (CoutPad > 64 && CoutPad % 128) CoutPad = (CoutPad + 127) / 128 * 128;
+    nchunk = (cin + C16_KC - 1) / C16_KC;
+    const int ntaps = kt * kh * kw;
+    // power-of-two pre-scale: largest |w| lands in [2^13, 2^14) so every lo part of a non-negligible weight is a normal
+    // fp16 number (full 2^-22 split precision) and hi stays far from the fp16 overflow threshold
+    double wmax = 0.0;
+    for (size_t i = 0; i < (size_t)cout * cin * ntaps; ++i) wmax = std::max(wmax, std::fabs((double)w_src[i] * scale));
+    wexp = 0;
+    if (wmax > 0.0 && std::isfinite(wmax)) {
+        wexp = (int)std::floor(std::log2(16384.0 / wmax));
+        wexp = std::max(-40, std::min(40, wexp));
+    }
+    const double pre = std::ldexp(1.0, wexp);
+    std::vector<_Float16> p((size_t)(ntaps + 1) * nchunk * CoutPad * 64, (_Float16)0.f);  // + one all-zero tap
+    for (int n = 0; n < cout; ++n)
+        for (int c = 0; c < cin; ++c)
+            for (int tap = 0; tap < ntaps; ++tap) {
+                const float v = (float)((double)w_src[((size_t)n * cin + c) * ntaps + tap] * scale * pre);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const int chunk = c / C16_KC, g = (c % C16_KC) / 8, j = c % 8;
+                _Float16* row = &p[(((size_t)tap * nchunk + chunk) * CoutPad + n) * 64];
+                row[g * 16 + j] = hi;
+                row[g * 16 + 8 + j] = lo;
+            }
+    int rc = w.upload(p.data(), p.size() * 2);
+    if (rc) return rc;
+    if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
+    bias.release();
+    return I2V_OK;
+}
+
+int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale) {
+    // two 2x3x3 kernels from one 3x3x3 kernel: parity 0 = (W[0], W[1]+W[2]), parity 1 = (W[0]+W[1], W[2]) along time
+    std::vector<float> w2((size_t)2 * cout * cin * 18);
+    for (int par = 0; par < 2; ++par)
+        for (size_t nc = 0; nc < (size_t)cout * cin; ++nc)
+            for (int hw = 0; hw < 9; ++hw) {
+                const double w0 = w_src[nc * 27 + hw], w1 = w_src[nc * 27 + 9 + hw], w2v = w_src[nc * 27 + 18 + hw];
+                float* dst = &w2[((size_t)par * cout * cin + nc) * 18];
+                dst[hw] = (float)(par == 0 ? w0 : w0 + w1);
+                dst[9 + hw] = (float)(par == 0 ? w1 + w2v : w2v);
+            }
+    // both sets share one power-of-two pre-scale: pack them as one [2*cout] tensor, then split the buffer
+    Conv16Weights tmp;
+    Cin = cin; Cout = cout; KT = 2; KH = 3; KW = 3; tdup = true;
+    CoutPad = (cout + 31) / 32 * 32;
+    if (CoutPad > 64 && CoutPad % 128) CoutPad = (CoutPad + 127) / 128 * 128;
+    nchunk = (cin + C16_KC - 1) / C16_KC;
+    const int ntaps = 18;
+    double wmax = 0.0;
+    for (float v : w2) wmax = std::max(wmax, std::fabs((double)v * scale));
+    wexp = 0;
+    if (wmax > 0.0 && std::isfinite(wmax)) wexp = std::max(-40, std::min(40, (int)std::floor(std::log2(16384.0 / wmax))));
+    const double pre = std::ldexp(1.0, wexp);
+    const size_t set_halfs = (size_t)(ntaps + 1) * nchunk * CoutPad * 64;
+    std::vector<_Float16> p(2 * set_halfs, (_Float16)0.f);
+    for (int par = 0; par < 2; ++par)
+        for (int n = 0; n < cout; ++n)
+            for (int c = 0; c < cin; ++c)
+                for (int tap = 0; tap < ntaps; ++tap) {
+                    const float v = (float)((double)w2[(((size_t)par * cout + n) * cin + c) * 18 + tap] * scale * pre);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const int chunk = c / C16_KC, g = (c % C16_KC) / 8, j = c % 8;
+                    _Float16* row = &p[par * set_halfs + (((size_t)tap * nchunk + chunk) * CoutPad + n) * 64];
+                    row[g * 16 + j] = hi;
+                    row[g * 16 + 8 + j] = lo;
+                }
+    set_bytes = (long)set_halfs * 2;
+    int rc = w.upload(p.data(), p.size() * 2);
+    if (rc) return rc;
+    if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
+    bias.release();
+    return I2V_OK;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
+static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
+    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(64 * WAVES_M * WAVES_N), lds, st, a);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+bool conv16_can_fuse_stats(int T, int H, int W) {
+    // the 256-position brick stays inside one sample when the sample has at least 256 positions (power-of-two dims)
+    return (long)T * H * W >= C16_BM;
+}
+
+int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
+                   int H, int W, int epi, hipStream_t st, double* stats) {
+    I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv16: weights not packed");
+    I2V_REQUIRE(wts.Cin % 8 == 0, I2V_E_INVALID, "conv16: Cin %d must be a multiple of 8", wts.Cin);
+    Conv16Args a{};
+    a.in = static_cast<const char*>(in_hl16); a.wp = wts.w.as<char>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
+    a.B = B; a.T = T; a.H = H; a.W = W; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
+    a.KT = wts.KT; a.KH = wts.KH; a.KW = wts.KW; a.tap_base = 0;
+    a.ztap = wts.KT * wts.KH * wts.KW;
+    a.tdup = wts.tdup ? 1 : 0;
+    a.wset_stride = wts.set_bytes;
+    if (wts.tdup) {  // T is the OUTPUT frame count; the (half-rate) input has T / 2 frames
+        I2V_REQUIRE(T % 2 == 0 && !res, I2V_E_INVALID, "conv16: temporal-duplication mode needs an even frame count and no residual");
+        T /= 2;
+        a.T = T;
+    }
+    if (T == 1 && wts.KT == 3) {  // a single frame only ever meets the centre time-slice of the kernel (rest is padding)
+        a.KT = 1;
+        a.tap_base = wts.KH * wts.KW;
+    }
+    a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
+    a.stats = stats;
+    a.oscale = (float)std::ldexp(1.0, -wts.wexp);
+    int TW = W < 8 ? W : 8, TH = H < 8 ? H : 8;
+    int rem = C16_BM / (TW * TH);
+    int TT = T < rem ? T : rem;
+    rem /= TT;
+    while (rem > 1 && W >= TW * 2) { TW *= 2; rem /= 2; }
+    while (rem > 1 && H >= TH * 2) { TH *= 2; rem /= 2; }
+    const int TB = rem;
+    I2V_REQUIRE(TB * TT * TH * TW == C16_BM && T % TT == 0 && H % TH == 0 && W % TW == 0, I2V_E_INVALID,
+                "conv16: cannot tile [T=%d,H=%d,W=%d] into bricks of %d positions", T, H, W, C16_BM);
+    I2V_REQUIRE(!stats || TB == 1, I2V_E_INVALID, "conv16: fused statistics need bricks inside one sample");
+    a.TB = TB; a.TT = TT; a.TH = TH; a.TW = TW;
+    a.nbB = (B + TB - 1) / TB; a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;
+    a.HWp = TW + a.KW - 1;
+    a.patch = (TW % 4 == 0 && TH % 4 == 0) ? 1 : 0;
+    if (a.patch) {  // a halo row pitch = 4 or 12 (mod 16) makes the 4x4 patches conflict-free; keep it if LDS allows
+        int hp = a.HWp;
+        while (hp % 16 != 4 && hp % 16 != 12) ++hp;
+        const size_t rows = (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * hp;
+        const size_t need = rows * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + rows * 4;
+        if (need <= 160 * 1024) a.HWp = hp;
+    }
+    const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * a.HWp;
+    // channel tile: the widest that divides CoutPad, narrowed while the launch would leave most CUs without a workgroup
+    // (head_0: 64 samples x 4 x 4 positions = 4 bricks x 8 tiles of 128 channels, each streaming 9 x 1024 channels of K)
+    int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
+    {
+        const long bricks = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.tdup ? 2 : 1);
+        while (BN > 32 && bricks * (a.CoutPad / BN) < 256) BN /= 2;
+    }
+    const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + (size_t)npos * 4;
+    I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
+    const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
+    I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
+    // (a 16-wave variant <8,2,1,2,1> -- 4 waves per SIMD, wave tile 32x64, 128 VGPRs -- was measured 5 % slower)
+    static const bool ws_ = getenv("I2V_CONV16_WS") != nullptr;  // experiment: wave-specialised 128-channel variant
+    if (BN == 128 && ws_) {
+        auto kern = conv_mfma_f16x3_ws_kernel<0>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * (unsigned)nblk : (unsigned)nblk), dim3(512), lds, st, a);
+        I2V_HIP_CHECK(hipGetLastError());
+        return I2V_OK;
+    }
+    if (BN == 128) return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
+    if (BN == 64) return launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
+    return launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);
+}
+
+}  // namespace i2v
