@@ -289,7 +289,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         }
         { const int r1_ = nst > 1 ? 1 : 0, r2_ = nst > 2 ? 2 : nst - 1; C16_REQUEST_W(wra, r1_) C16_REQUEST_W(wrb, r2_) }
         __syncthreads();
-        if (nst > 0) C16_LOAD_OPS(o0, tapo[0], w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
+        // LDS byte offsets of the taps of the current and of the next stage, fetched from the table a stage AHEAD: a
+        // ds_read_b32 right in front of the operand reads it addresses exposes one LDS round trip per k-step
+        int tcur[TPS], tnxt[TPS];
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) {
+            tcur[t] = tapo[t];
+            tnxt[t] = tapo[(nst > 1 ? TPS : 0) + t];
+        }
+        if (nst > 0) C16_LOAD_OPS(o0, tcur[0], w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
         // One pipeline stage = TPS taps.  WR holds the weights of stage st_+1, requested TWO stages ago (an L2/MALL miss on
         // a slab that every workgroup wants at the same moment costs more than one stage): park them in the other LDS buffer
         // -- its last readers finished before the previous barrier -- and request stage st_+3 into the same registers.
@@ -305,19 +313,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         _Pragma("unroll") for (int u = 0; u < WLD; ++u) *reinterpret_cast<float4*>(wnext + wdst[u]) = WR[u];         \
         { const int rq_ = (st_) + 3 < nst ? (st_) + 3 : nst - 1; C16_REQUEST_W(WR, rq_) }                            \
         if ((st_) == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)                                        \
+        int tnn[TPS]; /* tap offsets of stage st_ + 2 (clamped), needed one stage from now */                        \
+        _Pragma("unroll") for (int t = 0; t < TPS; ++t) tnn[t] = tapo[((st_) + 2 < nst ? (st_) + 2 : nst - 1) * TPS + t]; \
         _Pragma("unroll") for (int q = 0; q < 2 * TPS; ++q) {                                                        \
             if (q + 1 < 2 * TPS) {                                                                                   \
                 const int tq = (q + 1) >> 1, sq = (q + 1) & 1;                                                       \
-                if ((q + 1) & 1) C16_LOAD_OPS(o1, tapo[(st_) * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)     \
-                else C16_LOAD_OPS(o0, tapo[(st_) * TPS + tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)                 \
+                if ((q + 1) & 1) C16_LOAD_OPS(o1, tcur[tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)                   \
+                else C16_LOAD_OPS(o0, tcur[tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)                               \
             } else {                                                                                                 \
                 __syncthreads();                                                                                     \
-                if ((st_) + 1 < nst) C16_LOAD_OPS(o0, tapo[((st_) + 1) * TPS], wnext, 0)                             \
+                if ((st_) + 1 < nst) C16_LOAD_OPS(o0, tnxt[0], wnext, 0)                                             \
             }                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             if (q & 1) C16_MFMA(o1) else C16_MFMA(o0)                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < TPS; ++t) { tcur[t] = tnxt[t]; tnxt[t] = tnn[t]; }                     \
     }
         for (int st = 0; st < nst; st += 2) {
             C16_STAGE(st, wra)
