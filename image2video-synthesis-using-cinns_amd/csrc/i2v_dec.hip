@@ -95,7 +95,9 @@ __global__ void coef_kernel(const double* __restrict__ sums, float2* __restrict_
 
 // out[b][t][h][w][c] = act( (x[b][t/ut][h/us][w/us][c] * A + B) * gamma'[b][h][w][c] + beta[b][h][w][c] )
 //   gb: [B][H][W][2C] (gamma' = 1 + gamma in [0,C), beta in [C,2C)) or null.
-// One thread = one position x 8 channels (32 B in / 32 B out, consecutive threads = consecutive channel groups);
+// One thread = one (h, w) position x 8 channels (consecutive threads = consecutive channel groups), looping over the
+// frames: the per-(sample, channel) coefficients and the SPADE gamma/beta of the position -- neither depends on t -- are
+// loaded once and reused for all T frames, the source row once per `ut` frames; per frame 32 B are stored.
 // blockIdx.y = sample, all per-sample index math in 32 bits.  HL16: write the split-fp16 operand format of
 // i2v_conv16.hip (8 x fp16 hi | 8 x fp16 lo per 8 channels, lo = x - hi) instead of fp32.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -106,55 +108,65 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
                                                        int W, int C, int ut, int us, int lrelu) {
     const int C8 = C >> 3;
     const int b = blockIdx.y;
-    const int per = T * H * W * C8;  // < 2^31 per sample
+    const int per = H * W * C8;  // threads per sample
     const int Hl = H / us, Wl = W / us, Tl = T / ut;
     const float2* cp0 = coef + (long)b * C;
     const float* xb = x + (long)b * Tl * Hl * Wl * C;
     const float* gbb = gb ? gb + (long)b * H * W * 2 * C : nullptr;
-    char* ob = reinterpret_cast<char*>(out) + (long)b * per * 32;
+    char* ob = reinterpret_cast<char*>(out) + (long)b * T * per * 32;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
         const int c8 = i % C8;
         int p = i / C8;
-        const int w = p % W; p /= W;
-        const int h = p % H;
-        const int t = p / H;
-        const float* xp = xb + (((long)(t / ut) * Hl + h / us) * Wl + w / us) * C + 8 * c8;
-        const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 4);
-        float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        const float4* cp = reinterpret_cast<const float4*>(cp0 + 8 * c8);
+        const int w = p % W;
+        const int h = p / W;
+        float ca[8], cb[8];  // norm(x) == x * ca + cb
+        {
+            const float4* cp = reinterpret_cast<const float4*>(cp0 + 8 * c8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 ab = cp[j];
-            r[2 * j] = fmaf(r[2 * j], ab.x, ab.y);
-            r[2 * j + 1] = fmaf(r[2 * j + 1], ab.z, ab.w);
+            for (int j = 0; j < 4; ++j) {
+                const float4 ab = cp[j];
+                ca[2 * j] = ab.x; cb[2 * j] = ab.y; ca[2 * j + 1] = ab.z; cb[2 * j + 1] = ab.w;
+            }
         }
-        if (gbb) {
+        if (gbb) {  // fold SPADE's gamma / beta into the affine: (x ca + cb) ga + be
             const float* g = gbb + ((long)h * W + w) * (2 * C) + 8 * c8;
             const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
             const float4 e0 = *reinterpret_cast<const float4*>(g + C), e1 = *reinterpret_cast<const float4*>(g + C + 4);
             const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = fmaf(r[j], ga[j], be[j]);
+            for (int j = 0; j < 8; ++j) { cb[j] = fmaf(cb[j], ga[j], be[j]); ca[j] = ca[j] * ga[j]; }
         }
-        if (lrelu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = r[j] >= 0.f ? r[j] : 0.2f * r[j];
-        }
-        char* o = ob + (long)i * 32;
-        if (HL16) {
-            half8_t hi, lo;
+        const float* xp0 = xb + ((long)(h / us) * Wl + w / us) * C + 8 * c8;
+        const long xstride = (long)Hl * Wl * C;
+        float r0[8];
+        for (int t = 0; t < T; ++t) {
+            if (t % ut == 0) {
+                const float* xp = xp0 + (long)(t / ut) * xstride;
+                const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 4);
+                r0[0] = v0.x; r0[1] = v0.y; r0[2] = v0.z; r0[3] = v0.w; r0[4] = v1.x; r0[5] = v1.y; r0[6] = v1.z; r0[7] = v1.w;
+            }
+            float r[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const _Float16 hh = (_Float16)r[j];
-                hi[j] = hh;
-                lo[j] = (_Float16)(r[j] - (float)hh);
+                r[j] = fmaf(r0[j], ca[j], cb[j]);
+                if (lrelu) r[j] = r[j] >= 0.f ? r[j] : 0.2f * r[j];
             }
-            *reinterpret_cast<half8_t*>(o) = hi;
-            *reinterpret_cast<half8_t*>(o + 16) = lo;
-        } else {
-            *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
-            *reinterpret_cast<float4*>(o + 16) = make_float4(r[4], r[5], r[6], r[7]);
+            char* o = ob + ((long)t * per + i) * 32;
+            if (HL16) {
+                half8_t hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 hh = (_Float16)r[j];
+                    hi[j] = hh;
+                    lo[j] = (_Float16)(r[j] - (float)hh);
+                }
+                *reinterpret_cast<half8_t*>(o) = hi;
+                *reinterpret_cast<half8_t*>(o + 16) = lo;
+            } else {
+                *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+                *reinterpret_cast<float4*>(o + 16) = make_float4(r[4], r[5], r[6], r[7]);
+            }
         }
     }
 }
@@ -304,8 +316,8 @@ int run_coef(const double* sums, float* coef, int B, int C, int groups, double c
 int run_modulate(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
                  int us, int lrelu, hipStream_t st, bool hl16 = false) {
     I2V_REQUIRE(C % 8 == 0, I2V_E_INVALID, "modulate: channels %d not a multiple of 8", C);
-    const long per = (long)T * H * W * (C / 8);
-    I2V_REQUIRE(per < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
+    const long per = (long)H * W * (C / 8);  // threads per sample (each loops over the T frames)
+    I2V_REQUIRE(per * T < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
     if (hl16)
         hipLaunchKernelGGL(modulate_kernel<true>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb, out,
