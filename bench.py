@@ -164,6 +164,7 @@ def main():
                 "achieved": cinn_bytes / (cinn["inv_us"] * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": cinn_bytes / (cinn["inv_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS,
                 "inv_latency_us": cinn["inv_us"], "fwd_latency_us": cinn["fwd_us"], "batch": nb,
+                "measured_hbm_bytes_per_pass": cinn_measured_bytes(args.config == "bair64" and per_gpu == 64),
             },
         }
         if gen.mma == 1 and result["roofline"]:
@@ -185,6 +186,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cinn_measured_bytes(default_workload):
+    """HBM bytes one cINN pass moves, from the PMC counters of the flow kernels (profiles/r01_l_pmc_hbm_traffic.json:
+    FETCH_SIZE / WRITE_SIZE of every flow_* launch divided by the number of passes in that run = flow_pre_kernel launches).
+    Valid for the default workload only (the activations' share grows with the batch)."""
+    if not default_workload:
+        return None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_l_pmc_hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        flow = {n: v for n, v in k.items() if "flow_" in n}
+        passes = next(v["launches"] for n, v in flow.items() if "flow_pre_kernel" in n)
+        return sum(v["read_bytes"] + v["write_bytes"] for v in flow.values()) / passes
+    except (OSError, KeyError, ValueError, StopIteration):
+        return None
 
 
 def embedder_latency(cfg, x0_d):
@@ -225,12 +242,12 @@ def roofline(prof, dt, mma, default_workload=False):
         kernel = "conv_mfma_f32_kernel (3x3x3 Conv3d implicit GEMM, v_mfma_f32_32x32x2_f32)"
         peak = PEAK_FP32_MFMA_TFLOPS
     # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
-    # rocprofv3 --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/r01_h_pmc_hbm_traffic.json).
+    # rocprofv3 --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/r01_l_pmc_hbm_traffic.json).
     # bench.py cannot read PMCs itself: the figure is valid for the default workload (bair64, batch 64, mma = 1) only.
     traffic = None
     if mma == 1 and default_workload:
         try:
-            with open(os.path.join(REPO, "profiles", "r01_h_pmc_hbm_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r01_l_pmc_hbm_traffic.json")) as f:
                 traffic = json.load(f)["dominant_kernel"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None

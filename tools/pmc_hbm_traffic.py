@@ -5,7 +5,7 @@ Run on the GPU box:   python tools/pmc_hbm_traffic.py gpurun_out/pmc_traffic [--
 Two SEPARATE counter passes (FETCH_SIZE, then WRITE_SIZE) with --kernel-trace only, as MI355X_MICROARCH.md prescribes;
 FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read, so
 read bytes = 2 * FETCH_SIZE * 1024 (the guide's gfx950 correction); WRITE_SIZE is used as reported.
-Writes <outdir>/hbm_traffic.json; copy it to profiles/ (bench.py reads profiles/r01_h_pmc_hbm_traffic.json for `roofline.traffic`)."""
+Writes <outdir>/hbm_traffic.json; copy it to profiles/ (bench.py reads profiles/r01_l_pmc_hbm_traffic.json for `roofline.traffic`)."""
 import collections
 import csv
 import json
