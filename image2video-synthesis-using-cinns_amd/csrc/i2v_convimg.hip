@@ -11,17 +11,18 @@
 
 namespace i2v {
 
-constexpr int CI_TT = 4, CI_TH = 8, CI_TW = 8;
+constexpr int CI_TT = 8, CI_TH = 8, CI_TW = 8;  // 512-position brick: halo 1000 rows = 1.95x (a 4x8x8 brick: 2.34x)
+constexpr int CI_NTHR = 256;
 constexpr int CI_HT = CI_TT + 2, CI_HH = CI_TH + 2, CI_HW = CI_TW + 2;
-constexpr int CI_NPOS = CI_HT * CI_HH * CI_HW;  // 600
-constexpr int CI_KC = 8;                       // channels per chunk (small chunk -> 35 KB LDS -> 4 workgroups per CU)
+constexpr int CI_NPOS = CI_HT * CI_HH * CI_HW;  // 1000
+constexpr int CI_KC = 8;                       // channels per chunk (small chunk -> 56 KB LDS -> 2 workgroups of 4 waves per CU)
 constexpr int CI_LS = CI_KC + 4;               // floats per staged row (+4 pad)
 constexpr int CI_Q = CI_KC / 4;                // float4 pieces per row
 constexpr int CI_WCH = 27 * CI_KC * 4;         // weight floats per chunk: [tap][c][3(+1)]
 
 // One thread = TWO output positions (w and w+4 of the same brick row): every weight float4 fetched from LDS (a broadcast
 // read, all lanes the same address) feeds two FMA triplets, which keeps the LDS pipe below the VALU time.
-__global__ __launch_bounds__(128) void conv_img_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+__global__ __launch_bounds__(CI_NTHR) void conv_img_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int T,
                                                        int H, int W, int C, int nchunk) {
     __shared__ __attribute__((aligned(16))) float in_lds[CI_NPOS * CI_LS];
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(128) void conv_img_kernel(const float* __restrict__
     const int bh = brick % nbH; brick /= nbH;
     const int bt = brick % nbT; brick /= nbT;
     const int b = brick, t0 = bt * CI_TT, h0 = bh * CI_TH, w0 = bw * CI_TW;
-    for (int p0 = tid; p0 < CI_NPOS; p0 += 128) {
+    for (int p0 = tid; p0 < CI_NPOS; p0 += CI_NTHR) {
         int p = p0;
         const int iw = p % CI_HW; p /= CI_HW;
         const int ih = p % CI_HH; p /= CI_HH;
@@ -50,31 +51,31 @@ __global__ __launch_bounds__(128) void conv_img_kernel(const float* __restrict__
         __syncthreads();
         const int c0 = ch * CI_KC;
         {   // all of a thread's pieces are requested back to back (branch-free, clamped): one exposed latency per chunk
-            constexpr int NS = (CI_NPOS * CI_Q + 127) / 128;
+            constexpr int NS = (CI_NPOS * CI_Q + CI_NTHR - 1) / CI_NTHR;
             float4 v[NS];
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
-                const int idx = tid + u * 128;
+                const int idx = tid + u * CI_NTHR;
                 const int q = idx % CI_Q, gp = gpos[idx < CI_NPOS * CI_Q ? (idx / CI_Q) : 0];
                 const bool ok = idx < CI_NPOS * CI_Q && gp >= 0 && c0 + 4 * q < C;
                 const float4 t4 = *reinterpret_cast<const float4*>(in + (ok ? (long)gp * C + c0 + 4 * q : 0));
                 v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            constexpr int NW4 = CI_WCH / 4, NWS = (NW4 + 127) / 128;
+            constexpr int NW4 = CI_WCH / 4, NWS = (NW4 + CI_NTHR - 1) / CI_NTHR;
             float4 wv[NWS];
 #pragma unroll
             for (int u = 0; u < NWS; ++u) {
-                const int f = tid + u * 128;
+                const int f = tid + u * CI_NTHR;
                 wv[u] = *reinterpret_cast<const float4*>(wp + (long)ch * CI_WCH + (f < NW4 ? f : 0) * 4);
             }
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
-                const int idx = tid + u * 128;
+                const int idx = tid + u * CI_NTHR;
                 if (idx < CI_NPOS * CI_Q) *reinterpret_cast<float4*>(in_lds + (idx / CI_Q) * CI_LS + 4 * (idx % CI_Q)) = v[u];
             }
 #pragma unroll
             for (int u = 0; u < NWS; ++u) {
-                const int f = tid + u * 128;
+                const int f = tid + u * CI_NTHR;
                 if (f < NW4) *reinterpret_cast<float4*>(w_lds + f * 4) = wv[u];
             }
         }
@@ -128,7 +129,7 @@ int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv_img: weights not packed");
     I2V_REQUIRE(conv_img_supported(T, H, W, wts.Cin), I2V_E_INVALID, "conv_img: unsupported geometry");
     const long nblk = (long)B * (T / CI_TT) * (H / CI_TH) * (W / CI_TW);
-    hipLaunchKernelGGL(conv_img_kernel, dim3((unsigned)nblk), dim3(128), 0, st, in, wts.w.as<float>(), wts.bias.as<float>(), out,
+    hipLaunchKernelGGL(conv_img_kernel, dim3((unsigned)nblk), dim3(CI_NTHR), 0, st, in, wts.w.as<float>(), wts.bias.as<float>(), out,
                        B, T, H, W, wts.Cin, wts.nchunk);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
