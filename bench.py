@@ -62,6 +62,9 @@ def main():
     from stage2_cINN.modules.flow_blocks import ConditionalFlow
 
     cfg = CONFIGS[args.config]
+    # the host driver only supports dmabuf IPC: without this RCCL's buffer exchange fails (hipIpcGetMemHandle); it is
+    # exported on the GPU boxes already -- keep it for any environment this is launched from (read at HSA start-up)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
