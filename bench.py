@@ -183,6 +183,7 @@ def main():
                 "conv_kernel_issue_frac_of_sustained": r["mfma_issue_frac"] * PEAK_F16_MFMA_TFLOPS / sustained,
             }
         result["embedder"] = embedder_latency(cfg, x0_d)
+        result["encoder"] = encoder_latency(cfg, x0_d)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, fsd, dsd)
         print(json.dumps(result), flush=True)
@@ -227,6 +228,34 @@ def embedder_latency(cfg, x0_d):
         ts.append(e0.elapsed_time(e1))
     return {"what": "ResNet-50 conditioning embedder (InstanceNorm variant), same batch; not part of `value`",
             "ms_per_batch": float(np.median(ts)), "batch": int(x0_d.shape[0])}
+
+
+def encoder_latency(cfg, x0_d):
+    """Row N3 (motion encoder, 3D ResNet-18 in front of the cINN's forward direction in `Model.transfer`): device time of
+    Encoder.forward on a synthetic 16-frame clip per sample, reported separately like the embedder."""
+    import i2v_synth as synth
+    from stage1_VAE.modules.resnet3D import Encoder
+    bair = cfg["img"] == 64
+    geo = dict(channels=[64, 128, 256, 512, 512], stride_s=[1, 2, 2, 2]) if bair else \
+        dict(channels=[64, 128, 128, 256, 512], stride_s=[2, 2, 2, 2])  # stage1_VAE/configs/{bair,landscape}_config.yaml
+    enc = Encoder({"res_type_encoder": "resnet18", "use_max_pool": False, "z_dim": 64, "stride_t": [1, 2, 2, 2], **geo})
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.encoder3d_state_dict(seed=7, z_dim=64, **geo).items()})
+    enc = enc.to(x0_d.device).eval()
+    B = int(x0_d.shape[0])
+    g = torch.Generator().manual_seed(97)
+    clip = (2 * torch.rand(B, 3, 16, cfg["img"], cfg["img"], generator=g) - 1).to(x0_d.device)
+    for _ in range(2):
+        enc(clip)
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        enc(clip)
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return {"what": "motion encoder (3D ResNet-18, GroupNorm) on 16-frame clips, same batch; not part of `value`",
+            "ms_per_batch": float(np.median(ts)), "batch": B}
 
 
 def roofline(prof, dt, mma, default_workload=False):

@@ -86,8 +86,9 @@ int stats_forward(const float* x, double* sums, int B, long P, int C, hipStream_
 int coef_forward(const double* sums, float* coef, int B, int C, int groups, double count, hipStream_t st,
                  const float* gw = nullptr, const float* gb = nullptr);
 // out = act(x * A + B (+ res)) on a channels-last [B][P][C] tensor; coef index = b * cstride + c (i2v_embed.hip)
+// out_hl16 (optional): the same result in the split-fp16 operand format (input of conv16_forward); out may then be null
 int norm_act_forward(const float* x, const float* coef, long cstride, const float* res, float* out, int B, long P, int C, bool relu,
-                     hipStream_t st);
+                     hipStream_t st, void* out_hl16 = nullptr);
 // bilinear (align_corners=True) NCHW [B,3,Hi,Wi] -> channels-last [B][Ho][Wo][16] (channels 3..15 zero)
 int resize_forward(const float* img, float* out, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t st);
 

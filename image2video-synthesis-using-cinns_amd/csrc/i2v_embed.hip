@@ -17,10 +17,12 @@
 
 namespace i2v {
 
-// out = act(x * A + B (+ res)); coef index = b * cstride + c (cstride = C for per-sample norms, 0 for BatchNorm constants)
+// out = act(x * A + B (+ res)); coef index = b * cstride + c (cstride = C for per-sample norms, 0 for BatchNorm constants).
+// out16 (optional, C % 8 == 0): the same values in the split-fp16 operand format of i2v_conv16.hip (per 8 channels: 8 x fp16
+// hi | 8 x fp16 lo); out may then be null when only the next convolution reads the result.
 __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__ x, const float2* __restrict__ coef, long cstride,
-                                                       const float* __restrict__ res, float* __restrict__ out, long per, int C,
-                                                       int relu) {
+                                                       const float* __restrict__ res, float* __restrict__ out,
+                                                       char* __restrict__ out16, long per, int C, int relu) {
     const int C4 = C >> 2;
     const int b = blockIdx.y;
     const float2* cp = coef + (long)b * cstride;
@@ -35,7 +37,22 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__
             r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
         }
         if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-        *reinterpret_cast<float4*>(out + off) = r;
+        if (out) *reinterpret_cast<float4*>(out + off) = r;
+        if (out16) {
+            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+            half4_t hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const _Float16 hh = (_Float16)rr[j];
+                hi[j] = hh;
+                lo[j] = (_Float16)(rr[j] - (float)hh);
+            }
+            // element index (b, pos, c4): the 8-channel group c4 / 2 occupies 32 bytes, this thread owns half of each 16-byte part
+            char* o = out16 + ((long)b * per + (i - c4)) * 16 + (c4 >> 1) * 32 + (c4 & 1) * 8;
+            *reinterpret_cast<half4_t*>(o) = hi;
+            *reinterpret_cast<half4_t*>(o + 16) = lo;
+        }
     }
 }
 
@@ -70,10 +87,12 @@ __global__ void mean_from_sums_kernel(const double* __restrict__ sums, float* __
 }
 
 int norm_act_forward(const float* x, const float* coef, long cstride, const float* res, float* out, int B, long P, int C, bool relu,
-                     hipStream_t st) {
+                     hipStream_t st, void* out_hl16) {
+    I2V_REQUIRE(out || out_hl16, I2V_E_INVALID, "norm_act: no output");
+    I2V_REQUIRE(!out_hl16 || C % 8 == 0, I2V_E_INVALID, "norm_act: the split-fp16 output needs C %% 8 == 0 (C = %d)", C);
     const long per = P * (C / 4);
     hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)std::min<long>((per + 255) / 256, 4096), B), dim3(256), 0, st, x,
-                       reinterpret_cast<const float2*>(coef), cstride, res, out, per, C, relu ? 1 : 0);
+                       reinterpret_cast<const float2*>(coef), cstride, res, out, static_cast<char*>(out_hl16), per, C, relu ? 1 : 0);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }

@@ -96,6 +96,10 @@ struct GN { DevBuf w, b; int C = 0; };
 
 struct EncBlock {
     ConvWeights c1, c2, down;
+    // split-fp16 packing of the stride-1 3x3x3 convs (i2v_conv16.hip: fp16 matrix cores at fp32-class accuracy); the strided
+    // conv1 / downsample convs of a stage's first block stay on the exact-fp32 kernel
+    Conv16Weights c1_16, c2_16;
+    bool c1_is16 = false;
     GN n1, n2, nd;
     int planes = 0, ss = 1, st = 1;
     bool has_down = false;
@@ -124,7 +128,7 @@ struct i2v_encoder3d {
 
 namespace {
 
-struct EncWs { size_t buf[4], sums, coef, ml, total; };
+struct EncWs { size_t buf[4], h16[3], sums, coef, ml, total; };  // h16: activations in the split-fp16 operand format
 
 EncWs enc_ws(const i2v_encoder3d* e, int B, int T, int H, int W) {
     const int To = (T + 2 - 3) / 2 + 1, Ho = H / 2, Wo = W / 2;
@@ -139,6 +143,7 @@ EncWs enc_ws(const i2v_encoder3d* e, int B, int T, int H, int W) {
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o = align_up(o + floats * 4, 256); return r; };
     for (auto& b : L.buf) b = take((size_t)B * mx);
+    for (auto& b : L.h16) b = take((size_t)B * mx);
     L.sums = take((size_t)B * 1024 * 4);
     L.coef = take((size_t)B * 1024 * 2);
     L.ml = take((size_t)B * 2 * e->cfg.z_dim);
@@ -147,12 +152,13 @@ EncWs enc_ws(const i2v_encoder3d* e, int B, int T, int H, int W) {
 }
 
 // y = act(GroupNorm(16, affine)(x) (+ res))
-int gn_act(const GN& g, const float* x, const float* res, float* out, int B, long P, bool relu, double* sums, float* coef,
-           hipStream_t st) {
+// (out and / or out16: fp32 for residual connections and strided convs, split-fp16 for the next stride-1 conv)
+int gn_act(const GN& g, const float* x, const float* res, float* out, void* out16, int B, long P, bool relu, double* sums,
+           float* coef, hipStream_t st) {
     int rc;
     if ((rc = stats_forward(x, sums, B, P, g.C, st))) return rc;
     if ((rc = coef_forward(sums, coef, B, g.C, 16, (double)P, st, g.w.as<float>(), g.b.as<float>()))) return rc;
-    return norm_act_forward(x, coef, g.C, res, out, B, P, g.C, relu, st);
+    return norm_act_forward(x, coef, g.C, res, out, B, P, g.C, relu, st, out16);
 }
 
 }  // namespace
@@ -212,8 +218,10 @@ int i2v_encoder3d_load(i2v_encoder3d* e, const i2v_tensor* tensors, int32_t n_te
             const float* w1 = sd.f32(p + "conv1.weight", (int64_t)planes * inplanes * 27);
             const float* w2 = sd.f32(p + "conv2.weight", (int64_t)planes * planes * 27);
             if (!w1 || !w2) return I2V_E_MISSING;
-            if ((rc = b.c1.pack(w1, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc;
-            if ((rc = b.c2.pack(w2, nullptr, planes, planes, 3, 3, 3, 1.0))) return rc;
+            b.c1_is16 = b.ss == 1 && b.st == 1;
+            if (b.c1_is16) { if ((rc = b.c1_16.pack(w1, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc; }
+            else if ((rc = b.c1.pack(w1, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc;
+            if ((rc = b.c2_16.pack(w2, nullptr, planes, planes, 3, 3, 3, 1.0))) return rc;
             if ((rc = load_gn(sd, p + "bn1", planes, b.n1))) return rc;
             if ((rc = load_gn(sd, p + "bn2", planes, b.n2))) return rc;
             if (b.has_down) {
@@ -281,7 +289,8 @@ int i2v_encoder3d_forward(i2v_encoder3d* e, const float* x, int32_t t, int32_t h
                            W, C);
         I2V_HIP_CHECK(hipGetLastError());
     }
-    if ((rc = gn_act(e->nstem, b0, nullptr, b1, B, (long)T * H * W, true, sums, coef, st))) return rc;
+    void *x16 = ws + L.h16[0], *y16 = ws + L.h16[1], *t16 = ws + L.h16[2];
+    if ((rc = gn_act(e->nstem, b0, nullptr, b1, x16, B, (long)T * H * W, true, sums, coef, st))) return rc;
     float *xcur = b1, *y = b0, *t1 = b2, *t2 = b3;
     for (EncBlock& b : e->blocks) {
         I2V_REQUIRE(T % b.st == 0 || T == 1, I2V_E_INVALID, "i2v_encoder3d_forward: odd temporal extent %d", T);
@@ -289,22 +298,25 @@ int i2v_encoder3d_forward(i2v_encoder3d* e, const float* x, int32_t t, int32_t h
         const long Po = (long)To * Ho * Wo;
         // with T == 1 a temporal stride of 2 is the identity on the single frame (pad 1, kernel 3): use stride 1 there
         const int st_eff = (T == 1) ? 1 : b.st;
-        // out = relu(bn1(conv1(x)))
-        if ((rc = conv_forward(b.c1, xcur, C, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st, nullptr, b.ss, st_eff))) return rc;
-        if ((rc = gn_act(b.n1, t1, nullptr, t2, B, Po, true, sums, coef, st))) return rc;
+        // out = relu(bn1(conv1(x)))   (only conv2 reads it: split-fp16 copy only)
+        if (b.c1_is16) rc = conv16_forward(b.c1_16, x16, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st);
+        else rc = conv_forward(b.c1, xcur, C, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st, nullptr, b.ss, st_eff);
+        if (rc) return rc;
+        if ((rc = gn_act(b.n1, t1, nullptr, nullptr, t16, B, Po, true, sums, coef, st))) return rc;
         // out = bn2(conv2(out))
-        if ((rc = conv_forward(b.c2, t2, b.planes, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st))) return rc;
+        if ((rc = conv16_forward(b.c2_16, t16, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st))) return rc;
         const float* residual = xcur;
         if (b.has_down) {  // 3x3x3 strided conv + GroupNorm (resnet3D.py:181-189)
             if ((rc = conv_forward(b.down, xcur, C, t2, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st, nullptr, b.ss, st_eff))) return rc;
-            if ((rc = gn_act(b.nd, t2, nullptr, y, B, Po, false, sums, coef, st))) return rc;
-            // y now holds the residual; the block output goes to t2 below
-            if ((rc = gn_act(b.n2, t1, y, t2, B, Po, true, sums, coef, st))) return rc;
+            if ((rc = gn_act(b.nd, t2, nullptr, y, nullptr, B, Po, false, sums, coef, st))) return rc;
+            // y now holds the residual; the block output goes to t2 (and, split, to y16) below
+            if ((rc = gn_act(b.n2, t1, y, t2, y16, B, Po, true, sums, coef, st))) return rc;
             std::swap(xcur, t2);
         } else {
-            if ((rc = gn_act(b.n2, t1, residual, y, B, Po, true, sums, coef, st))) return rc;
+            if ((rc = gn_act(b.n2, t1, residual, y, y16, B, Po, true, sums, coef, st))) return rc;
             std::swap(xcur, y);
         }
+        std::swap(x16, y16);
         T = To; H = Ho; W = Wo; C = b.planes;
     }
     I2V_REQUIRE(T == 1 && H == 4 && W == 4, I2V_E_INVALID,
