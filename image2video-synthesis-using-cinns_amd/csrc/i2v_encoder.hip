@@ -74,6 +74,41 @@ __global__ __launch_bounds__(256) void enc_stem_kernel(const float* __restrict__
     }
 }
 
+// Space-to-depth for the strided 3x3x3 convs: a stride-2 conv with pad 1 reads x[2o + d - 1], d = 0..2, i.e. the ODD
+// phase at shifts (-1, 0) and the EVEN phase at shift 0.  With X'[o][phase p][c] = x[2o + p][c] it becomes a STRIDE-1 conv
+// with a 2-tap kernel (offsets -1, 0; the even phase's -1 tap is zero) over P x C channels -- which runs on the split-fp16
+// matrix-core kernel (27 of its 8 x 8 = 64 tap-phase products are non-zero; still 4x faster than the strided fp32 path).
+// in: fp32 channels-last [B][T][H][W][C]; out: hl16 [B][T/st][H/2][W/2][P*C], P = st*4, phase index (pt*2 + ph)*2 + pw.
+__global__ __launch_bounds__(256) void enc_s2d_hl16_kernel(const float* __restrict__ x, char* __restrict__ out, int B, int T, int H,
+                                                           int W, int C, int st) {
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    const int C8 = C >> 3, To = T / st, Ho = H / 2, Wo = W / 2, P = st * 4;
+    const long total = (long)B * To * Ho * Wo * P * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        long q = i / C8;
+        const int p = (int)(q % P); q /= P;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho); q /= Ho;
+        const int to = (int)(q % To);
+        const int b = (int)(q / To);
+        const int pw = p & 1, ph = (p >> 1) & 1, pt = p >> 2;
+        const float* src = x + ((((long)b * T + to * st + pt) * H + 2 * ho + ph) * W + 2 * wo + pw) * C + 8 * c8;
+        const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+        const float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        half8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 hh = (_Float16)r[j];
+            hi[j] = hh;
+            lo[j] = (_Float16)(r[j] - (float)hh);
+        }
+        char* o = out + i * 32;  // flat (b, to, ho, wo, p, c8) order == channels-last with channel index p*C + 8*c8
+        *reinterpret_cast<half8_t*>(o) = hi;
+        *reinterpret_cast<half8_t*>(o + 16) = lo;
+    }
+}
+
 // eps*std + mu with std = exp(0.5 logvar)  (Encoder.reparameterize, resnet3D.py:199-203); ml = [B][2z] = (mu | logvar)
 __global__ void reparam_kernel(const float* __restrict__ ml, const float* __restrict__ eps, float* __restrict__ sample,
                                float* __restrict__ mu, float* __restrict__ logvar, int B, int z) {
@@ -100,10 +135,38 @@ struct EncBlock {
     // conv1 / downsample convs of a stage's first block stay on the exact-fp32 kernel
     Conv16Weights c1_16, c2_16;
     bool c1_is16 = false;
+    // strided conv1 / downsample conv (spatial stride 2, temporal stride st) as stride-1 convs on the space-to-depth input
+    // (enc_s2d_hl16_kernel); the *_t1 variants serve a single-frame input, where the temporal stride is the identity
+    Conv16Weights c1_s2d, down_s2d, c1_s2d_t1, down_s2d_t1;
+    bool use_s2d = false;
     GN n1, n2, nd;
     int planes = 0, ss = 1, st = 1;
     bool has_down = false;
 };
+
+// weights [N][C][3][3][3] of a stride-(st,2,2) conv -> [N][P*C][kt][2][2] of the equivalent stride-1 conv on the
+// space-to-depth input (see enc_s2d_hl16_kernel): per strided dim, tap shift -1 <- (odd phase, w[0]); shift 0 <- (even
+// phase, w[1]) and (odd phase, w[2]).  A dim with stride 1 keeps its three taps.
+int pack_s2d(const float* w, int N, int C, int st, Conv16Weights& out) {
+    const int P = st * 4, kt = st == 2 ? 2 : 3;
+    std::vector<float> w2((size_t)N * P * C * kt * 4, 0.f);
+    auto src_tap = [](int phase, int shift) { return phase == 0 ? (shift == 1 ? 1 : -1) : (shift == 0 ? 0 : 2); };  // shift idx 0: -1, 1: 0
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c)
+            for (int pt = 0; pt < st; ++pt)
+                for (int ph = 0; ph < 2; ++ph)
+                    for (int pw = 0; pw < 2; ++pw)
+                        for (int it = 0; it < kt; ++it)
+                            for (int ih = 0; ih < 2; ++ih)
+                                for (int iw = 0; iw < 2; ++iw) {
+                                    const int dt = st == 2 ? src_tap(pt, it) : it, dh = src_tap(ph, ih), dw = src_tap(pw, iw);
+                                    if (dt < 0 || dh < 0 || dw < 0) continue;
+                                    const int p = (pt * 2 + ph) * 2 + pw;
+                                    w2[(((size_t)n * P * C + (size_t)p * C + c) * kt + it) * 4 + ih * 2 + iw] =
+                                        w[((size_t)n * C + c) * 27 + (dt * 3 + dh) * 3 + dw];
+                                }
+    return out.pack(w2.data(), nullptr, N, P * C, kt, 2, 2, 1.0);
+}
 
 int load_gn(const StateDict& sd, const std::string& name, int C, GN& g) {
     const float* w = sd.f32(name + ".weight", C);
@@ -219,15 +282,22 @@ int i2v_encoder3d_load(i2v_encoder3d* e, const i2v_tensor* tensors, int32_t n_te
             const float* w2 = sd.f32(p + "conv2.weight", (int64_t)planes * planes * 27);
             if (!w1 || !w2) return I2V_E_MISSING;
             b.c1_is16 = b.ss == 1 && b.st == 1;
+            b.use_s2d = b.ss == 2 && inplanes % 8 == 0;
             if (b.c1_is16) { if ((rc = b.c1_16.pack(w1, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc; }
-            else if ((rc = b.c1.pack(w1, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc;
+            else if (b.use_s2d) {
+                if ((rc = pack_s2d(w1, planes, inplanes, b.st, b.c1_s2d))) return rc;
+                if (b.st == 2 && (rc = pack_s2d(w1, planes, inplanes, 1, b.c1_s2d_t1))) return rc;
+            } else if ((rc = b.c1.pack(w1, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc;
             if ((rc = b.c2_16.pack(w2, nullptr, planes, planes, 3, 3, 3, 1.0))) return rc;
             if ((rc = load_gn(sd, p + "bn1", planes, b.n1))) return rc;
             if ((rc = load_gn(sd, p + "bn2", planes, b.n2))) return rc;
             if (b.has_down) {
                 const float* wd = sd.f32(p + "downsample.0.weight", (int64_t)planes * inplanes * 27);
                 if (!wd) return I2V_E_MISSING;
-                if ((rc = b.down.pack(wd, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc;
+                if (b.use_s2d) {
+                    if ((rc = pack_s2d(wd, planes, inplanes, b.st, b.down_s2d))) return rc;
+                    if (b.st == 2 && (rc = pack_s2d(wd, planes, inplanes, 1, b.down_s2d_t1))) return rc;
+                } else if ((rc = b.down.pack(wd, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc;
                 if ((rc = load_gn(sd, p + "downsample.1", planes, b.nd))) return rc;
             }
             inplanes = planes;
@@ -299,7 +369,15 @@ int i2v_encoder3d_forward(i2v_encoder3d* e, const float* x, int32_t t, int32_t h
         // with T == 1 a temporal stride of 2 is the identity on the single frame (pad 1, kernel 3): use stride 1 there
         const int st_eff = (T == 1) ? 1 : b.st;
         // out = relu(bn1(conv1(x)))   (only conv2 reads it: split-fp16 copy only)
+        if (b.use_s2d) {  // strided convs of this block read the space-to-depth copy of its input, built once in y16
+                          // (free until this block's output is written there by the last gn_act)
+            const long tot = (long)B * To * Ho * Wo * (st_eff * 4) * (C / 8);
+            hipLaunchKernelGGL(enc_s2d_hl16_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 16384)), dim3(256), 0, st, xcur,
+                               static_cast<char*>(y16), B, T, H, W, C, st_eff);
+            I2V_HIP_CHECK(hipGetLastError());
+        }
         if (b.c1_is16) rc = conv16_forward(b.c1_16, x16, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st);
+        else if (b.use_s2d) rc = conv16_forward(st_eff == b.st ? b.c1_s2d : b.c1_s2d_t1, y16, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st);
         else rc = conv_forward(b.c1, xcur, C, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st, nullptr, b.ss, st_eff);
         if (rc) return rc;
         if ((rc = gn_act(b.n1, t1, nullptr, nullptr, t16, B, Po, true, sums, coef, st))) return rc;
@@ -307,7 +385,9 @@ int i2v_encoder3d_forward(i2v_encoder3d* e, const float* x, int32_t t, int32_t h
         if ((rc = conv16_forward(b.c2_16, t16, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st))) return rc;
         const float* residual = xcur;
         if (b.has_down) {  // 3x3x3 strided conv + GroupNorm (resnet3D.py:181-189)
-            if ((rc = conv_forward(b.down, xcur, C, t2, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st, nullptr, b.ss, st_eff))) return rc;
+            if (b.use_s2d) rc = conv16_forward(st_eff == b.st ? b.down_s2d : b.down_s2d_t1, y16, t2, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st);
+            else rc = conv_forward(b.down, xcur, C, t2, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st, nullptr, b.ss, st_eff);
+            if (rc) return rc;
             if ((rc = gn_act(b.nd, t2, nullptr, y, nullptr, B, Po, false, sums, coef, st))) return rc;
             // y now holds the residual; the block output goes to t2 (and, split, to y16) below
             if ((rc = gn_act(b.n2, t1, y, t2, y16, B, Po, true, sums, coef, st))) return rc;
