@@ -6,9 +6,11 @@
 // Model.transfer (get_model.py:87) keeps the MEAN mu; logvar is returned as well.
 //
 // The 3-channel stem is a direct fp32 convolution on the vector ALU with its whole [3*7*7*3][c0] weight set resident in
-// LDS (a 7x7 stride-2 halo brick of 16-channel rows would not fit the MFMA kernel's LDS tile); every other conv runs on the
-// exact-fp32 MFMA implicit-GEMM kernel with spatial / temporal stride; GroupNorm + ReLU (+ residual) is one elementwise
-// pass over channels-last activations driven by per-(b,c) (A,B) pairs from fp64 statistics.
+// LDS (a 7x7 stride-2 halo brick of 16-channel rows would not fit the MFMA kernel's LDS tile).  The 3x3x3 convs run on the
+// split-fp16 matrix-core kernel (i2v_conv16.hip, fp32-class accuracy): the stride-1 ones directly, the strided conv1 /
+// down-sample convs as stride-1 2-tap convs on a space-to-depth copy of their input (enc_s2d_hl16_kernel).  GroupNorm +
+// ReLU (+ residual) is one elementwise pass over channels-last activations driven by per-(b,c) (A,B) pairs from fp64
+// statistics; it emits fp32 (residuals) and / or the split-fp16 operand format (next conv).  conv_mu | conv_var: one GEMM.
 #include <algorithm>
 #include <memory>
 
