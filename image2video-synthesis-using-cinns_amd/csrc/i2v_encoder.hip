@@ -135,7 +135,7 @@ struct EncBlock {
     ConvWeights c1, c2, down;
     // split-fp16 packing of the stride-1 3x3x3 convs (i2v_conv16.hip: fp16 matrix cores at fp32-class accuracy); the strided
     // conv1 / downsample convs of a stage's first block stay on the exact-fp32 kernel
-    Conv16Weights c1_16, c2_16;
+    Conv16Weights c1_16, c2_16, down_16;  // down_16: a channel-changing block without stride (its 3x3x3 projection conv)
     bool c1_is16 = false;
     // strided conv1 / downsample conv (spatial stride 2, temporal stride st) as stride-1 convs on the space-to-depth input
     // (enc_s2d_hl16_kernel); the *_t1 variants serve a single-frame input, where the temporal stride is the identity
@@ -296,7 +296,9 @@ int i2v_encoder3d_load(i2v_encoder3d* e, const i2v_tensor* tensors, int32_t n_te
             if (b.has_down) {
                 const float* wd = sd.f32(p + "downsample.0.weight", (int64_t)planes * inplanes * 27);
                 if (!wd) return I2V_E_MISSING;
-                if (b.use_s2d) {
+                if (b.c1_is16) {
+                    if ((rc = b.down_16.pack(wd, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc;
+                } else if (b.use_s2d) {
                     if ((rc = pack_s2d(wd, planes, inplanes, b.st, b.down_s2d))) return rc;
                     if (b.st == 2 && (rc = pack_s2d(wd, planes, inplanes, 1, b.down_s2d_t1))) return rc;
                 } else if ((rc = b.down.pack(wd, nullptr, planes, inplanes, 3, 3, 3, 1.0))) return rc;
@@ -387,7 +389,8 @@ int i2v_encoder3d_forward(i2v_encoder3d* e, const float* x, int32_t t, int32_t h
         if ((rc = conv16_forward(b.c2_16, t16, t1, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st))) return rc;
         const float* residual = xcur;
         if (b.has_down) {  // 3x3x3 strided conv + GroupNorm (resnet3D.py:181-189)
-            if (b.use_s2d) rc = conv16_forward(st_eff == b.st ? b.down_s2d : b.down_s2d_t1, y16, t2, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st);
+            if (b.c1_is16) rc = conv16_forward(b.down_16, x16, t2, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st);
+            else if (b.use_s2d) rc = conv16_forward(st_eff == b.st ? b.down_s2d : b.down_s2d_t1, y16, t2, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st);
             else rc = conv_forward(b.down, xcur, C, t2, nullptr, 1, 1, B, To, Ho, Wo, EPI_NONE, st, nullptr, b.ss, st_eff);
             if (rc) return rc;
             if ((rc = gn_act(b.nd, t2, nullptr, y, nullptr, B, Po, false, sums, coef, st))) return rc;
