@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         const int ih = m % a.TH; m /= a.TH;
         const int it = m % a.TT; m /= a.TT;
         const int b = b0 + m, t = t0 + it, h = h0 + ih, w = w0 + iw;
-        const bool ok = b < a.B;
+        const bool ok = b < a.B && m < a.TB;  // (a brick is only partly filled when LDS limits the samples per brick)
         const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + par : t;  // output frame
         rowpos[tid] = ok ? ((b * To + to) * a.H + h) * a.W + w : -1;
         rowres[tid] = ok ? ((b * (To / a.rt) + to / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs) + w / a.rs : 0;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         const int iw = m % a.TW; m /= a.TW;
         const int ih = m % a.TH; m /= a.TH;
         const int it = m % a.TT; m /= a.TT;
-        aoff[wm] = (((m * HT + it) * HH + ih) * HW + iw) * C16_ROW + kg * 32;
+        aoff[wm] = ((((m < a.TB ? m : 0) * HT + it) * HH + ih) * HW + iw) * C16_ROW + kg * 32;
     }
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) boff[wn] = (wave_n * (32 * WN) + 32 * wn + l31) * C16_ROW + kg * 32;
@@ -508,9 +508,17 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     rem /= TT;
     while (rem > 1 && W >= TW * 2) { TW *= 2; rem /= 2; }
     while (rem > 1 && H >= TH * 2) { TH *= 2; rem /= 2; }
-    const int TB = rem;
+    int TB = rem;
     I2V_REQUIRE(TB * TT * TH * TW == C16_BM && T % TT == 0 && H % TH == 0 && W % TW == 0, I2V_E_INVALID,
                 "conv16: cannot tile [T=%d,H=%d,W=%d] into bricks of %d positions", T, H, W, C16_BM);
+    {   // tiny feature maps x many samples: the halo tile of a full brick may not fit LDS -- take fewer samples per brick
+        // (the tile's unused rows are masked)
+        auto lds_of = [&](int tb) {
+            const size_t rows = (size_t)tb * (TT + a.KT - 1) * (TH + a.KH - 1) * (TW + a.KW - 1);
+            return rows * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + rows * 4;
+        };
+        while (TB > 1 && lds_of(TB) > 160 * 1024) TB /= 2;
+    }
     I2V_REQUIRE(!stats || TB == 1, I2V_E_INVALID, "conv16: fused statistics need bricks inside one sample");
     a.TB = TB; a.TT = TT; a.TH = TH; a.TW = TW;
     a.nbB = (B + TB - 1) / TB; a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;

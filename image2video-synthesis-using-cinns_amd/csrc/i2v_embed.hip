@@ -109,6 +109,8 @@ struct NormP {  // BatchNorm constants folded to (A,B) per channel; empty for In
 
 struct Bneck {
     ConvWeights c1, c2, c3, down;
+    Conv16Weights c2_16;  // the stride-1 3x3 convs run on the split-fp16 matrix-core kernel (i2v_conv16.hip)
+    bool c2_is16 = false;
     NormP n1, n2, n3, nd;
     int width = 0, stride = 1;
     bool has_down = false;
@@ -159,7 +161,7 @@ EmbWs emb_ws(int B, int H, int W) {
 
 // y = act(norm(x) (+ res)) for a channels-last [B][P][C] tensor
 int norm_act(const i2v_embedder* e, const NormP& np, const float* x, const float* res, float* out, int B, long P, int C, bool relu,
-             double* sums, float* coef, hipStream_t st) {
+             double* sums, float* coef, hipStream_t st, bool as_hl16 = false) {
     const float2* cp;
     long cstride;
     int rc;
@@ -172,7 +174,9 @@ int norm_act(const i2v_embedder* e, const NormP& np, const float* x, const float
         cp = reinterpret_cast<const float2*>(coef);
         cstride = C;
     }
-    return norm_act_forward(x, reinterpret_cast<const float*>(cp), cstride, res, out, B, P, C, relu, st);
+    // as_hl16: `out` receives the split-fp16 operand format (same bytes per element) for a following conv16_forward
+    return norm_act_forward(x, reinterpret_cast<const float*>(cp), cstride, res, as_hl16 ? nullptr : out, B, P, C, relu, st,
+                            as_hl16 ? out : nullptr);
 }
 
 }  // namespace
@@ -219,7 +223,9 @@ int i2v_embedder_load(i2v_embedder* e, const i2v_tensor* tensors, int32_t n_tens
             const float* w3 = sd.f32(p + "conv3.weight", (int64_t)outp * wd);
             if (!w1 || !w2 || !w3) return I2V_E_MISSING;
             if ((rc = b.c1.pack(w1, nullptr, wd, inplanes, 1, 1, 1, 1.0))) return rc;
-            if ((rc = b.c2.pack(w2, nullptr, wd, wd, 1, 3, 3, 1.0))) return rc;
+            b.c2_is16 = b.stride == 1;
+            if (b.c2_is16) { if ((rc = b.c2_16.pack(w2, nullptr, wd, wd, 1, 3, 3, 1.0))) return rc; }
+            else if ((rc = b.c2.pack(w2, nullptr, wd, wd, 1, 3, 3, 1.0))) return rc;
             if ((rc = b.c3.pack(w3, nullptr, outp, wd, 1, 1, 1, 1.0))) return rc;
             if (e->bn) {
                 if ((rc = load_bn(sd, p + "bn1", wd, b.n1))) return rc;
@@ -285,9 +291,11 @@ int i2v_embedder_forward(i2v_embedder* e, const float* img, int32_t h, int32_t w
         const long P = (long)H * W, Po = (long)Ho * Wo;
         // conv1 1x1 -> norm -> ReLU
         if ((rc = conv_forward(b.c1, x, C, t1, nullptr, 1, 1, B, 1, H, W, EPI_NONE, st))) return rc;
-        if ((rc = norm_act(e, b.n1, t1, nullptr, t2, B, P, wd, true, sums, coef, st))) return rc;
+        if ((rc = norm_act(e, b.n1, t1, nullptr, t2, B, P, wd, true, sums, coef, st, b.c2_is16))) return rc;
         // conv2 3x3 (stride on THIS conv, torchvision >= 0.3) -> norm -> ReLU
-        if ((rc = conv_forward(b.c2, t2, wd, t1, nullptr, 1, 1, B, 1, Ho, Wo, EPI_NONE, st, nullptr, b.stride))) return rc;
+        if (b.c2_is16) rc = conv16_forward(b.c2_16, t2, t1, nullptr, 1, 1, B, 1, Ho, Wo, EPI_NONE, st);
+        else rc = conv_forward(b.c2, t2, wd, t1, nullptr, 1, 1, B, 1, Ho, Wo, EPI_NONE, st, nullptr, b.stride);
+        if (rc) return rc;
         if ((rc = norm_act(e, b.n2, t1, nullptr, t2, B, Po, wd, true, sums, coef, st))) return rc;
         // conv3 1x1 -> norm
         if ((rc = conv_forward(b.c3, t2, wd, t1, nullptr, 1, 1, B, 1, Ho, Wo, EPI_NONE, st))) return rc;
