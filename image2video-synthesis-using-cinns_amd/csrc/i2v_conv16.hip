@@ -360,6 +360,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                 if (a.epi & EPI_FRAMES) {
                     const int bt_ = p / HWo, hw = p - bt_ * HWo;
                     a.out[((long)bt_ * a.Cout + n) * HWo + hw] = tanhf(v);
+                } else if (a.epi & EPI_HL16) {  // the next conv's operand format instead of fp32 (same bytes per element)
+                    const _Float16 hi = (_Float16)v;
+                    char* o = reinterpret_cast<char*>(a.out) + (long)p * a.Cout * 4 + (n >> 3) * 32 + (n & 7) * 2;
+                    *reinterpret_cast<_Float16*>(o) = hi;
+                    *reinterpret_cast<_Float16*>(o + 16) = (_Float16)(v - (float)hi);
                 } else {
                     a.out[(long)p * a.Cout + n] = v;
                 }

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
 
 // F.interpolate(img, size=(h,w), mode='bilinear', align_corners=True) (normalization_layer.py:20), written
 // channels-last with the 3 colour channels zero-padded to 16 (the conv kernel's K chunk).
-__global__ void resize_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo) {
+__global__ void resize_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
+                              int hl16) {
     const long total = (long)B * Ho * Wo;
     const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
     const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
@@ -186,14 +187,27 @@ __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__
         const int h1 = h0 + (h0 < Hi - 1 ? 1 : 0), w1 = w0 + (w0 < Wi - 1 ? 1 : 0);
         const float lh1 = fh - h0, lh0 = 1.f - lh1, lw1 = fw - w0, lw0 = 1.f - lw1;
         float* o = out + i * 16;
+        float v[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float* pl = img + ((long)b * 3 + c) * Hi * Wi;
-            o[c] = lh0 * (lw0 * pl[h0 * Wi + w0] + lw1 * pl[h0 * Wi + w1]) +
+            v[c] = lh0 * (lw0 * pl[h0 * Wi + w0] + lw1 * pl[h0 * Wi + w1]) +
                    lh1 * (lw0 * pl[h1 * Wi + w0] + lw1 * pl[h1 * Wi + w1]);
         }
 #pragma unroll
-        for (int c = 3; c < 16; ++c) o[c] = 0.f;
+        for (int c = 0; c < 16; ++c) o[c] = 0.f;
+        if (hl16) {  // split-fp16 operand format: per 8 channels 8 x fp16 hi | 8 x fp16 lo (64 bytes per position, as fp32)
+            _Float16* oh = reinterpret_cast<_Float16*>(o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const _Float16 hh = (_Float16)v[c];
+                oh[c] = hh;
+                oh[8 + c] = (_Float16)(v[c] - (float)hh);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = v[c];
+        }
     }
 }
 
@@ -227,6 +241,7 @@ struct Block {
     bool learned = false;
     int groups_spade = 16;
     ConvWeights conv0, conv1, convs, sp_conv, sp_gb;
+    Conv16Weights sp_conv16;  // SPADE's Conv2d(3, 128, 3) with the 3 input channels zero-padded to 8 (split-fp16 mode)
     Conv16Weights conv0_16, conv1_16, sp_gb16;  // split-fp16 variants (cfg.mma == 1)
     DevBuf gn_w, gn_b;
     int zoff = 0;  // offset of this block's ADAIN (gamma|beta) in the z-GEMM output
@@ -378,7 +393,7 @@ int coef_forward(const double* sums, float* coef, int B, int C, int groups, doub
 int resize_forward(const float* img, float* out, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
     const long tot = (long)B * Ho * Wo;
     hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, out, B, Hi, Wi,
-                       Ho, Wo);
+                       Ho, Wo, 0);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -413,11 +428,11 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     {
         const long tot = (long)B * l.H * l.W;
         hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, y0,
-                           B, img_h, img_w, l.H, l.W);
+                           B, img_h, img_w, l.H, l.W, d->cfg.mma == 1 ? 1 : 0);
         I2V_HIP_CHECK(hipGetLastError());
     }
     if (d->cfg.mma == 1) {
-        if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st))) return rc;
+        if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st))) return rc;
         if ((rc = conv16_forward(b.sp_gb16, y1, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
     } else {
         if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
@@ -611,6 +626,13 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         const float* bb = sd.f32(p + "norm_0.conv_beta.bias", b.n_in);
         if (!w1 || !b1 || !wg || !bg || !wb || !bb) return I2V_E_MISSING;
         if ((rc = b.sp_conv.pack(w1, b1, 128, 3, 1, 3, 3, 1.0))) return rc;
+        {   // the same conv for the split-fp16 path: input channels padded 3 -> 16 (the resize kernel's row)
+            std::vector<float> w16((size_t)128 * 16 * 9, 0.f);
+            for (int n = 0; n < 128; ++n)
+                for (int c = 0; c < 3; ++c)
+                    for (int t = 0; t < 9; ++t) w16[((size_t)n * 16 + c) * 9 + t] = w1[((size_t)n * 3 + c) * 9 + t];
+            if ((rc = b.sp_conv16.pack(w16.data(), b1, 128, 16, 1, 3, 3, 1.0))) return rc;
+        }
         std::vector<float> wgb((size_t)2 * b.n_in * 128 * 9), bgb((size_t)2 * b.n_in);
         std::memcpy(wgb.data(), wg, (size_t)b.n_in * 128 * 9 * 4);
         std::memcpy(wgb.data() + (size_t)b.n_in * 128 * 9, wb, (size_t)b.n_in * 128 * 9 * 4);
@@ -845,6 +867,13 @@ int i2v_gblock_load(i2v_gblock* g, const i2v_tensor* tensors, int32_t n_tensors)
         const float* bb = sd.f32("norm_0.conv_beta.bias", b.n_in);
         if (!w1 || !b1 || !wg || !bg || !wb || !bb) return I2V_E_MISSING;
         if ((rc = b.sp_conv.pack(w1, b1, 128, 3, 1, 3, 3, 1.0))) return rc;
+        {   // the same conv for the split-fp16 path: input channels padded 3 -> 16 (the resize kernel's row)
+            std::vector<float> w16((size_t)128 * 16 * 9, 0.f);
+            for (int n = 0; n < 128; ++n)
+                for (int c = 0; c < 3; ++c)
+                    for (int t = 0; t < 9; ++t) w16[((size_t)n * 16 + c) * 9 + t] = w1[((size_t)n * 3 + c) * 9 + t];
+            if ((rc = b.sp_conv16.pack(w16.data(), b1, 128, 16, 1, 3, 3, 1.0))) return rc;
+        }
         std::vector<float> wgb((size_t)2 * b.n_in * 128 * 9), bgb((size_t)2 * b.n_in);
         std::memcpy(wgb.data(), wg, (size_t)b.n_in * 128 * 9 * 4);
         std::memcpy(wgb.data() + (size_t)b.n_in * 128 * 9, wb, (size_t)b.n_in * 128 * 9 * 4);
@@ -918,10 +947,11 @@ int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* co
         if ((rc = run_coef(sums, coef, B, C, b.groups_spade, (double)P, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
         const long tot = (long)B * h * w;
         hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, cond, F(L.y0), B,
-                           img_h, img_w, h, w);
+                           img_h, img_w, h, w, g->ctx.cfg.mma == 1 ? 1 : 0);
         I2V_HIP_CHECK(hipGetLastError());
         if (g->ctx.cfg.mma == 1) {
-            if ((rc = conv_forward(b.sp_conv, F(L.y0), 16, F(L.y1), nullptr, 1, 1, B, 1, h, w, EPI_LRELU | EPI_HL16, st))) return rc;
+            if ((rc = conv16_forward(b.sp_conv16, F(L.y0), reinterpret_cast<float*>(F(L.y1)), nullptr, 1, 1, B, 1, h, w,
+                                     EPI_LRELU | EPI_HL16, st))) return rc;
             if ((rc = conv16_forward(b.sp_gb16, F(L.y1), F(L.gb), nullptr, 1, 1, B, 1, h, w, EPI_NONE, st))) return rc;
         } else {
             if ((rc = conv_forward(b.sp_conv, F(L.y0), 16, F(L.y1), nullptr, 1, 1, B, 1, h, w, EPI_LRELU, st))) return rc;
