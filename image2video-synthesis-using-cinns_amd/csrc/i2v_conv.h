@@ -78,6 +78,28 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
 // true when conv16_forward can accumulate per-(sample, channel) sum / sum-of-squares of its output in the epilogue
 bool conv16_can_fuse_stats(int T, int H, int W);
 
+// ---- split-fp16 path with a Winograd F(2,3) transform along W (i2v_conv16w.hip): 1.5x fewer MFMAs than conv16_forward.
+// Input: the TRANSFORMED activations V = B^T d in hl16 format, [B][T][Cin/16][4][H][W/2][16 channels] (written by the
+// producer kernel: per output pair (2j, 2j+1) and channel V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3,
+// d_k = a[.., 2j-1+k] zero padded; 16 channels = 2 groups x (8 fp16 hi | 8 fp16 lo) = 64 bytes).
+struct Wino16Weights {
+    DevBuf w;      // U = G g: [parity][tap (kt,kh)][chunk16][4][CoutPad][2 groups x (8 hi | 8 lo) fp16 = 64 B]
+    DevBuf bias;
+    int Cin = 0, Cout = 0, CoutPad = 0, nchunk = 0;
+    int KT = 3;    // temporal taps (3, 1, or 2 for the temporal-duplication pair)
+    int wexp = 0;
+    bool tdup = false;
+    long set_bytes = 0;
+    // w_src: torch layout [Cout][Cin][kt][3][3]
+    int pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, double scale);
+    int pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale);  // from a 3x3x3 kernel
+};
+// T = frames of the tensor V was built from (half the output frames for pack_tdup weights)
+bool wino16_supported(int cout, int cin, int T, int H, int W);
+// T,H,W = OUTPUT geometry; epi: EPI_NONE or EPI_LRELU; stats as conv16_forward
+int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T,
+                   int H, int W, int epi, hipStream_t st, double* stats = nullptr);
+
 // ---- helpers implemented in i2v_dec.hip, shared with the embedder (i2v_embed.hip)
 // per-(b,c) sum / sum of squares (fp64) of a channels-last tensor [B][P][C]
 int stats_forward(const float* x, double* sums, int B, long P, int C, hipStream_t st);

@@ -1,0 +1,512 @@
+// 3x3x3 Conv3d with a Winograd F(2,3) transform along W on the gfx950 fp16 matrix cores (split-fp16 operands).
+//
+// The split-fp16 implicit GEMM of i2v_conv16.hip is bound by the NUMBER of MFMAs (three per product; the matrix cores
+// run power-limited at 65-67 % of their sustained rate whatever the schedule).  This kernel issues 1.5x fewer of them:
+// for every pair of output positions (w = 2j, 2j+1) -- a "tile" -- and every (kt, kh) tap
+//     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3          d_k = a[t+kt-1][h+kh-1][2j-1+k]  (zero padded)
+//     U0 = g0        U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2     g_k = w[kt][kh][k]
+//     M_x = sum over (kt, kh, c) of V_x * U_x   (x = 0..3: four GEMMs instead of the six of two outputs x three kw taps)
+//     y[2j] = M0 + M1 + M2        y[2j+1] = M1 - M2 - M3
+// The input transform is done ONCE per element by the producer (the modulate kernel writes V = B^T d, computed in fp32
+// and then split into fp16 hi/lo, as [B][T][C/16][4][H][W/2][16 channels]: K-chunk-major, so that the 64-byte rows a
+// workgroup stages per chunk are contiguous along w); the weight transform G g is done in fp64 at load time.  Both
+// operands therefore keep the 2^-22 relative precision of the hl16 format and the products the three-term form
+// hi*hi + hi*lo + lo*hi of i2v_conv16.hip; the output transform A^T M runs in fp32 in the epilogue.
+//
+// Workgroup = 512 threads = 8 wavefronts: 128 tiles (256 output positions, TT x TH x 2TJ brick) x 64 output channels for
+// all four x.  Wave w owns x = w & 3 and the tile half w >> 2: a 64 x 64 accumulator block (2 x 2 MFMA tiles of
+// v_mfma_f32_32x32x16_f16), so no two waves ever add into the same accumulator; the four partial results of a tile meet
+// in the epilogue (through LDS).  K chunk = 16 channels = one MFMA k-step per tap.  LDS rows are 64 B (2 groups x (8 hi |
+// 8 lo)) WITHOUT padding; the 16-byte piece p of row r sits at p ^ ((r >> 2) & 3), which makes every ds_read_b128 lane
+// group (16 rows distinct mod 16) hit 16 distinct bank quads.  V halo brick: [x][TT+KT-1][TH+2][TJ] rows (no halo along
+// w -- it is inside V), single-buffered, the next chunk's pieces requested a few taps before the chunk ends.  Weights:
+// stages of two taps x 4 x x 64 channels (32 KB) double-buffered in LDS, requested two stages ahead into registers in
+// ONE continuous stream across the chunk boundaries (the stream never drains; requests are unconditional because the
+// vmcnt queue retires in order).  One barrier per stage plus one per chunk.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "i2v_conv.h"
+
+namespace i2v {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // (HIP's float4 is a struct: copies through it become memcpys that pin register arrays in scratch)
+
+constexpr int W16_TILES = 128;  // Winograd tiles per workgroup
+constexpr int W16_BN = 64;      // output channels per workgroup
+constexpr int W16_KC = 16;      // input channels per K chunk
+constexpr int W16_SLOTS = 8;    // prefetched 16-byte V pieces per thread and chunk
+constexpr int W16_VROWS = W16_SLOTS * 512 / 4;  // staged V rows (64 B each): the halo brick, padded to 1024 rows
+constexpr int W16_WBUF = 2 * 4 * W16_BN * 64;  // bytes per weight stage buffer: 2 taps x 4 x x 64 rows x 64 B
+
+struct WinoArgs {
+    const char* in;   // V: hl16 [B][T][Cin/16][4][H][J][16 channels = 64 B]
+    const char* wp;   // U: [parity][tap][chunk][4][CoutPad][64 B]
+    const float* bias;
+    const float* res;
+    float* out;       // fp32 channels-last [B][To][H][W][Cout]
+    double* stats;
+    int B, T, H, W, J, Cin, Cout, CoutPad, nchunk;  // T = frames of the INPUT tensor
+    int tdup;
+    long wset_stride;
+    int TT, TH, TJ, nbT, nbH, nbJ;
+    int rt, rs, epi;
+    float oscale;
+    int wofs, tofs;   // LDS byte offsets of the weight buffers / the index tables
+};
+
+template <int NT>  // (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time-slice (1x3x3)
+__global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
+    constexpr int NST = (NT + 1) / 2;  // weight stages (two taps each) per chunk
+    constexpr int KT = NT / 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xi = wave & 3, half = wave >> 2;
+    const int kg = lane >> 5, l31 = lane & 31;
+
+    // tile order / frame-parity placement: as in i2v_conv16.hip (workgroup b runs on XCD b % 8)
+    const unsigned nb_ = gridDim.x;
+    const bool pair_ = a.tdup && (nb_ & 15) == 0;
+    const int par = !a.tdup ? 0 : pair_ ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x >= (nb_ >> 1));
+    const int tile_id = !a.tdup ? (int)blockIdx.x
+                        : pair_ ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)(blockIdx.x % (nb_ >> 1));
+    const int pt = a.tdup ? 1 - par : KT / 2;
+    const int HT = a.TT + KT - 1, HH = a.TH + 2;
+    const int plane = HT * HH * a.TJ;
+    const int NROW = 4 * plane;
+
+    char* v_lds = smem;
+    char* w_lds = smem + a.wofs;
+    int* gpos = reinterpret_cast<int*>(smem + a.tofs);  // [NROW] global V row of every staged row, -1 = zero padding
+    int* tpos = gpos + W16_VROWS;                           // [128] output position of a tile's first column
+    int* tres = tpos + W16_TILES;                       // [128][2] residual rows of the tile's two columns
+
+    const int nNt = a.CoutPad / W16_BN;
+    const int ntile = tile_id % nNt;
+    int brick = tile_id / nNt;
+    const int bj = brick % a.nbJ; brick /= a.nbJ;
+    const int bh = brick % a.nbH; brick /= a.nbH;
+    const int bt = brick % a.nbT; brick /= a.nbT;
+    const int b0 = brick, t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * a.TJ;
+    const int n0 = ntile * W16_BN;
+
+    if (tid < W16_TILES) {
+        int m = tid;
+        const int ij = m % a.TJ; m /= a.TJ;
+        const int ih = m % a.TH; m /= a.TH;
+        const int t = t0 + m, h = h0 + ih, w = 2 * (j0 + ij);
+        const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + par : t;
+        tpos[tid] = ((b0 * To + to) * a.H + h) * a.W + w;
+        const int rbase = ((b0 * (To / a.rt) + to / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs);
+        tres[2 * tid] = rbase + w / a.rs;
+        tres[2 * tid + 1] = rbase + (w + 1) / a.rs;
+    }
+    for (int r = tid; r < W16_VROWS; r += 512) {  // (rows >= NROW: never read, staged as zeros so that no access is conditional)
+        const int x = r / plane;
+        int q = r - x * plane;
+        const int ij = q % a.TJ; q /= a.TJ;
+        const int ih = q % HH; q /= HH;
+        const int t = t0 + q - pt, h = h0 + ih - 1, j = j0 + ij;
+        const bool ok = r < NROW && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H;
+        gpos[r] = ok ? ((((b0 * a.T + t) * a.nchunk * 4 + x) * a.H + h) * a.J + j) : -1;  // chunk 0; 64-byte rows
+    }
+
+    // LDS row of this lane's tile (tap (0,0)) in its x plane, per MFMA row block; B operand byte offsets inside a stage tap
+    int arow[2], boff[2];
+#pragma unroll
+    for (int wm = 0; wm < 2; ++wm) {
+        int m = half * 64 + wm * 32 + l31;
+        const int ij = m % a.TJ; m /= a.TJ;
+        const int ih = m % a.TH; m /= a.TH;
+        arow[wm] = xi * plane + (m * HH + ih) * a.TJ + ij;
+    }
+#pragma unroll
+    for (int wn = 0; wn < 2; ++wn) {
+        const int rb = xi * W16_BN + wn * 32 + l31;
+        boff[wn] = (rb << 6) + ((((kg << 1) ^ ((rb >> 2) & 3))) << 4);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < 2; ++wn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+
+    // weight pieces of a stage: piece f = tid + 512 u (u < 4): tap-in-stage u >> 1, x = (tid >> 8) + 2 (u & 1),
+    // row (tid >> 2) & 63, 16-byte piece tid & 3
+    const long xstride = (long)a.CoutPad * 64;   // bytes per (tap, chunk, x)
+    const long cstride = 4 * xstride;            // per (tap, chunk)
+    const long wtap_stride = (long)a.nchunk * cstride;
+    const int rowq = (tid >> 2) & 63, piece = tid & 3, x0_ = tid >> 8;
+    const int wsrc0 = (int)(x0_ * xstride) + rowq * 64 + piece * 16, wsrc1 = wsrc0 + (int)(2 * xstride);
+    const int wdst0 = ((x0_ * W16_BN + rowq) << 6) + ((piece ^ ((rowq >> 2) & 3)) << 4), wdst1 = wdst0 + ((2 * W16_BN) << 6);
+    const char* wbase = a.wp + (long)par * a.wset_stride + (long)n0 * 64;
+
+    // V staging: piece idx = tid + 512 u (u < 8) -> LDS row (tid >> 2) + 128 u, 16-byte piece tid & 3; the swizzle term
+    // ((row >> 2) & 3) == ((tid >> 4) & 3) does not depend on u, so one base register + immediates address every piece
+    const int vst = ((tid >> 2) << 6) + (((tid & 3) ^ ((tid >> 4) & 3)) << 4);
+    const int* gq = gpos + (tid >> 2);
+    const long vpiece = (long)(tid & 3) * 16;
+    const long vchunk = (long)4 * a.H * a.J * 64;  // bytes between the K chunks of one frame
+    f32x4 vin[W16_SLOTS];
+#define W16_REQUEST_V(ch_)                                                                                           \
+    {                                                                                                                \
+        int gp_[W16_SLOTS];                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u) gp_[u] = gq[128 * u];                                  \
+        const char* vb_ = a.in + (long)(ch_) * vchunk + vpiece;                                                      \
+        _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u) {                                                      \
+            const bool ok = gp_[u] >= 0;                                                                             \
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vb_ + (ok ? (long)gp_[u] * 64 : 0));                     \
+            vin[u] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
+        }                                                                                                            \
+    }
+#define W16_WRITE_V()                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u) *reinterpret_cast<f32x4*>(v_lds + vst + u * 8192) = vin[u];
+
+    struct Ops { half8 ah[2], al[2], bh[2], bl[2]; };
+    Ops o0, o1;
+    // operands of tap TAP (compile-time): A from the V brick, B from tap slot TIS of weight buffer WB
+#define W16_LOAD_OPS(o, TAP, WB, TIS)                                                                                \
+    {                                                                                                                \
+        const int d_ = (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ;                                                      \
+        _Pragma("unroll") for (int wm = 0; wm < 2; ++wm) {                                                           \
+            const int r_ = arow[wm] + d_;                                                                            \
+            const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                        \
+            (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                               \
+            (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int wn = 0; wn < 2; ++wn) {                                                           \
+            const int bd_ = (TIS) * (4 * W16_BN * 64) + boff[wn];                                                    \
+            (o).bh[wn] = *reinterpret_cast<const half8*>((WB) + bd_);                                                \
+            (o).bl[wn] = *reinterpret_cast<const half8*>((WB) + (bd_ ^ 16));                                         \
+        }                                                                                                            \
+    }
+#define W16_MFMA(o)                                                                                                  \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < 2; ++wm) _Pragma("unroll") for (int wn = 0; wn < 2; ++wn)            \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+        _Pragma("unroll") for (int wm = 0; wm < 2; ++wm) _Pragma("unroll") for (int wn = 0; wn < 2; ++wn)            \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bl[wn], acc[wm][wn], 0, 0, 0);      \
+        _Pragma("unroll") for (int wm = 0; wm < 2; ++wm) _Pragma("unroll") for (int wn = 0; wn < 2; ++wn)            \
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+    }
+
+    // weight stream: stage (chunk rq_ch, stage rq_st) is the next one to request; it stops at the last stage (a harmless
+    // re-request) so that every request stays unconditional
+    int rq_ch = 0, rq_st = 0;
+    struct W4 { f32x4 a, b, c, d; };
+    W4 wr0, wr1;
+#define W16_REQUEST_W(WR)                                                                                            \
+    {                                                                                                                \
+        const int tb_ = rq_st * 2 + 1 < NT ? rq_st * 2 + 1 : NT - 1;                                                 \
+        const char* pa_ = wbase + (long)rq_ch * cstride + (long)(rq_st * 2) * wtap_stride;                           \
+        const char* pb_ = wbase + (long)rq_ch * cstride + (long)tb_ * wtap_stride;                                   \
+        WR.a = *reinterpret_cast<const f32x4*>(pa_ + wsrc0);                                                         \
+        WR.b = *reinterpret_cast<const f32x4*>(pa_ + wsrc1);                                                         \
+        WR.c = *reinterpret_cast<const f32x4*>(pb_ + wsrc0);                                                         \
+        WR.d = *reinterpret_cast<const f32x4*>(pb_ + wsrc1);                                                         \
+        if (rq_st + 1 < NST) ++rq_st;                                                                                \
+        else if (rq_ch + 1 < a.nchunk) { rq_st = 0; ++rq_ch; }                                                       \
+    }
+#define W16_PARK_W(WR, dst)                                                                                          \
+    {                                                                                                                \
+        *reinterpret_cast<f32x4*>((dst) + wdst0) = WR.a;                                                             \
+        *reinterpret_cast<f32x4*>((dst) + wdst1) = WR.b;                                                             \
+        *reinterpret_cast<f32x4*>((dst) + 4 * W16_BN * 64 + wdst0) = WR.c;                                           \
+        *reinterpret_cast<f32x4*>((dst) + 4 * W16_BN * 64 + wdst1) = WR.d;                                           \
+    }
+
+    __syncthreads();  // tables
+    W16_REQUEST_V(0)
+    W16_REQUEST_W(wr0)   // stage 0: straight to LDS below
+    W16_WRITE_V()
+    W16_PARK_W(wr0, w_lds)
+    W16_REQUEST_W(wr0)   // stage 1
+    W16_REQUEST_W(wr1)   // stage 2
+    __syncthreads();
+    W16_LOAD_OPS(o0, 0, w_lds, 0)
+
+    // One stage = the two taps 2 ST, 2 ST + 1 of the current chunk (the last stage of a 9-tap chunk holds one).  Stage g
+    // of the stream (over all chunks) reads weight buffer g & 1; register set g & 1 holds the weights of stage g + 1,
+    // requested two stages ago (under load a request takes longer than one stage): park them in the other buffer -- its
+    // readers finished before the previous barrier -- and request stage g + 3.  The operands of the following tap are
+    // read from LDS while the current tap's 12 MFMAs run; the stage's barrier publishes the parked weights.  The last
+    // stage of a chunk also swaps the V brick: barrier (all reads of the old brick done), write, MFMAs, barrier.
+    // The loop body is a PAIR of chunks (the chunk count is even): with an odd stage count per chunk the buffer /
+    // register-set roles flip from chunk to chunk, and everything stays compile-time and branch-free (after the last
+    // chunk the V write and the operand read repeat harmlessly).
+    constexpr int PFST = NST >= 3 ? NST - 3 : 0;
+#define W16_STAGE(ST, BP, WR, CH)                                                                                    \
+    {                                                                                                                \
+        constexpr int tA_ = 2 * (ST), tB_ = 2 * (ST) + 1;                                                            \
+        constexpr bool hasB_ = tB_ < NT, last_ = (ST) == NST - 1;                                                    \
+        static_assert(last_ || hasB_, "only the last stage of a chunk may hold a single tap");                       \
+        const char* wb_ = w_lds + (BP) * W16_WBUF;                                                                   \
+        char* wn_ = w_lds + (1 - (BP)) * W16_WBUF;                                                                   \
+        /* keep the per-tap operand addresses from being hoisted out of the chunk loop (54 registers) */            \
+        asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(boff[0]), "+v"(boff[1]));                               \
+        W16_PARK_W(WR, wn_)                                                                                          \
+        W16_REQUEST_W(WR)                                                                                            \
+        if constexpr ((ST) == PFST) W16_REQUEST_V((CH) + 1 < a.nchunk ? (CH) + 1 : (CH))                             \
+        if constexpr (hasB_) {                                                                                       \
+            W16_LOAD_OPS(o1, tB_, wb_, 1)                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            W16_MFMA(o0)                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        __syncthreads();                                                                                             \
+        if constexpr (!last_) {                                                                                      \
+            W16_LOAD_OPS(o0, tA_ + 2, wn_, 0)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            W16_MFMA(o1)                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        } else {                                                                                                     \
+            W16_WRITE_V()                                                                                            \
+            if constexpr (hasB_) W16_MFMA(o1) else W16_MFMA(o0)                                                      \
+            __syncthreads();                                                                                         \
+            W16_LOAD_OPS(o0, 0, wn_, 0)                                                                              \
+        }                                                                                                            \
+    }
+#define W16_CHUNK(P, Q, CH)                                                                                          \
+    {                                                                                                                \
+        W16_STAGE(0, P, wr##P, CH)                                                                                   \
+        if constexpr (NST > 1) W16_STAGE(1, Q, wr##Q, CH)                                                            \
+        if constexpr (NST > 2) W16_STAGE(2, P, wr##P, CH)                                                            \
+        if constexpr (NST > 3) W16_STAGE(3, Q, wr##Q, CH)                                                            \
+        if constexpr (NST > 4) W16_STAGE(4, P, wr##P, CH)                                                            \
+    }
+    for (int ch = 0; ch < a.nchunk; ch += 2) {
+        W16_CHUNK(0, 1, ch)
+        if constexpr (NST & 1) W16_CHUNK(1, 0, ch + 1) else W16_CHUNK(0, 1, ch + 1)
+    }
+
+    // ---- epilogue: the four partial GEMMs of a tile meet in LDS; y0 = M0 + M1 + M2, y1 = M1 - M2 - M3
+    __syncthreads();
+    float* E = reinterpret_cast<float*>(smem);  // [4][128 tiles][64 channels]
+#pragma unroll
+    for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < 2; ++wn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = half * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                E[(xi * W16_TILES + m) * W16_BN + wn * 32 + l31] = acc[wm][wn][r];
+            }
+    __syncthreads();
+    const int n4 = tid & 15;
+    const int n = n0 + 4 * n4;
+    const bool ncol = n < a.Cout;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias && ncol) bias = *reinterpret_cast<const float4*>(a.bias + n);
+    double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int tile = (tid >> 4) + 32 * it;
+        const float4 m0 = *reinterpret_cast<const float4*>(E + (0 * W16_TILES + tile) * W16_BN + 4 * n4);
+        const float4 m1 = *reinterpret_cast<const float4*>(E + (1 * W16_TILES + tile) * W16_BN + 4 * n4);
+        const float4 m2 = *reinterpret_cast<const float4*>(E + (2 * W16_TILES + tile) * W16_BN + 4 * n4);
+        const float4 m3 = *reinterpret_cast<const float4*>(E + (3 * W16_TILES + tile) * W16_BN + 4 * n4);
+        if (!ncol) continue;
+        const long p = tpos[tile];
+        float y[2][4] = {{m0.x + m1.x + m2.x, m0.y + m1.y + m2.y, m0.z + m1.z + m2.z, m0.w + m1.w + m2.w},
+                         {m1.x - m2.x - m3.x, m1.y - m2.y - m3.y, m1.z - m2.z - m3.z, m1.w - m2.w - m3.w}};
+        const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.res) {
+                const float4 r4 = *reinterpret_cast<const float4*>(a.res + (long)tres[2 * tile + c] * a.Cout + n);
+                rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+            }
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = fmaf(y[c][j], a.oscale, bv[j]) + rv[j];
+                ssum[j] += (double)v[j];
+                ssq[j] = fma((double)v[j], (double)v[j], ssq[j]);
+                if (a.epi & EPI_LRELU) v[j] = v[j] >= 0.f ? v[j] : 0.2f * v[j];
+            }
+            *reinterpret_cast<float4*>(a.out + (p + c) * a.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    if (a.stats) {
+        // fused normalisation statistics.  Lanes l, l^16, l^32, l^48 hold the same four channels -> wavefront shuffles;
+        // the eight waves' partials meet in LDS and ONE wave issues the workgroup's 128 fp64 atomics (2 instructions
+        // covering 8 cache lines each): all workgroups of a sample hit the same few lines of one L2 channel, and the
+        // atomic unit's cost is per (instruction, line) -- per-wave atomics (512 line requests per workgroup) cost
+        // 1.2 ms per launch at B = 8.  fp64 partials keep the totals independent of the tiling.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ssum[j] += __shfl_xor(ssum[j], 16);
+            ssq[j] += __shfl_xor(ssq[j], 16);
+            ssum[j] += __shfl_xor(ssum[j], 32);
+            ssq[j] += __shfl_xor(ssq[j], 32);
+        }
+        __syncthreads();  // E is free
+        double* S = reinterpret_cast<double*>(smem);  // [8 waves][64 channels][2]
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                S[(wave * W16_BN + 4 * lane + j) * 2] = ssum[j];
+                S[(wave * W16_BN + 4 * lane + j) * 2 + 1] = ssq[j];
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && n0 + lane < a.Cout) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                s0 += S[(w * W16_BN + lane) * 2];
+                s1 += S[(w * W16_BN + lane) * 2 + 1];
+            }
+            double* dst = a.stats + ((long)b0 * a.Cout + n0 + lane) * 2;
+            atomicAdd(dst, s0);
+            atomicAdd(dst + 1, s1);
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+
+// w3: [nset][Cout][Cin][KT][3][3] already multiplied by `scale`-free fp64 pre-sums; packs U = G g per (kt, kh).
+static int wino_pack_sets(Wino16Weights& o, const std::vector<double>& w3, int nset, int cout, int cin, int kt) {
+    o.Cin = cin; o.Cout = cout; o.KT = kt;
+    o.CoutPad = (cout + W16_BN - 1) / W16_BN * W16_BN;
+    o.nchunk = cin / W16_KC;
+    const int NT = kt * 3;
+    std::vector<double> u((size_t)nset * cout * cin * NT * 4);
+    double wmax = 0.0;
+    for (size_t i = 0; i < (size_t)nset * cout * cin * NT; ++i) {
+        const double g0 = w3[i * 3], g1 = w3[i * 3 + 1], g2 = w3[i * 3 + 2];
+        double* d = &u[i * 4];
+        d[0] = g0; d[1] = 0.5 * (g0 + g1 + g2); d[2] = 0.5 * (g0 - g1 + g2); d[3] = g2;
+        for (int x = 0; x < 4; ++x) wmax = std::max(wmax, std::fabs(d[x]));
+    }
+    o.wexp = 0;
+    if (wmax > 0.0 && std::isfinite(wmax)) o.wexp = std::max(-40, std::min(40, (int)std::floor(std::log2(16384.0 / wmax))));
+    const double pre = std::ldexp(1.0, o.wexp);
+    const size_t set_halfs = (size_t)NT * o.nchunk * 4 * o.CoutPad * 32;
+    std::vector<_Float16> p((size_t)nset * set_halfs, (_Float16)0.f);
+    for (int s = 0; s < nset; ++s)
+        for (int n = 0; n < cout; ++n)
+            for (int c = 0; c < cin; ++c)
+                for (int tap = 0; tap < NT; ++tap)
+                    for (int x = 0; x < 4; ++x) {
+                        const float v = (float)(u[((((size_t)s * cout + n) * cin + c) * NT + tap) * 4 + x] * pre);
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        const int chunk = c / W16_KC, g = (c % W16_KC) / 8, j = c % 8;
+                        _Float16* row = &p[s * set_halfs + ((((size_t)tap * o.nchunk + chunk) * 4 + x) * o.CoutPad + n) * 32];
+                        row[g * 16 + j] = hi;
+                        row[g * 16 + 8 + j] = lo;
+                    }
+    o.set_bytes = (long)set_halfs * 2;
+    return o.w.upload(p.data(), p.size() * 2);
+}
+
+bool wino16_supported(int cout, int cin, int T, int H, int W) {
+    if (cout % W16_BN || cin % (2 * W16_KC) || W % 8 || H < 8) return false;  // (the kernel's loop body is a chunk pair)
+    return (long)T * H * (W / 2) >= W16_TILES;
+}
+
+int Wino16Weights::pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, double scale) {
+    I2V_REQUIRE(kt == 3 || kt == 1, I2V_E_INVALID, "wino16: temporal kernel size %d", kt);
+    tdup = false;
+    std::vector<double> w3((size_t)cout * cin * kt * 9);
+    for (size_t i = 0; i < w3.size(); ++i) w3[i] = (double)w_src[i] * scale;
+    int rc = wino_pack_sets(*this, w3, 1, cout, cin, kt);
+    if (rc) return rc;
+    if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
+    bias.release();
+    return I2V_OK;
+}
+
+int Wino16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale) {
+    // parity 0 = (W[0], W[1]+W[2]), parity 1 = (W[0]+W[1], W[2]) along time (see Conv16Weights::pack_tdup)
+    std::vector<double> w3((size_t)2 * cout * cin * 18);
+    for (int par = 0; par < 2; ++par)
+        for (size_t nc = 0; nc < (size_t)cout * cin; ++nc)
+            for (int hw = 0; hw < 9; ++hw) {
+                const double w0 = w_src[nc * 27 + hw], w1 = w_src[nc * 27 + 9 + hw], w2 = w_src[nc * 27 + 18 + hw];
+                double* dst = &w3[((size_t)par * cout * cin + nc) * 18];
+                dst[hw] = (par == 0 ? w0 : w0 + w1) * scale;
+                dst[9 + hw] = (par == 0 ? w1 + w2 : w2) * scale;
+            }
+    tdup = true;
+    int rc = wino_pack_sets(*this, w3, 2, cout, cin, 2);
+    if (rc) return rc;
+    if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
+    bias.release();
+    return I2V_OK;
+}
+
+template <int NT>
+static int launch_wino(const WinoArgs& a, unsigned nblk, size_t lds, hipStream_t st) {
+    auto kern = conv_wino_f16x3_kernel<NT>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    I2V_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(512), lds, st, a);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T,
+                   int H, int W, int epi, hipStream_t st, double* stats) {
+    I2V_REQUIRE(wts.w.p, I2V_E_STATE, "wino16: weights not packed");
+    I2V_REQUIRE((epi & ~EPI_LRELU) == 0, I2V_E_INVALID, "wino16: unsupported epilogue %d", epi);
+    WinoArgs a{};
+    a.in = static_cast<const char*>(v_hl16); a.wp = wts.w.as<char>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
+    a.stats = stats;
+    a.B = B; a.H = H; a.W = W; a.J = W / 2; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
+    a.tdup = wts.tdup ? 1 : 0;
+    a.wset_stride = wts.set_bytes;
+    if (wts.tdup) {  // T is the OUTPUT frame count; the half-rate input has T / 2 frames
+        I2V_REQUIRE(T % 2 == 0 && !res, I2V_E_INVALID, "wino16: temporal-duplication mode needs an even frame count and no residual");
+        T /= 2;
+    }
+    a.T = T;
+    I2V_REQUIRE(wino16_supported(wts.Cout, wts.Cin, T, H, W), I2V_E_INVALID, "wino16: unsupported shape [%d,%d,%d] %d -> %d", T, H, W,
+                wts.Cin, wts.Cout);
+    a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
+    a.oscale = (float)std::ldexp(1.0, -wts.wexp);
+    // brick: TT x TH x TJ tiles = 128, TH * TJ a multiple of 32 (an MFMA row block = consecutive LDS rows of one frame)
+    const int J = W / 2;
+    int TT = 1;
+    while (TT < 4 && T % (TT * 2) == 0) TT *= 2;
+    int TJ = 4, TH = W16_TILES / (TT * TJ);
+    while (TH > H || H % TH) {  // small maps: widen the brick along w instead
+        TJ *= 2; TH /= 2;
+        I2V_REQUIRE(TH >= 1 && TJ <= J && J % TJ == 0, I2V_E_INVALID, "wino16: cannot tile [T=%d,H=%d,W=%d]", T, H, W);
+    }
+    I2V_REQUIRE(J % TJ == 0 && TH * TJ % 32 == 0 && TT * TH * TJ == W16_TILES, I2V_E_INVALID, "wino16: cannot tile [T=%d,H=%d,W=%d]", T, H, W);
+    const int KT = wts.KT;
+    const int nrow = 4 * (TT + KT - 1) * (TH + 2) * TJ;
+    I2V_REQUIRE(nrow <= W16_VROWS, I2V_E_INVALID, "wino16: halo brick of %d rows", nrow);
+    a.TT = TT; a.TH = TH; a.TJ = TJ; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = J / TJ;
+    a.wofs = W16_VROWS * 64;
+    const int body = std::max(a.wofs + 2 * W16_WBUF, 4 * W16_TILES * W16_BN * 4);
+    a.tofs = body;
+    const size_t lds = (size_t)body + (size_t)W16_VROWS * 4 + W16_TILES * 12;
+    I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino16: LDS %zu bytes", lds);
+    I2V_REQUIRE(!stats || (long)TT * TH * TJ <= (long)T * H * J, I2V_E_INVALID, "wino16: fused statistics need bricks inside one sample");
+    const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / W16_BN);
+    I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino16: grid of %ld workgroups", nblk);
+    if (KT == 3) return launch_wino<9>(a, (unsigned)nblk, lds, st);
+    if (KT == 2) return launch_wino<6>(a, (unsigned)nblk, lds, st);
+    return launch_wino<3>(a, (unsigned)nblk, lds, st);
+}
+
+}  // namespace i2v

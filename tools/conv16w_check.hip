@@ -1,0 +1,163 @@
+// Stand-alone check + benchmark of the Winograd split-fp16 conv kernel (csrc/i2v_conv16w.hip) against the direct
+// split-fp16 kernel (csrc/i2v_conv16.hip) on one layer shape.
+//   conv16w_check B T H W Cin Cout tdup res      (T = output frames; tdup: conv_0 behind a x2 temporal up-sampling)
+// Build: hipcc -O3 --offload-arch=gfx950 -I<csrc> tools/conv16w_check.hip <csrc>/i2v_conv16w.hip <csrc>/i2v_conv16.hip
+//        <csrc>/i2v_common.hip -o tools/conv16w_check
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "i2v_conv.h"
+
+using namespace i2v;
+
+static inline void split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 2, T = argc > 2 ? atoi(argv[2]) : 16, H = argc > 3 ? atoi(argv[3]) : 64,
+              W = argc > 4 ? atoi(argv[4]) : 64, Cin = argc > 5 ? atoi(argv[5]) : 256, Cout = argc > 6 ? atoi(argv[6]) : 128;
+    const int tdup = argc > 7 ? atoi(argv[7]) : 0, use_res = argc > 8 ? atoi(argv[8]) : 0, nostats = argc > 9 ? atoi(argv[9]) : 0;
+    const int Ti = tdup ? T / 2 : T, J = W / 2;
+    std::vector<float> w((size_t)Cout * Cin * 27), bias(Cout);
+    srand(1);
+    for (auto& v : w) v = (rand() / (float)RAND_MAX - 0.5f) * 0.05f;
+    for (auto& v : bias) v = rand() / (float)RAND_MAX - 0.5f;
+    Conv16Weights cw;
+    Wino16Weights ww;
+    int rc = tdup ? cw.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : cw.pack(w.data(), bias.data(), Cout, Cin, 3, 3, 3, 0.7);
+    if (rc) { printf("pack16: %s\n", i2v_last_error()); return 1; }
+    rc = tdup ? ww.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : ww.pack(w.data(), bias.data(), Cout, Cin, 3, 0.7);
+    if (rc) { printf("packw: %s\n", i2v_last_error()); return 1; }
+    if (!wino16_supported(Cout, Cin, Ti, H, W)) { printf("shape not supported by the Winograd kernel\n"); return 1; }
+
+    const size_t npi = (size_t)B * Ti * H * W, npo = (size_t)B * T * H * W;
+    std::vector<float> a(npi * Cin);
+    for (auto& v : a) {
+        v = (rand() / (float)RAND_MAX - 0.3f) * 2.f;
+        if (v < 0) v *= 0.2f;  // leaky-relu-like distribution
+    }
+    std::vector<_Float16> hl(npi * Cin * 2), V((size_t)B * Ti * H * J * 4 * Cin * 2);
+    for (size_t p = 0; p < npi; ++p)
+        for (int c = 0; c < Cin; ++c) {
+            _Float16 hi, lo;
+            split(a[p * Cin + c], hi, lo);
+            hl[p * Cin * 2 + (c >> 3) * 16 + (c & 7)] = hi;
+            hl[p * Cin * 2 + (c >> 3) * 16 + 8 + (c & 7)] = lo;
+        }
+    for (size_t row = 0; row < (size_t)B * Ti * H; ++row)
+        for (int j = 0; j < J; ++j)
+            for (int c = 0; c < Cin; ++c) {
+                float d[4];
+                for (int k = 0; k < 4; ++k) {
+                    const int wq = 2 * j - 1 + k;
+                    d[k] = (wq >= 0 && wq < W) ? a[(row * W + wq) * Cin + c] : 0.f;
+                }
+                const float v[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+                for (int x = 0; x < 4; ++x) {
+                    _Float16 hi, lo;
+                    split(v[x], hi, lo);
+                    // [B][T][Cin/16][4][H][J][32 halfs]
+                    const size_t bt = row / H, h = row % H;
+                    _Float16* dst = &V[((((bt * (Cin / 16) + c / 16) * 4 + x) * H + h) * J + j) * 32];
+                    dst[((c & 15) >> 3) * 16 + (c & 7)] = hi;
+                    dst[((c & 15) >> 3) * 16 + 8 + (c & 7)] = lo;
+                }
+            }
+    std::vector<float> res;
+    if (use_res) {
+        res.resize(npo * Cout);
+        for (auto& v : res) v = rand() / (float)RAND_MAX - 0.5f;
+    }
+    void *dhl, *dV;
+    float *o0, *o1, *dres = nullptr;
+    double *s0, *s1;
+    hipMalloc(&dhl, hl.size() * 2);
+    hipMalloc(&dV, V.size() * 2);
+    hipMalloc(&o0, npo * Cout * 4);
+    hipMalloc(&o1, npo * Cout * 4);
+    hipMalloc(&s0, (size_t)B * Cout * 16);
+    hipMalloc(&s1, (size_t)B * Cout * 16);
+    hipMemcpy(dhl, hl.data(), hl.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dV, V.data(), V.size() * 2, hipMemcpyHostToDevice);
+    if (use_res) {
+        hipMalloc(&dres, res.size() * 4);
+        hipMemcpy(dres, res.data(), res.size() * 4, hipMemcpyHostToDevice);
+    }
+    hipMemset(o1, 0xff, npo * Cout * 4);
+    hipMemset(s0, 0, (size_t)B * Cout * 16);
+    hipMemset(s1, 0, (size_t)B * Cout * 16);
+    const bool fuse = !nostats && conv16_can_fuse_stats(Ti, H, W);
+    if (conv16_forward(cw, dhl, o0, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, fuse ? s0 : nullptr)) { printf("conv16: %s\n", i2v_last_error()); return 1; }
+    if (wino16_forward(ww, dV, o1, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s1)) { printf("wino16: %s\n", i2v_last_error()); return 1; }
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+    std::vector<float> h0(npo * Cout), h1(npo * Cout);
+    std::vector<double> hs0((size_t)B * Cout * 2), hs1((size_t)B * Cout * 2);
+    hipMemcpy(h0.data(), o0, h0.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(h1.data(), o1, h1.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(hs0.data(), s0, hs0.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hs1.data(), s1, hs1.size() * 8, hipMemcpyDeviceToHost);
+    double num = 0, den = 0, mx = 0;
+    size_t bad = 0;
+    for (size_t i = 0; i < h0.size(); ++i) {
+        const double d = (double)h1[i] - h0[i];
+        if (!(std::fabs(d) < 1e30)) { ++bad; continue; }
+        num += d * d; den += (double)h0[i] * h0[i];
+        mx = std::max(mx, std::fabs(d));
+    }
+    double smx = 0;
+    if (fuse)
+        for (size_t i = 0; i < hs0.size(); ++i) smx = std::max(smx, std::fabs(hs1[i] - hs0[i]) / (std::fabs(hs0[i]) + 1.0));
+    // exact fp64 reference on a sample of outputs
+    double rnum = 0, rden = 0;
+    for (int s = 0; s < 400; ++s) {
+        const size_t p = ((size_t)rand() * 7919u + s) % npo;
+        const int n = rand() % Cout;
+        size_t q = p;
+        const int wq = q % W; q /= W;
+        const int hq = q % H; q /= H;
+        const int tq = q % T; q /= T;
+        const int b = (int)q;
+        double ref = bias[n];
+        for (int kt = 0; kt < 3; ++kt)
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int t = tq + kt - 1, h = hq + kh - 1, ww_ = wq + kw - 1;
+                    if (t < 0 || t >= T || h < 0 || h >= H || ww_ < 0 || ww_ >= W) continue;
+                    const int ti = tdup ? t / 2 : t;
+                    const float* ap = &a[((((size_t)b * Ti + ti) * H + h) * W + ww_) * Cin];
+                    for (int c = 0; c < Cin; ++c) ref += (double)ap[c] * (double)w[((size_t)n * Cin + c) * 27 + kt * 9 + kh * 3 + kw] * 0.7;
+                }
+        if (use_res) ref += res[p * Cout + n];
+        const double d = h1[p * Cout + n] - ref;
+        rnum += d * d; rden += ref * ref;
+    }
+    printf("[B=%d,T=%d,%dx%d] %d -> %d tdup=%d res=%d: wino vs direct rel-L2 %.3e max|d| %.3e nonfinite %zu  stats rel %.2e | wino vs fp64 (400 samples) rel-L2 %.3e\n",
+           B, T, H, W, Cin, Cout, tdup, use_res, std::sqrt(num / (den + 1e-30)), mx, bad, smx, std::sqrt(rnum / (rden + 1e-30)));
+
+    const double flops = 2.0 * npo * Cin * Cout * 27.0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int n = 5;
+    for (int which = 0; which < 2; ++which) {
+        for (int it = 0; it < 2; ++it) {
+            if (which) wino16_forward(ww, dV, o1, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s1);
+            else conv16_forward(cw, dhl, o0, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, fuse ? s0 : nullptr);
+        }
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int it = 0; it < n; ++it) {
+            if (which) wino16_forward(ww, dV, o1, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s1);
+            else conv16_forward(cw, dhl, o0, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, fuse ? s0 : nullptr);
+        }
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        ms /= n;
+        printf("   %-8s %8.3f ms  %7.1f TFLOP/s algorithmic\n", which ? "winograd" : "direct", ms, flops / ms / 1e9);
+    }
+    return 0;
+}
