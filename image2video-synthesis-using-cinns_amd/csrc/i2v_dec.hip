@@ -171,6 +171,101 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
     }
 }
 
+// The same modulation, written as the Winograd-transformed operand V = B^T d of i2v_conv16w.hip:
+//   V[b][t][c/16][x][h][j][c%16]  (hl16: per 8 channels 8 x fp16 hi | 8 x fp16 lo),  j = output pair (w = 2j, 2j+1),
+//   V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3,  d_k = act(...)[t][h][2j-1+k]  (0 outside the row).
+// One thread = one (h, j, 8-channel group), looping over the frames like modulate_kernel; every activation is evaluated by
+// the two pairs that use it (the kernel is bound by its 2x larger output, not by the FMAs).  Thread order: channel group
+// within a 32-channel (128-byte) input line fastest, then j -- a wave reads whole input lines and writes 1 KB runs of V.
+__global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
+                                                            const float* __restrict__ gb, char* __restrict__ out, int T, int H,
+                                                            int W, int C, int ut, int us, int lrelu) {
+    const int C8 = C >> 3, J = W >> 1;
+    const int b = blockIdx.y;
+    const int per = H * J * C8;  // threads per sample
+    const int Hl = H / us, Wl = W / us, Tl = T / ut;
+    const float2* cp0 = coef + (long)b * C;
+    const float* xb = x + (long)b * Tl * Hl * Wl * C;
+    const float* gbb = gb ? gb + (long)b * H * W * 2 * C : nullptr;
+    const int nchunk = C >> 4;
+    const long xstride = (long)Hl * Wl * C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+        // i = ((h * (C8/4) + c32) * J + j) * 4 + c8lo   (C8 % 4 == 0: channels are a multiple of 32)
+        const int c8lo = i & 3;
+        int q = i >> 2;
+        const int j = q % J; q /= J;
+        const int c32 = q % (C8 >> 2);
+        const int h = q / (C8 >> 2);
+        const int c8 = c32 * 4 + c8lo;
+        float ca[8], cb[8];
+        {
+            const float4* cp = reinterpret_cast<const float4*>(cp0 + 8 * c8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 ab = cp[k];
+                ca[2 * k] = ab.x; cb[2 * k] = ab.y; ca[2 * k + 1] = ab.z; cb[2 * k + 1] = ab.w;
+            }
+        }
+        // per-position affine (SPADE's gamma / beta depend on (h, w)); positions outside the row contribute d = 0
+        float pa[4][8], pb[4][8];
+        const float* xp[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int w = 2 * j - 1 + k;
+            ok[k] = w >= 0 && w < W;
+            const int wc = ok[k] ? w : 0;
+            xp[k] = xb + ((long)(h / us) * Wl + wc / us) * C + 8 * c8;
+            if (gbb) {
+                const float* g = gbb + ((long)h * W + wc) * (2 * C) + 8 * c8;
+                const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
+                const float4 e0 = *reinterpret_cast<const float4*>(g + C), e1 = *reinterpret_cast<const float4*>(g + C + 4);
+                const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { pb[k][c] = fmaf(cb[c], ga[c], be[c]); pa[k][c] = ca[c] * ga[c]; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { pa[k][c] = ca[c]; pb[k][c] = cb[c]; }
+            }
+        }
+        float d[4][8];
+        // V row of (t, chunk, x, h, j): 64 bytes; this thread owns the 32-byte half (c8 & 1)
+        char* ob = out + ((((long)b * T * nchunk + (c8 >> 1)) * 4 * H + h) * J + j) * 64 + (c8 & 1) * 32;
+        const long ostride_x = (long)H * J * 64, ostride_t = (long)nchunk * 4 * ostride_x;
+        for (int t = 0; t < T; ++t) {
+            if (t % ut == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* p = xp[k] + (long)(t / ut) * xstride;
+                    const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+                    const float r0[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float r = fmaf(r0[c], pa[k][c], pb[k][c]);
+                        if (lrelu) r = r >= 0.f ? r : 0.2f * r;
+                        d[k][c] = ok[k] ? r : 0.f;
+                    }
+                }
+            }
+            char* o = ob + (long)t * ostride_t;
+#pragma unroll
+            for (int xq = 0; xq < 4; ++xq) {
+                half8_t hi, lo;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float v = xq == 0 ? d[0][c] - d[2][c] : xq == 1 ? d[1][c] + d[2][c] : xq == 2 ? d[2][c] - d[1][c] : d[1][c] - d[3][c];
+                    const _Float16 hh = (_Float16)v;
+                    hi[c] = hh;
+                    lo[c] = (_Float16)(v - (float)hh);
+                }
+                *reinterpret_cast<half8_t*>(o + xq * ostride_x) = hi;
+                *reinterpret_cast<half8_t*>(o + xq * ostride_x + 16) = lo;
+            }
+        }
+    }
+}
+
 // F.interpolate(img, size=(h,w), mode='bilinear', align_corners=True) (normalization_layer.py:20), written
 // channels-last with the 3 colour channels zero-padded to 16 (the conv kernel's K chunk).
 __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
@@ -243,6 +338,8 @@ struct Block {
     ConvWeights conv0, conv1, convs, sp_conv, sp_gb;
     Conv16Weights sp_conv16;  // SPADE's Conv2d(3, 128, 3) with the 3 input channels zero-padded to 8 (split-fp16 mode)
     Conv16Weights conv0_16, conv1_16, sp_gb16;  // split-fp16 variants (cfg.mma == 1)
+    Wino16Weights conv0_w, conv1_w;             // Winograd F(2,3) variants of conv_0 / conv_1 (packed where the shape allows)
+    bool tdup0 = false;                          // conv_0 runs on the half-rate tensor (x2 temporal up-sampling in front)
     DevBuf gn_w, gn_b;
     int zoff = 0;  // offset of this block's ADAIN (gamma|beta) in the z-GEMM output
 };
@@ -260,6 +357,7 @@ struct i2v_dec {
     ConvWeights fc, zlin, conv_img;
     ConvImgWeights conv_img_v;  // vector-ALU variant (used when the output geometry tiles into 4x8x8 bricks)
     int Nz = 0;
+    int wino = 1;  // 1: 3x3x3 convs whose shape allows it use the Winograd kernel (env I2V_DEC_WINO=0 disables)
     int profile = 0;
     struct ProfEv { hipEvent_t e0, e1; double flops, exec_flops; };
     std::vector<ProfEv> prof_events;
@@ -277,6 +375,9 @@ struct DecWs {
     size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, total;
 };
 
+bool want_wino0(const i2v_dec* d, const Block& b, const Level& l);
+bool want_wino1(const i2v_dec* d, const Block& b, const Level& l);
+
 DecWs dec_ws(const i2v_dec* d, int B) {
     size_t mx_x = (size_t)16 * d->blk[0].n_in, mx_a = 0, mx_dx = 0, mx_xsin = 0, mx_xslow = 0, mx_y = 0, mx_gb = 0;
     int cmax = 0;
@@ -285,7 +386,9 @@ DecWs dec_ws(const i2v_dec* d, int B) {
         const Level& l = d->lvl[k];
         const size_t P = (size_t)l.T * l.H * l.W, Pl = P / ((size_t)l.ut * l.us * l.us);
         mx_x = std::max(mx_x, P * b.n_out);
-        mx_a = std::max(mx_a, P * std::max(b.n_in, b.n_mid));
+        // conv operands: hl16 (4 B per element), or the Winograd operand V (4 values per output pair: 8 B per element)
+        mx_a = std::max(mx_a, P * b.n_in * (want_wino0(d, b, l) ? 2 : 1));
+        mx_a = std::max(mx_a, P * b.n_mid * (want_wino1(d, b, l) ? 2 : 1));
         mx_dx = std::max(mx_dx, P * b.n_mid);
         if (b.learned) { mx_xsin = std::max(mx_xsin, Pl * b.n_in); mx_xslow = std::max(mx_xslow, Pl * b.n_out); }
         mx_y = std::max(mx_y, (size_t)l.H * l.W);
@@ -344,6 +447,18 @@ int run_modulate(const float* x, const float* coef, const float* gb, float* out,
     return I2V_OK;
 }
 
+int run_modulate_wino(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
+                      int us, int lrelu, hipStream_t st) {
+    I2V_REQUIRE(C % 32 == 0 && W % 2 == 0, I2V_E_INVALID, "modulate (Winograd operand): channels %d / width %d", C, W);
+    const long per = (long)H * (W / 2) * (C / 8);
+    I2V_REQUIRE(per * T * 4 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
+    const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
+    hipLaunchKernelGGL(modulate_wino_kernel, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
+                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
 // Brackets one 3x3x3 conv launch with HIP events on the launch stream WITHOUT synchronising; the pairs are
 // resolved later by i2v_dec_get_profile (after the caller has synchronised the stream).
 struct ProfScope {
@@ -380,6 +495,26 @@ int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* ou
     ProfScope ps(d, st, fl, 3.0 * fl * (w.tdup ? 18.0 / 27.0 : 1.0));
     return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats);
 }
+
+int conv3_w(i2v_dec* d, const Wino16Weights& w, const float* v_hl16, float* out, const float* res, int rt, int rs, int B,
+            const Level& l, int epi, hipStream_t st, double* stats = nullptr) {
+    if (stats) I2V_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * w.Cout * 16, st));
+    // matrix-core FLOPs issued: 4 Winograd products per 2 outputs x 3 kw taps (x 2/3), 3 fp16 MFMAs each, 18 of 27 taps in
+    // temporal-duplication mode
+    const double fl = 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0;
+    ProfScope ps(d, st, fl, 3.0 * fl * (2.0 / 3.0) * (w.tdup ? 18.0 / 27.0 : 1.0));
+    return wino16_forward(w, v_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats);
+}
+
+// which kernel conv_0 / conv_1 of a block use at this geometry (want_*: by shape; use_*: and the weights are packed for it)
+bool want_wino0(const i2v_dec* d, const Block& b, const Level& l) {
+    return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_mid, b.n_in, l.ut == 2 ? l.T / 2 : l.T, l.H, l.W);
+}
+bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
+    return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_out, b.n_mid, l.T, l.H, l.W);
+}
+bool use_wino0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_w.w.p && want_wino0(d, b, l); }
+bool use_wino1(const i2v_dec* d, const Block& b, const Level& l) { return b.conv1_w.w.p && want_wino1(d, b, l); }
 
 }  // namespace
 
@@ -440,20 +575,25 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     }
     if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
     const bool f16 = d->cfg.mma == 1;
-    const bool tdup = f16 && b.conv0_16.tdup;  // a0 is kept at the half temporal rate (its frames 2i and 2i+1 coincide)
-    if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true);
+    const bool tdup = f16 && b.tdup0;  // a0 is kept at the half temporal rate (its frames 2i and 2i+1 coincide)
+    const bool w0 = use_wino0(d, b, l), w1 = use_wino1(d, b, l);
+    if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st);
+    else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true);
     else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16);
     if (rc) return rc;
     if ((rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
     const bool fuse = f16 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
-    if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
+    if (w0) rc = conv3_w(d, b.conv0_w, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
+    else if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
     if (rc) return rc;
     if ((rc = tap(k, 2, dx, (size_t)B * P * b.n_mid))) return rc;
     // ADAIN (normalization_layer.py:47-51) + leaky_relu
     if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
     if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, zstride, b.zoff, nullptr, nullptr, st))) return rc;
-    if ((rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16))) return rc;
+    if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st);
+    else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16);
+    if (rc) return rc;
     if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
     // shortcut (decoder.py:44-49) at low resolution
     const float* res = x;
@@ -470,7 +610,8 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // (the shortcut's coefficients were derived from sums1 above, so conv_1 may now overwrite sums1 with the
     // statistics of the block OUTPUT = the next block's input)
     const bool fuse_out = f16 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
-    if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
+    if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
+    else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
     else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
     if (rc) return rc;
     x_stats_ready = fuse_out;
@@ -526,6 +667,16 @@ int sn_pack_tdup(const StateDict& sd, const std::string& name, bool spectral, in
     return out.pack_tdup(w, bias, cout, cin, scale);
 }
 
+int sn_pack_wino(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, bool tdup, Wino16Weights& out) {
+    const float* bias = sd.f32(name + ".bias", cout);
+    if (!bias) return I2V_E_MISSING;
+    const float* w = nullptr;
+    double scale = 1.0;
+    int rc = sn_scale(sd, name, spectral, cout, (int64_t)cin * 27, &w, &scale);
+    if (rc) return rc;
+    return tdup ? out.pack_tdup(w, bias, cout, cin, scale) : out.pack(w, bias, cout, cin, 3, scale);
+}
+
 }  // namespace
 
 extern "C" {
@@ -547,6 +698,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     I2V_REQUIRE(ndev > 0, I2V_E_HIP, "i2v_dec_create: no HIP device");
     auto d = std::make_unique<i2v_dec>();
     d->cfg = *cfg;
+    if (const char* e = std::getenv("I2V_DEC_WINO")) d->wino = std::atoi(e) != 0;
     const int nf = d->nf = cfg->channel_factor;
     const char* names[6] = {"head_0", "g_0", "g_1", "g_2", "g_3", "g_4"};
     const int cin[6] = {16, 16, 16, 8, 4, 2}, cout[6] = {16, 16, 8, 4, 2, 1};
@@ -601,10 +753,15 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         if (d->cfg.mma == 1) {
             // behind a x2 up-sampling in time, SPADE's output is identical for frames 2i and 2i+1 (gamma/beta do not depend
             // on t): conv_0 runs on the half-rate tensor with two pre-summed 2-tap temporal kernels (-1/3 of its MACs)
-            if (d->lvl[k].ut == 2) rc = sn_pack_tdup(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.conv0_16);
+            b.tdup0 = d->lvl[k].ut == 2;
+            // layers whose shape allows it run on the Winograd kernel (1.5x fewer MFMAs), the rest on the direct one
+            if (want_wino0(d, b, d->lvl[k])) rc = sn_pack_wino(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.tdup0, b.conv0_w);
+            else if (b.tdup0) rc = sn_pack_tdup(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.conv0_16);
             else rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0_16);
             if (rc) return rc;
-            if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1_16))) return rc;
+            if (want_wino1(d, b, d->lvl[k])) rc = sn_pack_wino(sd, p + "conv_1", sn, b.n_out, b.n_mid, false, b.conv1_w);
+            else rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1_16);
+            if (rc) return rc;
         } else {
             if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
             if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
@@ -785,7 +942,7 @@ GbWs gb_ws(const i2v_gblock* g, int B, int T, int H, int W) {
     GbWs L;
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o = align_up(o + floats * 4, 256); return r; };
-    L.x_cl = take(B * P * cm); L.out_cl = take(B * P * cm); L.a = take(B * P * cm); L.dx = take(B * P * b.n_mid);
+    L.x_cl = take(B * P * cm); L.out_cl = take(B * P * cm); L.a = take(B * P * cm * 2); L.dx = take(B * P * b.n_mid);
     L.xs_in = take(B * P * b.n_in); L.xs_low = take(B * P * b.n_out);
     L.y0 = take((size_t)B * H * W * 16); L.y1 = take((size_t)B * H * W * 128); L.gb = take((size_t)B * H * W * 2 * b.n_in);
     L.zl = take((size_t)B * 2 * b.n_mid);
@@ -817,6 +974,7 @@ int i2v_gblock_create(int32_t n_in, int32_t n_out, int32_t z_dim, int32_t spectr
     g->ctx.cfg.mma = mma;
     g->ctx.cfg.spectral_norm = spectral_norm;
     g->ctx.cfg.z_dim = z_dim;
+    if (const char* e = std::getenv("I2V_DEC_WINO")) g->ctx.wino = std::atoi(e) != 0;
     g->z_dim = z_dim;
     Block& b = g->b;
     b.name = "";
@@ -843,6 +1001,11 @@ int i2v_gblock_load(i2v_gblock* g, const i2v_tensor* tensors, int32_t n_tensors)
         if (f16) {
             if ((rc = sn_pack(sd, "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0_16))) return rc;
             if ((rc = sn_pack(sd, "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1_16))) return rc;
+            // the geometry is only known at the call: also pack the Winograd variants where the channel counts allow them
+            if (g->ctx.wino && wino16_supported(b.n_mid, b.n_in, 16, 64, 64) &&
+                (rc = sn_pack_wino(sd, "conv_0", sn, b.n_mid, b.n_in, false, b.conv0_w))) return rc;
+            if (g->ctx.wino && wino16_supported(b.n_out, b.n_mid, 16, 64, 64) &&
+                (rc = sn_pack_wino(sd, "conv_1", sn, b.n_out, b.n_mid, false, b.conv1_w))) return rc;
         } else {
             if ((rc = sn_pack(sd, "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
             if ((rc = sn_pack(sd, "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
