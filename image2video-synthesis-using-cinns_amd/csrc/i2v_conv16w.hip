@@ -60,13 +60,12 @@ struct WinoArgs {
 
 template <int NT>  // (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time-slice (1x3x3)
 __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
-    constexpr int NST = (NT + 1) / 2;  // weight stages (two taps each) per chunk
     constexpr int KT = NT / 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xi = wave & 3, half = wave >> 2;
+    const int xi = wave & 3, nh = wave >> 2;  // Winograd position and 32-channel half of this wave
     const int kg = lane >> 5, l31 = lane & 31;
 
     // tile order / frame-parity placement: as in i2v_conv16.hip (workgroup b runs on XCD b % 8)
@@ -80,11 +79,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     const int plane = HT * HH * a.TJ;
     const int NROW = 4 * plane;
 
-    char* v_lds = smem;
-    char* w_lds = smem + a.wofs;
-    int* gpos = reinterpret_cast<int*>(smem + a.tofs);  // [NROW] global V row of every staged row, -1 = zero padding
-    int* tpos = gpos + W16_VROWS;                           // [128] output position of a tile's first column
-    int* tres = tpos + W16_TILES;                       // [128][2] residual rows of the tile's two columns
+    char* v_lds = smem;                                  // two V bricks of W16_VROWS rows
+    int* gpos = reinterpret_cast<int*>(smem + a.tofs);   // [W16_VROWS] global V row of every staged row, -1 = zero padding
+    int* tpos = gpos + W16_VROWS;                        // [128] output position of a tile's first column
+    int* tres = tpos + W16_TILES;                        // [128][2] residual rows of the tile's two columns
 
     const int nNt = a.CoutPad / W16_BN;
     const int ntile = tile_id % nNt;
@@ -116,38 +114,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
         gpos[r] = ok ? ((((b0 * a.T + t) * a.nchunk * 4 + x) * a.H + h) * a.J + j) : -1;  // chunk 0; 64-byte rows
     }
 
-    // LDS row of this lane's tile (tap (0,0)) in its x plane, per MFMA row block; B operand byte offsets inside a stage tap
-    int arow[2], boff[2];
+    // LDS row of this lane's tile (tap (0,0)) in its x plane, per MFMA row block (4 blocks of 32 tiles)
+    int arow[4];
 #pragma unroll
-    for (int wm = 0; wm < 2; ++wm) {
-        int m = half * 64 + wm * 32 + l31;
+    for (int wm = 0; wm < 4; ++wm) {
+        int m = wm * 32 + l31;
         const int ij = m % a.TJ; m /= a.TJ;
         const int ih = m % a.TH; m /= a.TH;
         arow[wm] = xi * plane + (m * HH + ih) * a.TJ + ij;
     }
-#pragma unroll
-    for (int wn = 0; wn < 2; ++wn) {
-        const int rb = xi * W16_BN + wn * 32 + l31;
-        boff[wn] = (rb << 6) + ((((kg << 1) ^ ((rb >> 2) & 3))) << 4);
-    }
 
-    f32x16 acc[2][2];
+    f32x16 acc[4];
 #pragma unroll
-    for (int wm = 0; wm < 2; ++wm)
+    for (int wm = 0; wm < 4; ++wm)
 #pragma unroll
-        for (int wn = 0; wn < 2; ++wn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[wm][r] = 0.f;
 
-    // weight pieces of a stage: piece f = tid + 512 u (u < 4): tap-in-stage u >> 1, x = (tid >> 8) + 2 (u & 1),
-    // row (tid >> 2) & 63, 16-byte piece tid & 3
-    const long xstride = (long)a.CoutPad * 64;   // bytes per (tap, chunk, x)
-    const long cstride = 4 * xstride;            // per (tap, chunk)
+    // weights: fragment-major [tap][chunk][x][32-channel block][hi | lo][64 lanes][16 B]: a wave's B operand of one tap is
+    // two coalesced 1 KB loads straight into registers (no LDS staging, no barrier)
+    const long cstride = (long)a.CoutPad * 256;          // bytes per (tap, chunk): 4 x x CoutPad x 64
     const long wtap_stride = (long)a.nchunk * cstride;
-    const int rowq = (tid >> 2) & 63, piece = tid & 3, x0_ = tid >> 8;
-    const int wsrc0 = (int)(x0_ * xstride) + rowq * 64 + piece * 16, wsrc1 = wsrc0 + (int)(2 * xstride);
-    const int wdst0 = ((x0_ * W16_BN + rowq) << 6) + ((piece ^ ((rowq >> 2) & 3)) << 4), wdst1 = wdst0 + ((2 * W16_BN) << 6);
-    const char* wbase = a.wp + (long)par * a.wset_stride + (long)n0 * 64;
+    const char* wlane = a.wp + (long)par * a.wset_stride + ((long)xi * (a.CoutPad >> 5) + (n0 >> 5) + nh) * 2048 + lane * 16;
 
     // V staging: piece idx = tid + 512 u (u < 8) -> LDS row (tid >> 2) + 128 u, 16-byte piece tid & 3; the swizzle term
     // ((row >> 2) & 3) == ((tid >> 4) & 3) does not depend on u, so one base register + immediates address every piece
@@ -167,138 +154,119 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
             vin[u] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
         }                                                                                                            \
     }
-#define W16_WRITE_V()                                                                                                \
-    _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u) *reinterpret_cast<f32x4*>(v_lds + vst + u * 8192) = vin[u];
+#define W16_WRITE_V(VB)                                                                                              \
+    _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u)                                                            \
+        *reinterpret_cast<f32x4*>(v_lds + (VB) * (W16_VROWS * 64) + vst + u * 8192) = vin[u];
 
-    struct Ops { half8 ah[2], al[2], bh[2], bl[2]; };
-    Ops o0, o1;
-    // operands of tap TAP (compile-time): A from the V brick, B from tap slot TIS of weight buffer WB
-#define W16_LOAD_OPS(o, TAP, WB, TIS)                                                                                \
+    struct AOps { half8 ah[4], al[4]; };
+    struct BOps { half8 bh, bl; };
+    AOps a0, a1;
+    BOps bq0, bq1, bq2, bq3, bq4, bq5;  // ring of the B operands of six consecutive taps (requested five taps ahead)
+    // A operands of tap TAP (compile-time) from V brick VB
+#define W16_LOAD_A(o, TAP, VB)                                                                                       \
     {                                                                                                                \
-        const int d_ = (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ;                                                      \
-        _Pragma("unroll") for (int wm = 0; wm < 2; ++wm) {                                                           \
+        const int d_ = (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * W16_VROWS;                                   \
+        _Pragma("unroll") for (int wm = 0; wm < 4; ++wm) {                                                           \
             const int r_ = arow[wm] + d_;                                                                            \
             const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                        \
             (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                               \
             (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                        \
         }                                                                                                            \
-        _Pragma("unroll") for (int wn = 0; wn < 2; ++wn) {                                                           \
-            const int bd_ = (TIS) * (4 * W16_BN * 64) + boff[wn];                                                    \
-            (o).bh[wn] = *reinterpret_cast<const half8*>((WB) + bd_);                                                \
-            (o).bl[wn] = *reinterpret_cast<const half8*>((WB) + (bd_ ^ 16));                                         \
-        }                                                                                                            \
     }
-#define W16_MFMA(o)                                                                                                  \
+    // B operands of tap TAP of chunk CH (clamped to the last chunk: past the end the stream re-requests harmlessly)
+#define W16_REQUEST_B(q, TAP, CH)                                                                                    \
     {                                                                                                                \
-        _Pragma("unroll") for (int wm = 0; wm < 2; ++wm) _Pragma("unroll") for (int wn = 0; wn < 2; ++wn)            \
-            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
-        _Pragma("unroll") for (int wm = 0; wm < 2; ++wm) _Pragma("unroll") for (int wn = 0; wn < 2; ++wn)            \
-            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bl[wn], acc[wm][wn], 0, 0, 0);      \
-        _Pragma("unroll") for (int wm = 0; wm < 2; ++wm) _Pragma("unroll") for (int wn = 0; wn < 2; ++wn)            \
-            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
+        const int c_ = (CH) < a.nchunk ? (CH) : a.nchunk - 1;                                                        \
+        const char* p_ = wlane + (long)(TAP) * wtap_stride + (long)c_ * cstride;                                     \
+        (q).bh = *reinterpret_cast<const half8*>(p_);                                                                \
+        (q).bl = *reinterpret_cast<const half8*>(p_ + 1024);                                                         \
     }
-
-    // weight stream: stage (chunk rq_ch, stage rq_st) is the next one to request; it stops at the last stage (a harmless
-    // re-request) so that every request stays unconditional
-    int rq_ch = 0, rq_st = 0;
-    struct W4 { f32x4 a, b, c, d; };
-    W4 wr0, wr1;
-#define W16_REQUEST_W(WR)                                                                                            \
-    {                                                                                                                \
-        const int tb_ = rq_st * 2 + 1 < NT ? rq_st * 2 + 1 : NT - 1;                                                 \
-        const char* pa_ = wbase + (long)rq_ch * cstride + (long)(rq_st * 2) * wtap_stride;                           \
-        const char* pb_ = wbase + (long)rq_ch * cstride + (long)tb_ * wtap_stride;                                   \
-        WR.a = *reinterpret_cast<const f32x4*>(pa_ + wsrc0);                                                         \
-        WR.b = *reinterpret_cast<const f32x4*>(pa_ + wsrc1);                                                         \
-        WR.c = *reinterpret_cast<const f32x4*>(pb_ + wsrc0);                                                         \
-        WR.d = *reinterpret_cast<const f32x4*>(pb_ + wsrc1);                                                         \
-        if (rq_st + 1 < NST) ++rq_st;                                                                                \
-        else if (rq_ch + 1 < a.nchunk) { rq_st = 0; ++rq_ch; }                                                       \
-    }
-#define W16_PARK_W(WR, dst)                                                                                          \
-    {                                                                                                                \
-        *reinterpret_cast<f32x4*>((dst) + wdst0) = WR.a;                                                             \
-        *reinterpret_cast<f32x4*>((dst) + wdst1) = WR.b;                                                             \
-        *reinterpret_cast<f32x4*>((dst) + 4 * W16_BN * 64 + wdst0) = WR.c;                                           \
-        *reinterpret_cast<f32x4*>((dst) + 4 * W16_BN * 64 + wdst1) = WR.d;                                           \
+#ifndef W16_ABLATE
+#define W16_ABLATE 0   // measurement builds only (tools/conv16w_check): 1 no MFMAs, 2 no weight traffic, 4 no V staging (16: no V requests, 32: no V LDS writes), 8 no barriers
+#endif
+#define W16_SYNC() { if (!(W16_ABLATE & 8)) __syncthreads(); }
+#define W16_MFMA(o, q)                                                                                               \
+    if (W16_ABLATE & 1) {                                                                                            \
+        asm volatile("" :: "v"((o).ah[0]), "v"((o).al[0]), "v"((q).bh), "v"((q).bl), "v"((o).ah[1]), "v"((o).al[1]), \
+                     "v"((o).ah[2]), "v"((o).al[2]), "v"((o).ah[3]), "v"((o).al[3]));                                \
+    } else {                                                                                                         \
+        _Pragma("unroll") for (int wm = 0; wm < 4; ++wm)                                                             \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+        _Pragma("unroll") for (int wm = 0; wm < 4; ++wm)                                                             \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
+        _Pragma("unroll") for (int wm = 0; wm < 4; ++wm)                                                             \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
     }
 
     __syncthreads();  // tables
     W16_REQUEST_V(0)
-    W16_REQUEST_W(wr0)   // stage 0: straight to LDS below
-    W16_WRITE_V()
-    W16_PARK_W(wr0, w_lds)
-    W16_REQUEST_W(wr0)   // stage 1
-    W16_REQUEST_W(wr1)   // stage 2
+    W16_REQUEST_B(bq0, 0 % NT, 0 / NT)
+    W16_REQUEST_B(bq1, 1 % NT, 1 / NT)
+    W16_REQUEST_B(bq2, 2 % NT, 2 / NT)
+    W16_REQUEST_B(bq3, 3 % NT, 3 / NT)
+    W16_REQUEST_B(bq4, 4 % NT, 4 / NT)
+    W16_WRITE_V(0)
     __syncthreads();
-    W16_LOAD_OPS(o0, 0, w_lds, 0)
+    W16_LOAD_A(a0, 0, 0)
 
-    // One stage = the two taps 2 ST, 2 ST + 1 of the current chunk (the last stage of a 9-tap chunk holds one).  Stage g
-    // of the stream (over all chunks) reads weight buffer g & 1; register set g & 1 holds the weights of stage g + 1,
-    // requested two stages ago (under load a request takes longer than one stage): park them in the other buffer -- its
-    // readers finished before the previous barrier -- and request stage g + 3.  The operands of the following tap are
-    // read from LDS while the current tap's 12 MFMAs run; the stage's barrier publishes the parked weights.  The last
-    // stage of a chunk also swaps the V brick: barrier (all reads of the old brick done), write, MFMAs, barrier.
-    // The loop body is a PAIR of chunks (the chunk count is even): with an odd stage count per chunk the buffer /
-    // register-set roles flip from chunk to chunk, and everything stays compile-time and branch-free (after the last
-    // chunk the V write and the operand read repeat harmlessly).
-    constexpr int PFST = NST >= 3 ? NST - 3 : 0;
-#define W16_STAGE(ST, BP, WR, CH)                                                                                    \
+    // The loop body is a PAIR of chunks = 2 NT taps, numbered U = 0 .. 2 NT - 1 (a multiple of 6).  Tap U multiplies the A
+    // operands in register set U & 1 (read from LDS during the previous tap) with the B operands in ring slot U % 6
+    // (requested five taps ago); meanwhile it requests the B operands of tap U + 5 and reads the A operands of tap U + 1.
+    // The V brick is double-buffered: chunk c reads buffer c & 1; the next chunk's pieces are requested at the chunk's
+    // first tap, written into the other buffer two taps before its end and published by the chunk's ONE barrier, which
+    // sits in front of the last tap's MFMAs (the first A read of the next chunk follows it).  Everything is compile-time
+    // and branch-free; after the last chunk the stream re-requests / re-writes harmlessly.
+#define W16_TAP(U, ACUR, ANXT, BCUR, BREQ)                                                                           \
     {                                                                                                                \
-        constexpr int tA_ = 2 * (ST), tB_ = 2 * (ST) + 1;                                                            \
-        constexpr bool hasB_ = tB_ < NT, last_ = (ST) == NST - 1;                                                    \
-        static_assert(last_ || hasB_, "only the last stage of a chunk may hold a single tap");                       \
-        const char* wb_ = w_lds + (BP) * W16_WBUF;                                                                   \
-        char* wn_ = w_lds + (1 - (BP)) * W16_WBUF;                                                                   \
-        /* keep the per-tap operand addresses from being hoisted out of the chunk loop (54 registers) */            \
-        asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(boff[0]), "+v"(boff[1]));                               \
-        W16_PARK_W(WR, wn_)                                                                                          \
-        W16_REQUEST_W(WR)                                                                                            \
-        if constexpr ((ST) == PFST) W16_REQUEST_V((CH) + 1 < a.nchunk ? (CH) + 1 : (CH))                             \
-        if constexpr (hasB_) {                                                                                       \
-            W16_LOAD_OPS(o1, tB_, wb_, 1)                                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-            W16_MFMA(o0)                                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        constexpr int cp_ = (U) / NT, t_ = (U) % NT;          /* chunk of the pair, tap of the chunk */             \
+        constexpr int un_ = (U) + 5, cn_ = un_ / NT, tn_ = un_ % NT;                                                 \
+        asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[2]), "+v"(arow[3]));                               \
+        if (!(W16_ABLATE & 2)) W16_REQUEST_B(BREQ, tn_, ch + cn_)                                                    \
+        if constexpr (t_ == 0 && !(W16_ABLATE & (4 | 16))) W16_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_) \
+        /* the eight staged pieces go to LDS two per tap over the last taps in front of the barrier (a burst of 64   \
+           ds_write_b128 per workgroup stalls the A operand reads queued behind it) */                              \
+        if constexpr (!(W16_ABLATE & 4)) {                                                                           \
+            constexpr int w0_ = NT >= 6 ? NT - 5 : 1, nw_ = NT >= 6 ? 2 : 8;                                         \
+            if constexpr (t_ >= w0_ && t_ < w0_ + 8 / nw_) {                                                         \
+                _Pragma("unroll") for (int u = (t_ - w0_) * nw_; u < (t_ - w0_ + 1) * nw_; ++u)                      \
+                    *reinterpret_cast<f32x4*>(v_lds + (1 - cp_) * (W16_VROWS * 64) + vst + u * 8192) = vin[u];       \
+            }                                                                                                        \
         }                                                                                                            \
-        __syncthreads();                                                                                             \
-        if constexpr (!last_) {                                                                                      \
-            W16_LOAD_OPS(o0, tA_ + 2, wn_, 0)                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-            W16_MFMA(o1)                                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if constexpr (t_ < NT - 1) {                                                                                 \
+            W16_LOAD_A(ANXT, t_ + 1, cp_)                                                                            \
         } else {                                                                                                     \
-            W16_WRITE_V()                                                                                            \
-            if constexpr (hasB_) W16_MFMA(o1) else W16_MFMA(o0)                                                      \
-            __syncthreads();                                                                                         \
-            W16_LOAD_OPS(o0, 0, wn_, 0)                                                                              \
+            W16_SYNC()                                                                                               \
+            W16_LOAD_A(ANXT, 0, 1 - cp_)                                                                             \
         }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        W16_MFMA(ACUR, BCUR)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
-#define W16_CHUNK(P, Q, CH)                                                                                          \
+#define W16_TAP6(U0)                                                                                                 \
     {                                                                                                                \
-        W16_STAGE(0, P, wr##P, CH)                                                                                   \
-        if constexpr (NST > 1) W16_STAGE(1, Q, wr##Q, CH)                                                            \
-        if constexpr (NST > 2) W16_STAGE(2, P, wr##P, CH)                                                            \
-        if constexpr (NST > 3) W16_STAGE(3, Q, wr##Q, CH)                                                            \
-        if constexpr (NST > 4) W16_STAGE(4, P, wr##P, CH)                                                            \
+        W16_TAP((U0) + 0, a0, a1, bq0, bq5)                                                                          \
+        W16_TAP((U0) + 1, a1, a0, bq1, bq0)                                                                          \
+        W16_TAP((U0) + 2, a0, a1, bq2, bq1)                                                                          \
+        W16_TAP((U0) + 3, a1, a0, bq3, bq2)                                                                          \
+        W16_TAP((U0) + 4, a0, a1, bq4, bq3)                                                                          \
+        W16_TAP((U0) + 5, a1, a0, bq5, bq4)                                                                          \
     }
     for (int ch = 0; ch < a.nchunk; ch += 2) {
-        W16_CHUNK(0, 1, ch)
-        if constexpr (NST & 1) W16_CHUNK(1, 0, ch + 1) else W16_CHUNK(0, 1, ch + 1)
+        W16_TAP6(0)
+        if constexpr (NT >= 6) W16_TAP6(6)
+        if constexpr (NT >= 9) W16_TAP6(12)
     }
 
     // ---- epilogue: the four partial GEMMs of a tile meet in LDS; y0 = M0 + M1 + M2, y1 = M1 - M2 - M3
     __syncthreads();
     float* E = reinterpret_cast<float*>(smem);  // [4][128 tiles][64 channels]
 #pragma unroll
-    for (int wm = 0; wm < 2; ++wm)
+    for (int wm = 0; wm < 4; ++wm)
 #pragma unroll
-        for (int wn = 0; wn < 2; ++wn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = half * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                E[(xi * W16_TILES + m) * W16_BN + wn * 32 + l31] = acc[wm][wn][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            E[(xi * W16_TILES + m) * W16_BN + nh * 32 + l31] = acc[wm][r];
+        }
     __syncthreads();
     const int n4 = tid & 15;
     const int n = n0 + 4 * n4;
@@ -402,10 +370,11 @@ static int wino_pack_sets(Wino16Weights& o, const std::vector<double>& w3, int n
                         const float v = (float)(u[((((size_t)s * cout + n) * cin + c) * NT + tap) * 4 + x] * pre);
                         const _Float16 hi = (_Float16)v;
                         const _Float16 lo = (_Float16)(v - (float)hi);
-                        const int chunk = c / W16_KC, g = (c % W16_KC) / 8, j = c % 8;
-                        _Float16* row = &p[s * set_halfs + ((((size_t)tap * o.nchunk + chunk) * 4 + x) * o.CoutPad + n) * 32];
-                        row[g * 16 + j] = hi;
-                        row[g * 16 + 8 + j] = lo;
+                        // fragment-major: [tap][chunk][x][32-channel block][hi | lo][lane = kg * 32 + n % 32][8 halfs]
+                        const int chunk = c / W16_KC, kgq = (c % W16_KC) / 8, j = c % 8;
+                        _Float16* blk = &p[s * set_halfs + ((((size_t)tap * o.nchunk + chunk) * 4 + x) * (o.CoutPad / 32) + n / 32) * 1024];
+                        blk[(kgq * 32 + n % 32) * 8 + j] = hi;
+                        blk[512 + (kgq * 32 + n % 32) * 8 + j] = lo;
                     }
     o.set_bytes = (long)set_halfs * 2;
     return o.w.upload(p.data(), p.size() * 2);
@@ -478,6 +447,7 @@ int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, con
         T /= 2;
     }
     a.T = T;
+    I2V_REQUIRE(!(T == 1 && wts.KT == 3), I2V_E_INVALID, "wino16: single-frame inputs need weights packed with kt = 1");
     I2V_REQUIRE(wino16_supported(wts.Cout, wts.Cin, T, H, W), I2V_E_INVALID, "wino16: unsupported shape [%d,%d,%d] %d -> %d", T, H, W,
                 wts.Cin, wts.Cout);
     a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
@@ -496,8 +466,8 @@ int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, con
     const int nrow = 4 * (TT + KT - 1) * (TH + 2) * TJ;
     I2V_REQUIRE(nrow <= W16_VROWS, I2V_E_INVALID, "wino16: halo brick of %d rows", nrow);
     a.TT = TT; a.TH = TH; a.TJ = TJ; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = J / TJ;
-    a.wofs = W16_VROWS * 64;
-    const int body = std::max(a.wofs + 2 * W16_WBUF, 4 * W16_TILES * W16_BN * 4);
+    a.wofs = 0;
+    const int body = std::max(2 * W16_VROWS * 64, 4 * W16_TILES * W16_BN * 4);  // two V bricks; the epilogue's exchange buffer
     a.tofs = body;
     const size_t lds = (size_t)body + (size_t)W16_VROWS * 4 + W16_TILES * 12;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino16: LDS %zu bytes", lds);
