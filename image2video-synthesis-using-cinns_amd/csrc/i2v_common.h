@@ -92,4 +92,27 @@ struct DevBuf {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize has to be raised once PER DEVICE (every device has its own copy of the code
+// object); `done` = the call site's static bool[I2V_MAX_DEV].
+// A handle owns device memory (packed weights) on the device that was current when it was created; every call that
+// enqueues work must run with that device current (one handle per GPU / rank).
+#define I2V_REQUIRE_DEVICE(bound, what)                                                                              \
+    do {                                                                                                             \
+        int cur_ = -1;                                                                                               \
+        I2V_HIP_CHECK(hipGetDevice(&cur_));                                                                          \
+        I2V_REQUIRE(cur_ == (bound), I2V_E_INVALID,                                                                  \
+                    "%s: the handle lives on HIP device %d but the current device is %d (one handle per GPU; make its "  \
+                    "device current before the call)", what, (bound), cur_);                                         \
+    } while (0)
+
+constexpr int I2V_MAX_DEV = 64;
+inline int ensure_dynamic_lds(const void* kernel, int bytes, bool* done) {
+    int dev = 0;
+    I2V_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < I2V_MAX_DEV && done[dev]) return I2V_OK;
+    I2V_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < I2V_MAX_DEV) done[dev] = true;
+    return I2V_OK;
+}
+
 }  // namespace i2v

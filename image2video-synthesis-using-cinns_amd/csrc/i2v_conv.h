@@ -73,8 +73,9 @@ struct Conv16Weights {
 
 // in_hl16: channels-last activations in the hl16 format (4 bytes per element, Cin % 8 == 0); out: fp32 channels-last.
 // T,H,W = OUTPUT geometry (for pack_tdup weights the input tensor has T/2 frames).
+// range_flag (optional, with EPI_HL16): device int set to 1 when a stored value does not fit the fp16 hi part
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st, double* stats = nullptr);
+                   int H, int W, int epi, hipStream_t st, double* stats = nullptr, int* range_flag = nullptr);
 // true when conv16_forward can accumulate per-(sample, channel) sum / sum-of-squares of its output in the epilogue
 bool conv16_can_fuse_stats(int T, int H, int W);
 

@@ -329,12 +329,8 @@ namespace {
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 int launch(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
     auto kern = conv_mfma_f32_kernel<WAVES_M, WAVES_N, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[I2V_MAX_DEV] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
     constexpr int BN = 32 * WN * WAVES_N;
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "conv: grid of %ld workgroups", nblk);

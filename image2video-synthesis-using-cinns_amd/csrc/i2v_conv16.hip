@@ -44,6 +44,7 @@ struct Conv16Args {
     const float* res;
     float* out;       // fp32 channels-last [B][T][H][W][Cout]
     double* stats;    // optional [B][Cout][2]: per-(sample, channel) sum / sum of squares of the stored values (TB == 1)
+    int* range_flag;  // optional (EPI_HL16): set when a stored value leaves the fp16 range
     int B, T, H, W, Cin, Cout, CoutPad, nchunk;  // T,H,W: geometry of the INPUT tensor
     int tdup;            // 1: temporal-duplication mode -- the output has 2T frames, two tiles (frame parities) per brick
     long wset_stride;    // bytes between the two parity weight sets (tdup)
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         // per-lane partial statistics in fp64: the totals must not depend on how many rows a wave tile holds, or a shard
         // of the batch (which may pick a narrower tile) would not reproduce the full batch bit for bit
         double ssum = 0.0, ssq = 0.0;
+        bool bad = false;
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
 #pragma unroll
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                     a.out[((long)bt_ * a.Cout + n) * HWo + hw] = tanhf(v);
                 } else if (a.epi & EPI_HL16) {  // the next conv's operand format instead of fp32 (same bytes per element)
                     const _Float16 hi = (_Float16)v;
+                    bad |= !(fabsf(v) <= 65504.f);
                     char* o = reinterpret_cast<char*>(a.out) + (long)p * a.Cout * 4 + (n >> 3) * 32 + (n & 7) * 2;
                     *reinterpret_cast<_Float16*>(o) = hi;
                     *reinterpret_cast<_Float16*>(o + 16) = (_Float16)(v - (float)hi);
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                 }
             }
         }
+        if (bad && a.range_flag) atomicOr(a.range_flag, 1);
         if (a.stats) {
             // fused normalisation statistics (InstanceNorm of conv_0's output / GroupNorm of the block output): the
             // workgroup tile lies inside one sample; lanes l and l^32 hold the same column -> wavefront shuffle, then one
@@ -468,12 +472,8 @@ int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
 static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
     auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[I2V_MAX_DEV] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(64 * WAVES_M * WAVES_N), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
@@ -485,7 +485,7 @@ bool conv16_can_fuse_stats(int T, int H, int W) {
 }
 
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st, double* stats) {
+                   int H, int W, int epi, hipStream_t st, double* stats, int* range_flag) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv16: weights not packed");
     I2V_REQUIRE(wts.Cin % 8 == 0, I2V_E_INVALID, "conv16: Cin %d must be a multiple of 8", wts.Cin);
     Conv16Args a{};
@@ -506,6 +506,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     }
     a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
     a.stats = stats;
+    a.range_flag = range_flag;
     a.oscale = (float)std::ldexp(1.0, -wts.wexp);
     int TW = W < 8 ? W : 8, TH = H < 8 ? H : 8;
     int rem = C16_BM / (TW * TH);

@@ -419,14 +419,8 @@ int Wino16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
 template <int NT>
 static int launch_wino(const WinoArgs& a, unsigned nblk, size_t lds, hipStream_t st) {
     auto kern = conv_wino_f16x3_kernel<NT>;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    I2V_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          160 * 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static bool attr_set[I2V_MAX_DEV] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(512), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;

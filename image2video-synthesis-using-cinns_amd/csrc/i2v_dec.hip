@@ -105,10 +105,11 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 template <bool HL16>
 __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
                                                        const float* __restrict__ gb, float* __restrict__ out, int T, int H,
-                                                       int W, int C, int ut, int us, int lrelu) {
+                                                       int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag) {
     const int C8 = C >> 3;
     const int b = blockIdx.y;
     const int per = H * W * C8;  // threads per sample
+    bool bad = false;  // HL16: a value left the fp16 range of the hi part (sticky flag, see i2v_dec_status)
     const int Hl = H / us, Wl = W / us, Tl = T / ut;
     const float2* cp0 = coef + (long)b * C;
     const float* xb = x + (long)b * Tl * Hl * Wl * C;
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const _Float16 hh = (_Float16)r[j];
+                    bad |= !(fabsf(r[j]) <= 65504.f);
                     hi[j] = hh;
                     lo[j] = (_Float16)(r[j] - (float)hh);
                 }
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
             }
         }
     }
+    if (HL16 && bad && range_flag) atomicOr(range_flag, 1);
 }
 
 // The same modulation, written as the Winograd-transformed operand V = B^T d of i2v_conv16w.hip:
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
 // within a 32-channel (128-byte) input line fastest, then j -- a wave reads whole input lines and writes 1 KB runs of V.
 __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
                                                             const float* __restrict__ gb, char* __restrict__ out, int T, int H,
-                                                            int W, int C, int ut, int us, int lrelu) {
+                                                            int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag) {
+    bool bad = false;
     const int C8 = C >> 3, J = W >> 1;
     const int b = blockIdx.y;
     const int per = H * J * C8;  // threads per sample
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
                 for (int c = 0; c < 8; ++c) {
                     const float v = xq == 0 ? d[0][c] - d[2][c] : xq == 1 ? d[1][c] + d[2][c] : xq == 2 ? d[2][c] - d[1][c] : d[1][c] - d[3][c];
                     const _Float16 hh = (_Float16)v;
+                    bad |= !(fabsf(v) <= 65504.f);
                     hi[c] = hh;
                     lo[c] = (_Float16)(v - (float)hh);
                 }
@@ -264,12 +269,14 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
             }
         }
     }
+    if (bad && range_flag) atomicOr(range_flag, 1);
 }
 
 // F.interpolate(img, size=(h,w), mode='bilinear', align_corners=True) (normalization_layer.py:20), written
 // channels-last with the 3 colour channels zero-padded to 16 (the conv kernel's K chunk).
 __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
-                              int hl16) {
+                              int hl16, int* __restrict__ range_flag) {
+    bool bad = false;
     const long total = (long)B * Ho * Wo;
     const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
     const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
@@ -296,6 +303,7 @@ __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const _Float16 hh = (_Float16)v[c];
+                bad |= !(fabsf(v[c]) <= 65504.f);
                 oh[c] = hh;
                 oh[8 + c] = (_Float16)(v[c] - (float)hh);
             }
@@ -304,6 +312,7 @@ __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__
             for (int c = 0; c < 3; ++c) o[c] = v[c];
         }
     }
+    if (bad && range_flag) atomicOr(range_flag, 1);
 }
 
 // Layout conversion for the stand-alone sub-module entry points: the reference surface is [B][C][T][H][W] ("NCDHW"),
@@ -358,9 +367,20 @@ struct i2v_dec {
     ConvImgWeights conv_img_v;  // vector-ALU variant (used when the output geometry tiles into 4x8x8 bricks)
     int Nz = 0;
     int wino = 1;  // 1: 3x3x3 convs whose shape allows it use the Winograd kernel (env I2V_DEC_WINO=0 disables)
+    int device = 0;             // the device the packed weights live on
+    int* status_dev = nullptr;  // sticky range flag of the hl16 producers (device) ...
+    int* status_host = nullptr; // ... and its pinned host mirror, refreshed asynchronously at the end of every forward
+    ~i2v_dec() {
+        if (status_dev) (void)hipFree(status_dev);
+        if (status_host) (void)hipHostFree(status_host);
+    }
     int profile = 0;
-    struct ProfEv { hipEvent_t e0, e1; double flops, exec_flops; };
+    struct ProfEv { hipEvent_t e0, e1; double flops, exec_flops; int layer; };
     std::vector<ProfEv> prof_events;
+    // per-layer totals of the profiled 3x3x3 launches: layer = 2 * block + (0: conv_0, 1: conv_1)
+    struct ProfLayer { double ms = 0, flops = 0, exec_flops = 0; long launches = 0; int kernel = 0; long grid = 0; };
+    ProfLayer prof_layers[12];
+    int prof_cur_layer = 0, prof_cur_kernel = 0;
     double prof_conv3_ms = 0, prof_conv3_flops = 0, prof_conv3_exec = 0;
     long prof_conv3_launches = 0;
     // debug tap: copy one intermediate (channels-last) of one block out of the workspace during forward
@@ -432,29 +452,29 @@ int run_coef(const double* sums, float* coef, int B, int C, int groups, double c
 }
 
 int run_modulate(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
-                 int us, int lrelu, hipStream_t st, bool hl16 = false) {
+                 int us, int lrelu, hipStream_t st, bool hl16 = false, int* range_flag = nullptr) {
     I2V_REQUIRE(C % 8 == 0, I2V_E_INVALID, "modulate: channels %d not a multiple of 8", C);
     const long per = (long)H * W * (C / 8);  // threads per sample (each loops over the T frames)
     I2V_REQUIRE(per * T < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
     if (hl16)
         hipLaunchKernelGGL(modulate_kernel<true>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb, out,
-                           T, H, W, C, ut, us, lrelu);
+                           T, H, W, C, ut, us, lrelu, range_flag);
     else
         hipLaunchKernelGGL(modulate_kernel<false>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb, out,
-                           T, H, W, C, ut, us, lrelu);
+                           T, H, W, C, ut, us, lrelu, range_flag);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
 
 int run_modulate_wino(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
-                      int us, int lrelu, hipStream_t st) {
+                      int us, int lrelu, hipStream_t st, int* range_flag) {
     I2V_REQUIRE(C % 32 == 0 && W % 2 == 0, I2V_E_INVALID, "modulate (Winograd operand): channels %d / width %d", C, W);
     const long per = (long)H * (W / 2) * (C / 8);
     I2V_REQUIRE(per * T * 4 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
     hipLaunchKernelGGL(modulate_wino_kernel, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
-                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu);
+                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -474,7 +494,8 @@ struct ProfScope {
             hipEvent_t e1 = nullptr;
             (void)hipEventCreate(&e1);
             (void)hipEventRecord(e1, st);
-            d->prof_events.push_back({e0, e1, flops, exec_flops});
+            d->prof_events.push_back({e0, e1, flops, exec_flops, d->prof_cur_layer});
+            if (d->prof_cur_layer >= 0 && d->prof_cur_layer < 12) d->prof_layers[d->prof_cur_layer].kernel = d->prof_cur_kernel;
         }
     }
 };
@@ -528,7 +549,7 @@ int coef_forward(const double* sums, float* coef, int B, int C, int groups, doub
 int resize_forward(const float* img, float* out, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
     const long tot = (long)B * Ho * Wo;
     hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, out, B, Hi, Wi,
-                       Ho, Wo, 0);
+                       Ho, Wo, 0, static_cast<int*>(nullptr));
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -563,11 +584,12 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     {
         const long tot = (long)B * l.H * l.W;
         hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, y0,
-                           B, img_h, img_w, l.H, l.W, d->cfg.mma == 1 ? 1 : 0);
+                           B, img_h, img_w, l.H, l.W, d->cfg.mma == 1 ? 1 : 0, d->status_dev);
         I2V_HIP_CHECK(hipGetLastError());
     }
     if (d->cfg.mma == 1) {
-        if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st))) return rc;
+        if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st, nullptr, d->status_dev)))
+            return rc;
         if ((rc = conv16_forward(b.sp_gb16, y1, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
     } else {
         if ((rc = conv_forward(b.sp_conv, y0, 16, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
@@ -577,12 +599,15 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     const bool f16 = d->cfg.mma == 1;
     const bool tdup = f16 && b.tdup0;  // a0 is kept at the half temporal rate (its frames 2i and 2i+1 coincide)
     const bool w0 = use_wino0(d, b, l), w1 = use_wino1(d, b, l);
-    if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st);
-    else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true);
-    else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16);
+    int* flag = d->status_dev;
+    if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag);
+    else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true, flag);
+    else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16, flag);
     if (rc) return rc;
     if ((rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
     const bool fuse = f16 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
+    d->prof_cur_layer = 2 * k;
+    d->prof_cur_kernel = w0 ? 2 : (f16 ? 1 : 0);
     if (w0) rc = conv3_w(d, b.conv0_w, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
@@ -591,8 +616,8 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // ADAIN (normalization_layer.py:47-51) + leaky_relu
     if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
     if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, zstride, b.zoff, nullptr, nullptr, st))) return rc;
-    if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st);
-    else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16);
+    if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag);
+    else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16, flag);
     if (rc) return rc;
     if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
     // shortcut (decoder.py:44-49) at low resolution
@@ -610,6 +635,8 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // (the shortcut's coefficients were derived from sums1 above, so conv_1 may now overwrite sums1 with the
     // statistics of the block OUTPUT = the next block's input)
     const bool fuse_out = f16 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
+    d->prof_cur_layer = 2 * k + 1;
+    d->prof_cur_kernel = w1 ? 2 : (f16 ? 1 : 0);
     if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
     else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
     else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
@@ -667,6 +694,26 @@ int sn_pack_tdup(const StateDict& sd, const std::string& name, bool spectral, in
     return out.pack_tdup(w, bias, cout, cin, scale);
 }
 
+// device binding + the sticky range flag (device word and pinned host mirror)
+int init_status(i2v_dec* d) {
+    I2V_HIP_CHECK(hipGetDevice(&d->device));
+    I2V_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->status_dev), sizeof(int)));
+    I2V_HIP_CHECK(hipMemset(d->status_dev, 0, sizeof(int)));
+    I2V_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->status_host), sizeof(int), hipHostMallocDefault));
+    *d->status_host = 0;
+    return I2V_OK;
+}
+
+// entry check of every call that enqueues work: right device, and no overflow reported by an earlier call
+int check_entry(i2v_dec* d, const char* what) {
+    I2V_REQUIRE_DEVICE(d->device, what);
+    I2V_REQUIRE(!(*static_cast<volatile int*>(d->status_host) & 1), I2V_E_RANGE,
+                "%s: an earlier call on this handle produced activations outside the fp16 range of the split-fp16 operand "
+                "format (|x| > 65504 or non-finite); its output is invalid.  Use the exact-fp32 mode (mma = 0 / I2V_DEC_MMA=0) "
+                "for this checkpoint, or clear the flag with i2v_dec_status(reset = 1)", what);
+    return I2V_OK;
+}
+
 int sn_pack_wino(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, bool tdup, Wino16Weights& out) {
     const float* bias = sd.f32(name + ".bias", cout);
     if (!bias) return I2V_E_MISSING;
@@ -699,6 +746,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     auto d = std::make_unique<i2v_dec>();
     d->cfg = *cfg;
     if (const char* e = std::getenv("I2V_DEC_WINO")) d->wino = std::atoi(e) != 0;
+    if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
     const char* names[6] = {"head_0", "g_0", "g_1", "g_2", "g_3", "g_4"};
     const int cin[6] = {16, 16, 16, 8, 4, 2}, cout[6] = {16, 16, 8, 4, 2, 1};
@@ -729,6 +777,7 @@ void i2v_dec_destroy(i2v_dec* d) { delete d; }
 
 int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
     I2V_REQUIRE(d && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_dec_load: null argument");
+    I2V_REQUIRE_DEVICE(d->device, "i2v_dec_load");
     StateDict sd(tensors, n_tensors);
     const int nf = d->nf, zd = d->cfg.z_dim;
     const bool sn = d->cfg.spectral_norm != 0;
@@ -850,6 +899,7 @@ int i2v_dec_set_profile(i2v_dec* d, int32_t on) {
     d->profile = on;
     d->prof_conv3_ms = d->prof_conv3_flops = d->prof_conv3_exec = 0;
     d->prof_conv3_launches = 0;
+    for (auto& pl : d->prof_layers) pl = i2v_dec::ProfLayer{};
     return I2V_OK;
 }
 
@@ -869,6 +919,10 @@ int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, doubl
         d->prof_conv3_flops += ev.flops;
         d->prof_conv3_exec += ev.exec_flops;
         d->prof_conv3_launches += 1;
+        if (ev.layer >= 0 && ev.layer < 12) {
+            auto& pl = d->prof_layers[ev.layer];
+            pl.ms += ms; pl.flops += ev.flops; pl.exec_flops += ev.exec_flops; pl.launches += 1;
+        }
         (void)hipEventDestroy(ev.e0);
         (void)hipEventDestroy(ev.e1);
     }
@@ -880,9 +934,24 @@ int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, doubl
     return I2V_OK;
 }
 
+int i2v_dec_get_layer_profile(i2v_dec* d, int32_t layer, char* name, int32_t name_len, double* ms, double* flops,
+                              double* mfma_flops, int64_t* launches, int32_t* kernel) {
+    I2V_REQUIRE(d && layer >= 0 && layer < 12, I2V_E_INVALID, "i2v_dec_get_layer_profile: layer index %d", layer);
+    if (int rc = i2v_dec_get_profile(d, nullptr, nullptr, nullptr, nullptr)) return rc;  // resolves pending event pairs
+    const auto& pl = d->prof_layers[layer];
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s.conv_%d", d->blk[layer / 2].name.c_str(), layer & 1);
+    if (ms) *ms = pl.ms;
+    if (flops) *flops = pl.flops;
+    if (mfma_flops) *mfma_flops = pl.exec_flops;
+    if (launches) *launches = pl.launches;
+    if (kernel) *kernel = pl.kernel;
+    return I2V_OK;
+}
+
 int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, const float* motion, float* out,
                     void* workspace, size_t workspace_bytes, int32_t batch, void* stream) {
     I2V_REQUIRE(d && d->loaded, I2V_E_STATE, "i2v_dec_forward: weights not loaded");
+    if (int rc0 = check_entry(d, "i2v_dec_forward")) return rc0;
     I2V_REQUIRE(img && motion && out && workspace && batch > 0 && img_h > 0 && img_w > 0, I2V_E_INVALID,
                 "i2v_dec_forward: null argument or bad size");
     const int B = batch;
@@ -915,6 +984,22 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
         if (conv_img_supported(l.T, l.H, l.W, d->nf)) rc = conv_img_forward(d->conv_img_v, x, out, B, l.T, l.H, l.W, st);
         else rc = conv_forward(d->conv_img, x, d->nf, out, nullptr, 1, 1, B, l.T, l.H, l.W, EPI_FRAMES, st);
         if (rc) return rc;
+    }
+    if (d->cfg.mma == 1) I2V_HIP_CHECK(hipMemcpyAsync(d->status_host, d->status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    return I2V_OK;
+}
+
+int i2v_dec_status(i2v_dec* d, int32_t* flags, int32_t reset, void* stream) {
+    I2V_REQUIRE(d && flags, I2V_E_INVALID, "i2v_dec_status: null argument");
+    I2V_REQUIRE_DEVICE(d->device, "i2v_dec_status");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    I2V_HIP_CHECK(hipMemcpyAsync(d->status_host, d->status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    I2V_HIP_CHECK(hipStreamSynchronize(st));
+    *flags = *d->status_host;
+    if (reset) {
+        I2V_HIP_CHECK(hipMemsetAsync(d->status_dev, 0, sizeof(int), st));
+        I2V_HIP_CHECK(hipStreamSynchronize(st));
+        *d->status_host = 0;
     }
     return I2V_OK;
 }
@@ -975,6 +1060,7 @@ int i2v_gblock_create(int32_t n_in, int32_t n_out, int32_t z_dim, int32_t spectr
     g->ctx.cfg.spectral_norm = spectral_norm;
     g->ctx.cfg.z_dim = z_dim;
     if (const char* e = std::getenv("I2V_DEC_WINO")) g->ctx.wino = std::atoi(e) != 0;
+    if (int rc = init_status(&g->ctx)) return rc;
     g->z_dim = z_dim;
     Block& b = g->b;
     b.name = "";
@@ -992,6 +1078,7 @@ void i2v_gblock_destroy(i2v_gblock* g) { delete g; }
 
 int i2v_gblock_load(i2v_gblock* g, const i2v_tensor* tensors, int32_t n_tensors) {
     I2V_REQUIRE(g && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_gblock_load: null argument");
+    I2V_REQUIRE_DEVICE(g->ctx.device, "i2v_gblock_load");
     StateDict sd(tensors, n_tensors);
     Block& b = g->b;
     const bool sn = g->ctx.cfg.spectral_norm != 0, f16 = g->ctx.cfg.mma == 1;
@@ -1068,6 +1155,7 @@ int i2v_gblock_forward(i2v_gblock* g, const float* x, const float* z, const floa
     I2V_REQUIRE(g && g->has_convs && g->has_spade && g->has_adain && (!g->b.learned || g->has_norm_s), I2V_E_STATE,
                 "i2v_gblock_forward: block weights not (fully) loaded");
     I2V_REQUIRE(x && z && img && out && workspace && batch > 0, I2V_E_INVALID, "i2v_gblock_forward: null argument");
+    if (int rc0 = check_entry(&g->ctx, "i2v_gblock_forward")) return rc0;
     const GbWs L = gb_ws(g, batch, t, h, w);
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_gblock_forward: workspace %zu < required %zu", workspace_bytes, L.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1085,12 +1173,16 @@ int i2v_gblock_forward(i2v_gblock* g, const float* x, const float* z, const floa
     if ((rc = block_forward(&g->ctx, 0, b, l, F(L.x_cl), F(L.out_cl), img, img_h, img_w, F(L.zl), 2 * b.n_mid, batch, bufs, ready,
                             false, st)))
         return rc;
-    return run_transpose(F(L.out_cl), out, batch, b.n_out, P, false, st);
+    if ((rc = run_transpose(F(L.out_cl), out, batch, b.n_out, P, false, st))) return rc;
+    if (g->ctx.cfg.mma == 1)
+        I2V_HIP_CHECK(hipMemcpyAsync(g->ctx.status_host, g->ctx.status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    return I2V_OK;
 }
 
 int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* cond, int32_t img_h, int32_t img_w, float* out,
                     void* workspace, size_t workspace_bytes, int32_t batch, int32_t t, int32_t h, int32_t w, void* stream) {
     I2V_REQUIRE(g && x && out && workspace && batch > 0 && part >= 0 && part <= 2, I2V_E_INVALID, "i2v_gblock_norm: bad argument");
+    if (int rc0 = check_entry(&g->ctx, "i2v_gblock_norm")) return rc0;
     const GbWs L = gb_ws(g, batch, t, h, w);
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_gblock_norm: workspace %zu < required %zu", workspace_bytes, L.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1110,11 +1202,11 @@ int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* co
         if ((rc = run_coef(sums, coef, B, C, b.groups_spade, (double)P, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
         const long tot = (long)B * h * w;
         hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, cond, F(L.y0), B,
-                           img_h, img_w, h, w, g->ctx.cfg.mma == 1 ? 1 : 0);
+                           img_h, img_w, h, w, g->ctx.cfg.mma == 1 ? 1 : 0, g->ctx.status_dev);
         I2V_HIP_CHECK(hipGetLastError());
         if (g->ctx.cfg.mma == 1) {
             if ((rc = conv16_forward(b.sp_conv16, F(L.y0), reinterpret_cast<float*>(F(L.y1)), nullptr, 1, 1, B, 1, h, w,
-                                     EPI_LRELU | EPI_HL16, st))) return rc;
+                                     EPI_LRELU | EPI_HL16, st, nullptr, g->ctx.status_dev))) return rc;
             if ((rc = conv16_forward(b.sp_gb16, F(L.y1), F(L.gb), nullptr, 1, 1, B, 1, h, w, EPI_NONE, st))) return rc;
         } else {
             if ((rc = conv_forward(b.sp_conv, F(L.y0), 16, F(L.y1), nullptr, 1, 1, B, 1, h, w, EPI_LRELU, st))) return rc;

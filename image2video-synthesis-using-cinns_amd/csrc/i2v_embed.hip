@@ -120,6 +120,7 @@ struct Bneck {
 
 struct i2v_embedder {
     int E = 0, bn = 0;
+    int device = 0;
     bool loaded = false;
     ConvWeights stem, fc;
     NormP nstem;
@@ -191,6 +192,7 @@ int i2v_embedder_create(int32_t z_dim, int32_t use_batchnorm, i2v_embedder** out
     auto e = std::make_unique<i2v_embedder>();
     e->E = z_dim;
     e->bn = use_batchnorm ? 1 : 0;
+    I2V_HIP_CHECK(hipGetDevice(&e->device));
     *out = e.release();
     return I2V_OK;
 }
@@ -198,6 +200,7 @@ int i2v_embedder_create(int32_t z_dim, int32_t use_batchnorm, i2v_embedder** out
 void i2v_embedder_destroy(i2v_embedder* e) { delete e; }
 
 int i2v_embedder_load(i2v_embedder* e, const i2v_tensor* tensors, int32_t n_tensors) {
+    if (e) I2V_REQUIRE_DEVICE(e->device, "i2v_embedder_load");
     I2V_REQUIRE(e && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_embedder_load: null argument");
     StateDict sd(tensors, n_tensors);
     int rc;
@@ -256,6 +259,7 @@ size_t i2v_embedder_workspace_bytes(const i2v_embedder* e, int32_t batch, int32_
 
 int i2v_embedder_forward(i2v_embedder* e, const float* img, int32_t h, int32_t w, float* embed, void* workspace,
                          size_t workspace_bytes, int32_t batch, void* stream) {
+    if (e) I2V_REQUIRE_DEVICE(e->device, "i2v_embedder_forward");
     I2V_REQUIRE(e && e->loaded, I2V_E_STATE, "i2v_embedder_forward: weights not loaded");
     I2V_REQUIRE(img && embed && workspace && batch > 0, I2V_E_INVALID, "i2v_embedder_forward: null argument");
     I2V_REQUIRE(h >= 64 && w >= 64 && (h & (h - 1)) == 0 && (w & (w - 1)) == 0, I2V_E_INVALID,

@@ -184,6 +184,7 @@ int load_gn(const StateDict& sd, const std::string& name, int C, GN& g) {
 
 struct i2v_encoder3d {
     i2v_encoder3d_cfg cfg;
+    int device = 0;
     bool loaded = false;
     DevBuf stem_w;
     GN nstem;
@@ -246,6 +247,7 @@ int i2v_encoder3d_create(const i2v_encoder3d_cfg* cfg, i2v_encoder3d** out) {
     I2V_REQUIRE(ndev > 0, I2V_E_HIP, "i2v_encoder3d_create: no HIP device");
     auto e = std::make_unique<i2v_encoder3d>();
     e->cfg = *cfg;
+    I2V_HIP_CHECK(hipGetDevice(&e->device));
     *out = e.release();
     return I2V_OK;
 }
@@ -253,6 +255,7 @@ int i2v_encoder3d_create(const i2v_encoder3d_cfg* cfg, i2v_encoder3d** out) {
 void i2v_encoder3d_destroy(i2v_encoder3d* e) { delete e; }
 
 int i2v_encoder3d_load(i2v_encoder3d* e, const i2v_tensor* tensors, int32_t n_tensors) {
+    if (e) I2V_REQUIRE_DEVICE(e->device, "i2v_encoder3d_load");
     I2V_REQUIRE(e && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_encoder3d_load: null argument");
     StateDict sd(tensors, n_tensors);
     const int* ch = e->cfg.channels;
@@ -334,6 +337,7 @@ size_t i2v_encoder3d_workspace_bytes(const i2v_encoder3d* e, int32_t batch, int3
 
 int i2v_encoder3d_forward(i2v_encoder3d* e, const float* x, int32_t t, int32_t h, int32_t w, const float* eps, float* sample,
                           float* mu, float* logvar, void* workspace, size_t workspace_bytes, int32_t batch, void* stream) {
+    if (e) I2V_REQUIRE_DEVICE(e->device, "i2v_encoder3d_forward");
     I2V_REQUIRE(e && e->loaded, I2V_E_STATE, "i2v_encoder3d_forward: weights not loaded");
     I2V_REQUIRE(x && mu && logvar && workspace && batch > 0 && t >= 1, I2V_E_INVALID, "i2v_encoder3d_forward: bad argument");
     I2V_REQUIRE(!sample || eps, I2V_E_INVALID, "i2v_encoder3d_forward: a sample needs eps");
@@ -353,12 +357,8 @@ int i2v_encoder3d_forward(i2v_encoder3d* e, const float* x, int32_t t, int32_t h
     int T = (t + 2 - 3) / 2 + 1, H = h / 2, W = w / 2, C = e->cfg.channels[0];
     I2V_REQUIRE((T & (T - 1)) == 0, I2V_E_INVALID, "i2v_encoder3d_forward: %d input frames give %d stem frames (need a power of two)", t, T);
     {
-        static bool attr = false;
-        if (!attr) {
-            I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              160 * 1024));
-            attr = true;
-        }
+        static bool attr[I2V_MAX_DEV] = {};
+        if (int rc2 = ensure_dynamic_lds(reinterpret_cast<const void*>(enc_stem_kernel), 160 * 1024, attr)) return rc2;
         hipLaunchKernelGGL(enc_stem_kernel, dim3(1024), dim3(256), (size_t)147 * 3 * C * 4, st, x, e->stem_w.as<float>(), b0, B, t, h, w, T, H,
                            W, C);
         I2V_HIP_CHECK(hipGetLastError());

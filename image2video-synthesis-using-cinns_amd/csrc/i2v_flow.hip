@@ -459,6 +459,7 @@ int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out) {
 void i2v_flow_destroy(i2v_flow* f) { delete f; }
 
 int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
+    if (f) I2V_REQUIRE_DEVICE(f->device, "i2v_flow_load");
     I2V_REQUIRE(f && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_flow_load: null argument");
     StateDict sd(tensors, n_tensors);
     const int nf = f->cfg.n_flows, H = f->H, E = f->E, ld0 = f->ld0, D = f->depth, S = f->S, N2 = 2 * H;
@@ -571,12 +572,15 @@ size_t i2v_flow_param_bytes(const i2v_flow* f) { return f ? f->param_bytes : 0; 
 
 int i2v_flow_forward(i2v_flow* f, const float* x, const float* embed, float* zt, float* logdet, void* workspace,
                      size_t workspace_bytes, int32_t batch, void* stream) {
-    I2V_REQUIRE(logdet, I2V_E_INVALID, "i2v_flow_forward: logdet is null");
+    I2V_REQUIRE(f && logdet, I2V_E_INVALID, "i2v_flow_forward: null argument");
+    I2V_REQUIRE_DEVICE(f->device, "i2v_flow_forward");
     return run_pass(f, false, x, embed, zt, logdet, workspace, workspace_bytes, batch, static_cast<hipStream_t>(stream));
 }
 
 int i2v_flow_inverse(i2v_flow* f, const float* residual, const float* embed, float* z, void* workspace,
                      size_t workspace_bytes, int32_t batch, void* stream) {
+    I2V_REQUIRE(f, I2V_E_INVALID, "i2v_flow_inverse: null handle");
+    I2V_REQUIRE_DEVICE(f->device, "i2v_flow_inverse");
     return run_pass(f, true, residual, embed, z, nullptr, workspace, workspace_bytes, batch,
                     static_cast<hipStream_t>(stream));
 }

@@ -67,6 +67,7 @@ using namespace i2v;
 
 struct i2v_mlp {
     int dim, hidden, depth, out_dim;
+    int device = 0;
     bool loaded = false;
     std::vector<DevBuf> W, b;  // depth + 2 layers, torch layout [out][in]
 };
@@ -123,6 +124,7 @@ int i2v_mlp_create(int32_t dim, int32_t hidden_dim, int32_t depth, int32_t out_d
     m->dim = dim; m->hidden = hidden_dim; m->depth = depth; m->out_dim = out_dim;
     m->W.resize(depth + 2);
     m->b.resize(depth + 2);
+    I2V_HIP_CHECK(hipGetDevice(&m->device));
     *out = m.release();
     return I2V_OK;
 }
@@ -130,6 +132,7 @@ int i2v_mlp_create(int32_t dim, int32_t hidden_dim, int32_t depth, int32_t out_d
 void i2v_mlp_destroy(i2v_mlp* m) { delete m; }
 
 int i2v_mlp_load(i2v_mlp* m, const i2v_tensor* tensors, int32_t n_tensors) {
+    if (m) I2V_REQUIRE_DEVICE(m->device, "i2v_mlp_load");
     I2V_REQUIRE(m && tensors && n_tensors > 0, I2V_E_INVALID, "i2v_mlp_load: null argument");
     StateDict sd(tensors, n_tensors);
     for (int li = 0; li < m->depth + 2; ++li) {
@@ -153,6 +156,7 @@ size_t i2v_mlp_workspace_bytes(const i2v_mlp* m, int32_t batch) {
 
 int i2v_mlp_forward(i2v_mlp* m, const float* x, float* y, void* workspace, size_t workspace_bytes, int32_t batch,
                     void* stream) {
+    if (m) I2V_REQUIRE_DEVICE(m->device, "i2v_mlp_forward");
     I2V_REQUIRE(m && m->loaded, I2V_E_STATE, "i2v_mlp_forward: weights not loaded");
     I2V_REQUIRE(x && y && workspace && batch > 0, I2V_E_INVALID, "i2v_mlp_forward: null argument");
     I2V_REQUIRE(workspace_bytes >= i2v_mlp_workspace_bytes(m, batch), I2V_E_WORKSPACE, "i2v_mlp_forward: workspace too small");

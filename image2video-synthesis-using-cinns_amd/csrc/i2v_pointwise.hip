@@ -176,21 +176,13 @@ int pw_launch(const PwArgs& a, hipStream_t st) {
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "pointwise conv: grid of %ld workgroups", nblk);
     if (a.coef) {
         auto kern = pw_mfma_f32_kernel<WAVES_M, WAVES_N, WM, WN, true>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              96 * 1024));
-            attr_set = true;
-        }
+        static bool attr_set[I2V_MAX_DEV] = {};
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 96 * 1024, attr_set)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
     } else {
         auto kern = pw_mfma_f32_kernel<WAVES_M, WAVES_N, WM, WN, false>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            I2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              96 * 1024));
-            attr_set = true;
-        }
+        static bool attr_set[I2V_MAX_DEV] = {};
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 96 * 1024, attr_set)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
     }
     I2V_HIP_CHECK(hipGetLastError());

@@ -7,9 +7,11 @@ globs ``./assets/GT_samples/<dataset>/*.{jpg,png,jpeg}``, normalises to [-1,1], 
 ``Model`` batch by batch and writes ``./assets/results/<dataset>/results.gif``.
 
 The image I/O side is thin glue: cv2 / kornia / imageio are replaced by PIL + numpy + a bilinear
-``F.interpolate`` (align_corners=False, kornia.Resize's default).  The conditioning embedder (ResNet-50, row N1 of the
-coverage contract) is not part of this build yet: pass ``-embed_npy FILE`` with a precomputed ``[N,E]`` embedding, or
-``-embed_seed S`` to draw a synthetic one (demo / smoke use).
+``F.interpolate`` (align_corners=False, kornia.Resize's default).  The conditioning embedding comes from the ResNet-50
+embedder that ``Model`` loads from ``Conditioning_Model.model_path`` (row N1, csrc/i2v_embed.hip), exactly as in the
+reference; for checkpoints shipped without it pass ``-embed_npy FILE`` with a precomputed ``[N,E]`` embedding, or
+``-embed_seed S`` to draw a synthetic one (demo / smoke use).  E is the embedder's width (``Conditioning_Model.z_dim``):
+for endpoint-controlled models the 30 position one-hots are appended by the model, not by the caller.
 """
 import argparse
 import glob
@@ -52,6 +54,7 @@ def main(argv=None):
     parser.add_argument("-embed_seed", type=int, help="draw synthetic conditioning embeddings with this seed")
     parser.add_argument("-img_path", type=str, help="override ./assets/GT_samples/<dataset>/")
     parser.add_argument("-out_path", type=str, help="override ./assets/results/<dataset>/")
+    parser.add_argument("-raw_npy", type=str, help="also write the uint8 frame strip [T,H,N*W,3] (the GIF's palette is lossy)")
     args = parser.parse_args(argv)
     os.environ["HIP_VISIBLE_DEVICES"] = args.gpu   # the reference sets CUDA_VISIBLE_DEVICES (generate_samples.py:20)
 
@@ -70,7 +73,7 @@ def main(argv=None):
     model = Model(ckpt_path, args.seq_length)
     img_res = model.config.Data["img_size"]
     imgs = load_images(img_list, img_res)
-    E = model.flow.flow.cond_channels
+    E = model.flow.flow.cond_channels - 3 * model.flow.cond_size  # width of the image embedding (without the control one-hots)
     if args.embed_npy:
         embeds = torch.from_numpy(np.load(args.embed_npy).astype(np.float32))
     elif args.embed_seed is not None:
@@ -92,6 +95,8 @@ def main(argv=None):
     os.makedirs(os.path.dirname(save_path), exist_ok=True)
     gif = aux.convert_seq2gif(videos)
     save_gif(save_path + "results.gif", gif, fps=3)
+    if args.raw_npy:
+        np.save(args.raw_npy, gif.astype(np.uint8))
     print(f"Animations saved in {save_path}")
 
 

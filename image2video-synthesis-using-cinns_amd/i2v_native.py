@@ -5,6 +5,7 @@ PyTorch-ROCm tensors are used only as containers: every call passes raw device p
 library is missing, or a tensor does not live on a GPU, the call raises.
 """
 import ctypes
+import functools
 import os
 import subprocess
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
@@ -95,6 +96,9 @@ SYMBOLS = {
     "i2v_dec_set_profile": (c_int32, [c_void_p, c_int32]),
     "i2v_dec_debug_tap": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t]),
     "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "i2v_dec_status": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_void_p]),
+    "i2v_dec_get_layer_profile": (c_int32, [c_void_p, c_int32, ctypes.c_char_p, c_int32, POINTER(c_double), POINTER(c_double),
+                                            POINTER(c_double), POINTER(c_int64), POINTER(c_int32)]),
 }
 
 
@@ -144,6 +148,36 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _device_of(device):
+    """torch.device of a handle: an explicit cuda device, else the current one.  A handle owns packed weights on ONE GPU."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise I2VError("libi2v_hip needs a HIP device (torch.cuda.is_available() is False); this package has no CPU fallback")
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise I2VError(f"libi2v_hip kernels run on HIP devices only (got '{device}'); this package has no CPU fallback -- "
+                       "move the module and its inputs to 'cuda'")
+    return torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+
+
+class _Handle:
+    """Common part of the native handles: the device binding.  Creation, load and every call run with the handle's device
+    current (``torch.cuda.device``), so the weights, the launches and the stream all belong to the GPU the tensors live on;
+    tensors on another device are rejected (the C side checks the same thing and returns I2V_E_INVALID)."""
+
+    def _bind(self, device):
+        self.device = _device_of(device)
+        return torch.cuda.device(self.device)
+
+    def _on(self, *tensors):
+        for t in tensors:
+            if t is not None and t.is_cuda and t.device != self.device:
+                raise I2VError(f"tensor on {t.device} passed to a handle that lives on {self.device}: a native handle serves one GPU "
+                               "(move the module with .to(device) -- that rebuilds the handle -- or the input)")
+        return torch.cuda.device(self.device)
+
+
 def _pack_state_dict(sd):
     """{key: tensor/ndarray} -> (ctypes array of i2v_tensor, keep-alive list)."""
     keep, items = [], []
@@ -178,15 +212,26 @@ class _Workspace:
         return self.buf
 
 
-class NativeFlow:
+def _on_device(fn):
+    """Method decorator of the native handles: reject tensors that live on another GPU, run with the handle's device current."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        tensors = [t for t in list(args) + list(kwargs.values()) if isinstance(t, torch.Tensor)]
+        with self._on(*tensors):
+            return fn(self, *args, **kwargs)
+    return wrapper
+
+
+class NativeFlow(_Handle):
     """Handle for ``i2v_flow_*`` (ConditionalFlow, flow_blocks.py:8-60)."""
 
     def __init__(self, in_channels, embedding_dim, hidden_dim, hidden_depth, n_flows, control=False,
-                 activation="lrelu", skip_actnorm=False, skip_shuffle=False, use_graph=True):
+                 activation="lrelu", skip_actnorm=False, skip_shuffle=False, use_graph=True, device=None):
         cfg = FlowCfg(in_channels, embedding_dim, hidden_dim, hidden_depth, n_flows, int(control),
                       1 if activation == "lrelu" else 0, int(skip_actnorm), int(skip_shuffle), int(use_graph))
         h = c_void_p()
-        _check(lib().i2v_flow_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_flow_create")
+        with self._bind(device):
+            _check(lib().i2v_flow_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_flow_create")
         self._h = h
         self.embedding_dim = embedding_dim
         self._ws = _Workspace()
@@ -196,6 +241,7 @@ class NativeFlow:
             _lib.i2v_flow_destroy(self._h)
             self._h = None
 
+    @_on_device
     def load(self, state_dict):
         arr, keep = _pack_state_dict(state_dict)
         _check(lib().i2v_flow_load(self._h, arr, len(arr)), "i2v_flow_load")
@@ -205,6 +251,7 @@ class NativeFlow:
     def param_bytes(self):
         return int(lib().i2v_flow_param_bytes(self._h))
 
+    @_on_device
     def _run(self, x, embed, reverse):
         _require_gpu(x, embed)
         B = x.shape[0]
@@ -222,6 +269,7 @@ class NativeFlow:
                                       ws.data_ptr(), ws.numel(), B, _stream()), "i2v_flow_forward")
         return out, logdet
 
+    @_on_device
     def forward(self, x, embed):
         return self._run(x, embed, False)
 
@@ -229,14 +277,15 @@ class NativeFlow:
         return self._run(x, embed, True)
 
 
-class NativeDecoder:
+class NativeDecoder(_Handle):
     """Handle for ``i2v_dec_*`` (Generator, decoder.py:55-120)."""
 
-    def __init__(self, channel_factor, z_dim, upsample_s, upsample_t, spectral_norm=True, mma=0):
+    def __init__(self, channel_factor, z_dim, upsample_s, upsample_t, spectral_norm=True, mma=0, device=None):
         cfg = DecCfg(channel_factor, z_dim, (c_int32 * 2)(*upsample_s), (c_int32 * 2)(*upsample_t),
                      int(bool(spectral_norm)), mma)
         h = c_void_p()
-        _check(lib().i2v_dec_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_dec_create")
+        with self._bind(device):
+            _check(lib().i2v_dec_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_dec_create")
         self._h = h
         self.z_dim = z_dim
         self._ws = _Workspace()
@@ -249,6 +298,7 @@ class NativeDecoder:
             _lib.i2v_dec_destroy(self._h)
             self._h = None
 
+    @_on_device
     def load(self, state_dict):
         arr, keep = _pack_state_dict(state_dict)
         _check(lib().i2v_dec_load(self._h, arr, len(arr)), "i2v_dec_load")
@@ -257,15 +307,40 @@ class NativeDecoder:
     def flops_per_sample(self, img_h, img_w):
         return float(lib().i2v_dec_flops_per_sample(self._h, img_h, img_w))
 
+    @_on_device
     def set_profile(self, on):
         _check(lib().i2v_dec_set_profile(self._h, int(on)), "i2v_dec_set_profile")
 
+    @_on_device
     def get_profile(self):
         a, b, e, c = c_double(), c_double(), c_double(), c_int64()
         _check(lib().i2v_dec_get_profile(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(e), ctypes.byref(c)),
                "i2v_dec_get_profile")
         return {"conv3_ms": a.value, "conv3_flops": b.value, "conv3_mfma_flops": e.value, "conv3_launches": c.value}
 
+    @_on_device
+    def get_layer_profile(self):
+        """Per-layer totals of the profiled 3x3x3 conv launches since set_profile(True) (i2v_dec_get_layer_profile)."""
+        rows = []
+        for layer in range(12):
+            name = ctypes.create_string_buffer(48)
+            ms, fl, ex, n, k = c_double(), c_double(), c_double(), c_int64(), c_int32()
+            _check(lib().i2v_dec_get_layer_profile(self._h, layer, name, 48, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ex),
+                                                   ctypes.byref(n), ctypes.byref(k)), "i2v_dec_get_layer_profile")
+            if n.value:
+                rows.append({"layer": name.value.decode(), "kernel": ("conv_mfma_f32", "conv_mfma_f16x3", "conv_wino_f16x3")[k.value],
+                             "launches": int(n.value), "ms": ms.value, "flops": fl.value, "mfma_flops": ex.value})
+        return rows
+
+    @_on_device
+    def status(self, reset=False):
+        """Range guard of the split-fp16 operand format (i2v_dec_status): synchronises the current stream and returns the
+        sticky flag word (bit 0: an activation left the fp16 range, the outputs since then are invalid)."""
+        flags = c_int32()
+        _check(lib().i2v_dec_status(self._h, ctypes.byref(flags), int(bool(reset)), _stream()), "i2v_dec_status")
+        return int(flags.value)
+
+    @_on_device
     def debug_tap(self, block, which, dst):
         """Test hook (i2v_dec_debug_tap): dst = float32 CUDA tensor or None."""
         if dst is None:
@@ -273,6 +348,7 @@ class NativeDecoder:
         else:
             _check(lib().i2v_dec_debug_tap(self._h, block, which, dst.data_ptr(), dst.numel()), "i2v_dec_debug_tap")
 
+    @_on_device
     def forward(self, img, motion):
         _require_gpu(img, motion)
         B = img.shape[0]
@@ -287,12 +363,13 @@ class NativeDecoder:
         return out
 
 
-class NativeMLP:
+class NativeMLP(_Handle):
     """Handle for ``i2v_mlp_*`` (BasicFullyConnectedNet, modules.py:9-30)."""
 
-    def __init__(self, dim, hidden_dim, depth, out_dim):
+    def __init__(self, dim, hidden_dim, depth, out_dim, device=None):
         h = c_void_p()
-        _check(lib().i2v_mlp_create(dim, hidden_dim, depth, out_dim, ctypes.byref(h)), "i2v_mlp_create")
+        with self._bind(device):
+            _check(lib().i2v_mlp_create(dim, hidden_dim, depth, out_dim, ctypes.byref(h)), "i2v_mlp_create")
         self._h = h
         self.dim, self.out_dim = dim, out_dim
         self._ws = _Workspace()
@@ -302,11 +379,13 @@ class NativeMLP:
             _lib.i2v_mlp_destroy(self._h)
             self._h = None
 
+    @_on_device
     def load(self, state_dict):
         arr, keep = _pack_state_dict(state_dict)
         _check(lib().i2v_mlp_load(self._h, arr, len(arr)), "i2v_mlp_load")
         del keep
 
+    @_on_device
     def forward(self, x):
         _require_gpu(x)
         if x.dim() != 2 or x.shape[1] != self.dim:
@@ -329,9 +408,10 @@ def _channel_op(op, x, p0=None, p1=None, idx=None, alpha=0.0):
     B, C = x.shape[0], x.shape[1]
     inner = x.numel() // (B * C)
     out = torch.empty_like(x)
-    _check(lib().i2v_channel_op(op, x.data_ptr(), out.data_ptr(), B, C, inner,
-                                p0.data_ptr() if p0 is not None else None, p1.data_ptr() if p1 is not None else None,
-                                idx.data_ptr() if idx is not None else None, float(alpha), _stream()), "i2v_channel_op")
+    with torch.cuda.device(x.device):
+        _check(lib().i2v_channel_op(op, x.data_ptr(), out.data_ptr(), B, C, inner,
+                                    p0.data_ptr() if p0 is not None else None, p1.data_ptr() if p1 is not None else None,
+                                    idx.data_ptr() if idx is not None else None, float(alpha), _stream()), "i2v_channel_op")
     return out
 
 
@@ -347,8 +427,9 @@ def actnorm_logdet(scale, hw, batch):
     scale = scale.detach().reshape(-1).contiguous()
     _require_gpu(scale)
     out = torch.empty(batch, dtype=torch.float32, device=scale.device)
-    _check(lib().i2v_actnorm_logdet(scale.data_ptr(), scale.numel(), float(hw), out.data_ptr(), batch, _stream()),
-           "i2v_actnorm_logdet")
+    with torch.cuda.device(scale.device):
+        _check(lib().i2v_actnorm_logdet(scale.data_ptr(), scale.numel(), float(hw), out.data_ptr(), batch, _stream()),
+               "i2v_actnorm_logdet")
     return out
 
 
@@ -390,7 +471,8 @@ def channel_mean_std(flat):
     C, N = flat.shape
     mean = torch.empty(C, dtype=torch.float32, device=flat.device)
     std = torch.empty(C, dtype=torch.float32, device=flat.device)
-    _check(lib().i2v_row_mean_std(flat.data_ptr(), C, N, mean.data_ptr(), std.data_ptr(), _stream()), "i2v_row_mean_std")
+    with torch.cuda.device(flat.device):
+        _check(lib().i2v_row_mean_std(flat.data_ptr(), C, N, mean.data_ptr(), std.data_ptr(), _stream()), "i2v_row_mean_std")
     return mean, std
 
 
@@ -399,13 +481,14 @@ def default_mma():
     return int(os.environ.get("I2V_DEC_MMA", "1"))
 
 
-class NativeGBlock:
+class NativeGBlock(_Handle):
     """Handle for ``i2v_gblock_*`` (GeneratorBlock, decoder.py:7-52; tensors in the reference layout [B,C,T,H,W])."""
 
-    def __init__(self, n_in, n_out, z_dim, spectral_norm=True, mma=None):
+    def __init__(self, n_in, n_out, z_dim, spectral_norm=True, mma=None, device=None):
         h = c_void_p()
-        _check(lib().i2v_gblock_create(n_in, n_out, z_dim, int(bool(spectral_norm)), default_mma() if mma is None else mma,
-                                       ctypes.byref(h)), "i2v_gblock_create")
+        with self._bind(device):
+            _check(lib().i2v_gblock_create(n_in, n_out, z_dim, int(bool(spectral_norm)), default_mma() if mma is None else mma,
+                                           ctypes.byref(h)), "i2v_gblock_create")
         self._h = h
         self.n_in, self.n_out, self.n_mid, self.z_dim = n_in, n_out, min(n_in, n_out), z_dim
         self._ws = _Workspace()
@@ -415,6 +498,7 @@ class NativeGBlock:
             _lib.i2v_gblock_destroy(self._h)
             self._h = None
 
+    @_on_device
     def load(self, state_dict):
         arr, keep = _pack_state_dict(state_dict)
         _check(lib().i2v_gblock_load(self._h, arr, len(arr)), "i2v_gblock_load")
@@ -427,6 +511,7 @@ class NativeGBlock:
         ws = self._ws.get(lib().i2v_gblock_workspace_bytes(self._h, B, T, H, W), x.device)
         return B, T, H, W, ws
 
+    @_on_device
     def forward(self, x, z, img):
         _require_gpu(x, z, img)
         B, T, H, W, ws = self._geom(x, self.n_in)
@@ -437,6 +522,7 @@ class NativeGBlock:
                                         out.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, W, _stream()), "i2v_gblock_forward")
         return out
 
+    @_on_device
     def norm(self, part, x, cond):
         _require_gpu(x, cond)
         B, T, H, W, ws = self._geom(x, self.n_mid if part == 1 else self.n_in)
@@ -457,9 +543,9 @@ class NativeNorm:
     """A lone Spade / ADAIN / Norm3D (normalization_layer.py:5-51) on top of a partially loaded ``i2v_gblock``."""
     _PART = {"spade": (0, "norm_0."), "adain": (1, "norm_1."), "norm3d": (2, "norm_s.")}
 
-    def __init__(self, kind, num_features, z_dim, mma=None):
+    def __init__(self, kind, num_features, z_dim, mma=None, device=None):
         self.part, self.prefix = self._PART[kind]
-        self.blk = NativeGBlock(num_features, num_features, z_dim if z_dim else 64, spectral_norm=False, mma=mma)
+        self.blk = NativeGBlock(num_features, num_features, z_dim if z_dim else 64, spectral_norm=False, mma=mma, device=device)
 
     def load(self, state_dict):
         self.blk.load({self.prefix + k: v for k, v in state_dict.items()})
@@ -468,12 +554,13 @@ class NativeNorm:
         return self.blk.norm(self.part, x, cond)
 
 
-class NativeEmbedder:
+class NativeEmbedder(_Handle):
     """Handle for ``i2v_embedder_*`` (ResnetEncoder.encode(x).mode(), AE.py:91-166)."""
 
-    def __init__(self, z_dim, use_batchnorm):
+    def __init__(self, z_dim, use_batchnorm, device=None):
         h = c_void_p()
-        _check(lib().i2v_embedder_create(z_dim, int(bool(use_batchnorm)), ctypes.byref(h)), "i2v_embedder_create")
+        with self._bind(device):
+            _check(lib().i2v_embedder_create(z_dim, int(bool(use_batchnorm)), ctypes.byref(h)), "i2v_embedder_create")
         self._h = h
         self.z_dim = z_dim
         self._ws = _Workspace()
@@ -483,11 +570,13 @@ class NativeEmbedder:
             _lib.i2v_embedder_destroy(self._h)
             self._h = None
 
+    @_on_device
     def load(self, state_dict):
         arr, keep = _pack_state_dict(state_dict)
         _check(lib().i2v_embedder_load(self._h, arr, len(arr)), "i2v_embedder_load")
         del keep
 
+    @_on_device
     def forward(self, img):
         _require_gpu(img)
         if img.dim() != 4 or img.shape[1] != 3:
@@ -500,13 +589,14 @@ class NativeEmbedder:
         return out
 
 
-class NativeEncoder3D:
+class NativeEncoder3D(_Handle):
     """Handle for ``i2v_encoder3d_*`` (Encoder.forward, resnet3D.py:138-219)."""
 
-    def __init__(self, z_dim, channels, stride_s, stride_t):
+    def __init__(self, z_dim, channels, stride_s, stride_t, device=None):
         cfg = Enc3dCfg(z_dim, (c_int32 * 5)(*channels), (c_int32 * 4)(*stride_s), (c_int32 * 4)(*stride_t), 0)
         h = c_void_p()
-        _check(lib().i2v_encoder3d_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_encoder3d_create")
+        with self._bind(device):
+            _check(lib().i2v_encoder3d_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_encoder3d_create")
         self._h = h
         self.z_dim = z_dim
         self._ws = _Workspace()
@@ -516,11 +606,13 @@ class NativeEncoder3D:
             _lib.i2v_encoder3d_destroy(self._h)
             self._h = None
 
+    @_on_device
     def load(self, state_dict):
         arr, keep = _pack_state_dict(state_dict)
         _check(lib().i2v_encoder3d_load(self._h, arr, len(arr)), "i2v_encoder3d_load")
         del keep
 
+    @_on_device
     def forward(self, x, eps=None):
         _require_gpu(x, eps)
         if x.dim() != 5 or x.shape[1] != 3:

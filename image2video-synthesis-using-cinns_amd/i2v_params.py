@@ -70,6 +70,16 @@ class AffineParams(_NoForward):
         self.bias = nn.Parameter(torch.zeros(num_features))
 
 
+def _adopt(parent, value):
+    """Record ``parent`` as the NativeBacked ancestor of the NativeBacked modules reachable from ``value`` (a module, or a
+    container such as nn.ModuleList / nn.Sequential) that have no recorded ancestor yet (a nested owner -- a GeneratorBlock
+    inside the Generator -- has already adopted its own children when it was constructed)."""
+    if isinstance(value, nn.Module):
+        for m in value.modules():
+            if m is not parent and isinstance(m, NativeBacked) and m.__dict__.get("_native_parent") is None:
+                object.__setattr__(m, "_native_parent", parent)
+
+
 class NativeBacked(nn.Module):
     """Mixin: lazily builds the native handle from the module's own state_dict and drops it whenever the
     parameters may have changed (load_state_dict, .to()/.cuda(), explicit refresh_native())."""
@@ -77,10 +87,28 @@ class NativeBacked(nn.Module):
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_native", None)
+        object.__setattr__(self, "_native_parent", None)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_native())
 
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        _adopt(self, value)
+
     def refresh_native(self):
-        object.__setattr__(self, "_native", None)
+        """Drop this module's handle and those of every NativeBacked ancestor that packed this module's parameters into its
+        own handle (e.g. ``gen.g_0.load_state_dict(...)`` must invalidate ``gen``'s decoder handle too)."""
+        m = self
+        while m is not None:
+            object.__setattr__(m, "_native", None)
+            m = m.__dict__.get("_native_parent")
+
+    def module_device(self):
+        """Device the parameters live on (the device the native handle is created on)."""
+        for t in self.parameters():
+            return t.device
+        for t in self.buffers():
+            return t.device
+        return None
 
     def _apply(self, fn, *a, **k):
         self.refresh_native()

@@ -30,7 +30,7 @@ class GeneratorBlock(NativeBacked):
             self.norm_s = Norm3D(n_in)
 
     def _build_native(self):
-        h = native.NativeGBlock(self.n_in, self.n_out, self.z_dim, self.use_spectral)
+        h = native.NativeGBlock(self.n_in, self.n_out, self.z_dim, self.use_spectral, device=self.module_device())
         h.load(self.state_dict())
         return h
 
@@ -68,7 +68,7 @@ class Generator(NativeBacked):
 
     def _build_native(self):
         h = native.NativeDecoder(self.channel_factor, self.z_dim, self.upsample_s, self.upsample_t, self.use_spectral,
-                                 mma=self.mma)
+                                 mma=self.mma, device=self.module_device())
         h.load(self.state_dict())
         return h
 

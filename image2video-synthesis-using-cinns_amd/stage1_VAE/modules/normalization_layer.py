@@ -24,7 +24,7 @@ class Spade(NativeBacked):
         self.conv_beta = ConvParams(128, num_features, 3, 2)
 
     def _build_native(self):
-        h = native.NativeNorm("spade", self.num_features, 0)
+        h = native.NativeNorm("spade", self.num_features, 0, device=self.module_device())
         h.load(self.state_dict())
         return h
 
@@ -43,7 +43,7 @@ class Norm3D(NativeBacked):
         self.bn = AffineParams(num_features)
 
     def _build_native(self):
-        h = native.NativeNorm("norm3d", self.num_features, 0)
+        h = native.NativeNorm("norm3d", self.num_features, 0, device=self.module_device())
         h.load(self.state_dict())
         return h
 
@@ -61,7 +61,7 @@ class ADAIN(NativeBacked):
         self.linear = LinearParams(z_dim, num_features * 2)
 
     def _build_native(self):
-        h = native.NativeNorm("adain", self.num_features, self.z_dim)
+        h = native.NativeNorm("adain", self.num_features, self.z_dim, device=self.module_device())
         h.load(self.state_dict())
         return h
 

@@ -62,7 +62,7 @@ class Encoder(NativeBacked):
         self.conv_var = ConvParams(self.channels[-1], self.z_dim, 4, 2, bias=True)
 
     def _build_native(self):
-        h = native.NativeEncoder3D(self.z_dim, self.channels, self.stride_s, self.stride_t)
+        h = native.NativeEncoder3D(self.z_dim, self.channels, self.stride_s, self.stride_t, device=self.module_device())
         h.load(self.state_dict())
         return h
 

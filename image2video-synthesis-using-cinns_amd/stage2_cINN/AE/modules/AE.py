@@ -91,7 +91,7 @@ class ResnetEncoder(NativeBacked):
         self.model.fc = DenseEncoderLayer(0, spatial_size=1, out_size=2 * self.z_dim, in_channels=2048)
 
     def _build_native(self):
-        h = native.NativeEmbedder(self.z_dim, self.norm == "bn")
+        h = native.NativeEmbedder(self.z_dim, self.norm == "bn", device=self.module_device())
         h.load({k: v for k, v in self.state_dict().items() if not k.endswith("num_batches_tracked")})
         return h
 

@@ -58,7 +58,8 @@ class SupervisedTransformer(nn.Module):
                                    "were not found under Conditioning_Model.model_path); pass embed=[B,E] explicitly")
             with torch.no_grad():
                 embed = self.embedder.encode(cond[0]).mode().reshape(input.size(0), -1).detach()
-        if self.control:
+        if self.control and embed.shape[1] == self.flow.cond_channels - 3 * self.cond_size:
+            # (a caller-supplied embedding may already carry the 30 position one-hots: full width -> used as is)
             embed = torch.cat((embed, self.embed_pos(cond[1]).to(embed)), dim=1)
         return embed.contiguous()
 

@@ -35,15 +35,21 @@ class ConditionalFlow(NativeBacked):
             # the sampling path always passes "None" (get_model.py:40); the per-block 1x1 conditioning convs of
             # the "parallel"/"sequential" options (flow_blocks.py:28-40) are outside the hot path
             raise NotImplementedError("ConditionalFlow: only conditioning_option='none' is supported")
-        self.sub_layers = nn.ModuleList()
+        layers = []
         for fl in range(n_flows):
             mode = "cond" if (fl % 4 != 0 and control) else "normal"
-            self.sub_layers.append(ConditionalFlatDoubleCouplingFlowBlock(
+            layers.append(ConditionalFlatDoubleCouplingFlowBlock(
                 in_channels, embedding_dim, hidden_dim, hidden_depth, activation=activation, mode=mode))
+        self.sub_layers = nn.ModuleList(layers)
+        # the reference records every block's output / log-det of the last forward in these two lists
+        # (flow_blocks.py:34-35,49-50); here that costs 20 separate block launches instead of one fused pass, so it is
+        # opt-in: set ``record_intermediates = True`` (the lists stay empty otherwise)
+        self.record_intermediates = False
+        self._init_checked = False
 
     def _build_native(self):
         h = native.NativeFlow(self.in_channels, self.cond_channels, self.mid_channels, self.num_blocks, self.n_flows,
-                              control=1 if self.control else 0, activation=self.activation)
+                              control=1 if self.control else 0, activation=self.activation, device=self.module_device())
         h.load(self.state_dict())
         return h
 
@@ -53,15 +59,36 @@ class ConditionalFlow(NativeBacked):
         h = x
         for blk in self.sub_layers:
             h, _ = blk(h[:, :, None, None], embedding[:, :, None, None])
-        self.refresh_native()
+        super().refresh_native()
+
+    def refresh_native(self):
+        super().refresh_native()
+        object.__setattr__(self, "_init_checked", False)  # parameters may have changed: look at `initialized` again
+
+    def _forward_recorded(self, x2, e2):
+        """Block-by-block forward that fills last_outs / last_logdets like flow_blocks.py:42-51."""
+        h, logdet = x2[:, :, None, None], 0.0
+        e4 = e2[:, :, None, None]
+        for blk in self.sub_layers:
+            h, ld = blk(h.reshape(h.shape[0], -1, 1, 1), e4)
+            logdet = logdet + ld
+            self.last_outs.append(h)
+            self.last_logdets.append(ld)
+        return h[:, :, None, None], logdet
 
     def forward(self, x, embedding, reverse=False):
         self.last_outs, self.last_logdets = [], []
         x2 = x.reshape(x.shape[0], -1).contiguous()
         e2 = embedding.reshape(embedding.shape[0], -1).contiguous()
         if not reverse:
-            if self._native is None and any(int(b.norm_layer.initialized.item()) == 0 for b in self.sub_layers):
-                self._data_dependent_init(x2, e2)  # checked only when the native handle is (re)built: no per-call sync
+            # Q1: the `initialized` buffers are looked at on the first FORWARD after every (re)load / move, whether or not a
+            # reverse pass has already built the native handle (no per-call device sync afterwards)
+            if not self._init_checked:
+                if any(int(b.norm_layer.initialized.item()) == 0 for b in self.sub_layers):
+                    self._data_dependent_init(x2, e2)
+                object.__setattr__(self, "_init_checked", True)
+            if self.record_intermediates:
+                return self._forward_recorded(x2, e2)
             out, logdet = self.native().forward(x2, e2)
             return out[:, :, None, None], logdet
         return self.native().inverse(x2, e2)[:, :, None, None]
@@ -86,7 +113,7 @@ class ConditionalDoubleVectorCouplingBlock(NativeBacked):
     def _build_native(self):
         c, e, hdim, depth = self._geom
         h = native.NativeFlow(c, e, hdim, depth, 1, control=2 if self.mode != "normal" else 0, activation="none",
-                              skip_actnorm=True, skip_shuffle=True)
+                              skip_actnorm=True, skip_shuffle=True, device=self.module_device())
         h.load(_prefixed(self, "sub_layers.0.coupling."))
         return h
 
@@ -114,7 +141,8 @@ class ConditionalFlatDoubleCouplingFlowBlock(NativeBacked):
 
     def _build_native(self):
         c, e, hdim, depth, act, mode = self._geom
-        h = native.NativeFlow(c, e, hdim, depth, 1, control=2 if mode != "normal" else 0, activation=act)
+        h = native.NativeFlow(c, e, hdim, depth, 1, control=2 if mode != "normal" else 0, activation=act,
+                              device=self.module_device())
         h.load(_prefixed(self, "sub_layers.0."))
         return h
 

@@ -26,7 +26,7 @@ class BasicFullyConnectedNet(NativeBacked):
         self.main = nn.Sequential(*layers)
 
     def _build_native(self):
-        h = native.NativeMLP(self.dim, self.hidden_dim, self.depth, self.out_dim)
+        h = native.NativeMLP(self.dim, self.hidden_dim, self.depth, self.out_dim, device=self.module_device())
         h.load({k: v for k, v in self.state_dict().items()})
         return h
 

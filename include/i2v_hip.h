@@ -34,6 +34,7 @@ extern "C" {
 #define I2V_E_HIP (-3)       /* a HIP runtime call failed */
 #define I2V_E_WORKSPACE (-4) /* workspace too small */
 #define I2V_E_STATE (-5)     /* weights not loaded */
+#define I2V_E_RANGE (-6)     /* an activation left the fp16 range of the split-fp16 operand format (see i2v_dec_status) */
 
 #define I2V_F32 0
 #define I2V_I64 1
@@ -159,9 +160,21 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
  * FLOPs actually issued (3 per product in split-fp16 mode, 18 of 27 taps in temporal-duplication mode) and launches. */
 int i2v_dec_set_profile(i2v_dec* d, int32_t on);
 int i2v_dec_get_profile(i2v_dec* d, double* conv3_ms, double* conv3_flops, double* conv3_mfma_flops, int64_t* conv3_launches);
+/* The same totals per layer: layer = 2 * block + {0: conv_0, 1: conv_1}, block 0..5 = head_0, g_0 .. g_4 (decoder.py:74-79).
+ * name receives "<block>.conv_<i>"; kernel: 0 = fp32 MFMA implicit GEMM, 1 = split-fp16 direct, 2 = split-fp16 Winograd. */
+int i2v_dec_get_layer_profile(i2v_dec* d, int32_t layer, char* name, int32_t name_len, double* ms, double* flops,
+                              double* mfma_flops, int64_t* launches, int32_t* kernel);
 /* Test hook: during the next forwards copy up to max_floats of one channels-last intermediate of GeneratorBlock
  * `block` (0 = head_0 .. 5 = g_4) into dst (device).  which: 0 = SPADE (1+gamma | beta) [B,H,W,2C], 1 = lrelu(Spade(x)),
  * 2 = conv_0 output, 3 = lrelu(ADAIN(.)), 4 = shortcut (low resolution), 5 = block output.  dst = NULL disables. */
+/* Range guard of the split-fp16 ("hl16") operand format (mma = 1): the kernels that produce conv operands raise a sticky
+ * device flag when a value is non-finite or exceeds the fp16 range (|x| > 65504 -- a regime no synthetic-weight parity
+ * test reaches, but a released checkpoint with a large SPADE (1 + gamma) might).  Nothing synchronises on the fast path:
+ * every i2v_dec_forward ends with an async copy of the flag to pinned host memory, and the NEXT i2v_dec_forward (or
+ * i2v_gblock_forward) on the handle returns I2V_E_RANGE when it finds it set.  i2v_dec_status synchronises `stream`, reads
+ * the flag (bit 0 = overflow seen) and optionally clears it; use mma = 0 (exact fp32 MFMA) for such checkpoints. */
+int i2v_dec_status(i2v_dec* d, int32_t* flags, int32_t reset, void* stream);
+
 int i2v_dec_debug_tap(i2v_dec* d, int32_t block, int32_t which, float* dst, size_t max_floats);
 
 /* ------------------------------------------------------------------------------------------

@@ -259,6 +259,26 @@ def model_small():
          yq3_shape=np.array(yq3.shape), yq3_t4=yq3[:, ::4].contiguous(), y20_shape=np.array(y20.shape))
 
 
+def model_t32_128():
+    # cfg5 geometry (128x128, nf = 32, E = 128, vid_length = 32): the get_model.py:65-75 sequence with the reference
+    # flow + decoder, B = 2 -> two dependent decoder passes; frames stored on a stride-4 pixel lattice (all 32 frames)
+    g, dargs = _gen(32, [2, 2], [2, 1], 7)
+    fargs = dict(seed=7, n_flows=20, embedding_dim=128, control=False)
+    flow = ref_fb.ConditionalFlow(64, 128, 512, 2, 20, conditioning_option="None").eval()
+    flow.load_state_dict(T(synth.flow_state_dict(**fargs)))
+    x0 = 2 * torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(81)) - 1
+    r, e = rnd(82, 2, 64), rnd(83, 2, 128)
+    z = flow(r, e, reverse=True).view(2, -1)
+    seq = g(x0, z)
+    while seq.shape[1] < 32:
+        seq = torch.cat((seq, g(seq[:, -1], z)), dim=1)
+    assert tuple(seq.shape) == (2, 32, 3, 128, 128)
+    save("model_nf32_128_t32", dict(synth_dec=dargs, synth_flow=fargs, upsample_s=[2, 2], upsample_t=[2, 1], stride=4),
+         x0=x0, r=r, e=e, z=z, out_s4=seq[..., ::4, ::4].contiguous())
+    print("   nf32 128 T=32 |y| mean", float(seq.abs().mean()), "max", float(seq.abs().max()),
+          "second pass |y| mean", float(seq[:, 16:].abs().mean()))
+
+
 def encoder3d():
     # N3: the motion Encoder of the reference (stage1_VAE/modules/resnet3D.py:138-219), BAIR and landscape geometries
     from stage1_VAE.modules import resnet3D as ref_r3d
@@ -277,7 +297,8 @@ def encoder3d():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["flow_units", "flow_full", "dec_units", "dec_small", "dec_full", "model_small", "encoder3d"]
+    which = sys.argv[1:] or ["flow_units", "flow_full", "dec_units", "dec_small", "dec_full", "model_small", "encoder3d",
+                             "model_t32_128"]
     if "flow_units" in which:
         flow_units()
     if "flow_full" in which:
@@ -294,3 +315,5 @@ if __name__ == "__main__":
         model_small()
     if "encoder3d" in which:
         encoder3d()
+    if "model_t32_128" in which:
+        model_t32_128()

@@ -307,9 +307,12 @@ def test_model_from_pixels_with_embedder(tmp_path):
 
 
 def test_generate_samples_cli(tmp_path, monkeypatch):
-    """The sampling CLI end to end: PNG start frames -> results.gif (B = 5 images, -bs 2 -> short last batch)."""
+    """The sampling CLI end to end: PNG start frames -> results.gif (B = 5 images, -bs 2 -> short last batch), and the
+    frames it writes against convert_seq2gif(oracle chain) for the same latent / embedding draws (row M3)."""
     from PIL import Image
     import generate_samples
+    from oracle import decoder_ref, model_ref
+    from utils import auxiliaries as aux
     _, meta = load_golden("model_nf8")
     ckpt = _write_checkpoints(tmp_path, meta)
     img_dir = tmp_path / "imgs"
@@ -318,10 +321,72 @@ def test_generate_samples_cli(tmp_path, monkeypatch):
     for i in range(5):
         Image.fromarray(rng.integers(0, 255, (48, 72, 3), dtype=np.uint8)).save(img_dir / f"f{i}.png")
     out_dir = tmp_path / "out"
+    torch.manual_seed(123)  # Model draws the residuals from the global CPU generator, like get_model.py:59
     generate_samples.main(["-gpu", os.environ.get("HIP_VISIBLE_DEVICES", "0"), "-dataset", "bair", "-ckpt_path", ckpt,
-                           "-bs", "2", "-embed_seed", "1", "-img_path", str(img_dir) + "/", "-out_path", str(out_dir) + "/"])
+                           "-bs", "2", "-embed_seed", "1", "-img_path", str(img_dir) + "/", "-out_path", str(out_dir) + "/",
+                           "-raw_npy", str(out_dir / "frames.npy")])
     gif = Image.open(out_dir / "results.gif")
     assert gif.n_frames == 16 and gif.size == (5 * 64, 64)
+    # the same computation through the CPU oracle
+    names = sorted(str(p) for p in img_dir.glob("*.png"))
+    imgs = generate_samples.load_images(names, 64)
+    embeds = torch.randn(5, 64, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(123)
+    fsd = T(synth.flow_state_dict(**meta["synth_flow"]))
+    dsd = decoder_ref.fold_spectral_norm(T(synth.decoder_state_dict(**meta["synth_dec"])))
+    vids = []
+    for i in range(3):
+        x = imgs[2 * i:2 * i + 2]
+        r = torch.randn(x.size(0), 64)
+        vids.append(model_ref.model_forward(fsd, dsd, x, r, embeds[2 * i:2 * i + 2], 16, upsample_s=meta["upsample_s"],
+                                            upsample_t=meta["upsample_t"], faithful=False))
+    ref = aux.convert_seq2gif(torch.cat(vids)).astype(np.uint8)
+    raw = np.load(out_dir / "frames.npy")
+    assert raw.shape == ref.shape == (16, 64, 5 * 64, 3) and raw.dtype == np.uint8
+    diff = np.abs(raw.astype(np.int16) - ref.astype(np.int16))
+    assert int(diff.max()) <= 1 and float((diff > 0).mean()) < 0.01, (int(diff.max()), float((diff > 0).mean()))
+    # the GIF itself carries the same strip up to palette quantisation
+    gif.seek(3)
+    g3 = np.asarray(gif.convert("RGB"), dtype=np.int16)
+    assert float(np.abs(g3 - ref[3].astype(np.int16)).mean()) < 12.0
+
+
+def test_sample_prior_loop_vs_oracle():
+    """Row N4: the prior-sampling loop of the reference's evaluate_FVD_prior (utils/auxiliaries.py:87-101) -- second caller
+    of cINN^-1 + decoder -- over a small loader, vs the oracle chain on the same latent draws."""
+    from oracle import decoder_ref, flow_ref
+    from stage2_cINN.modules.INN import SupervisedTransformer
+    from utils import auxiliaries as aux
+    _, meta = load_golden("model_nf8")
+    gen = _gen(dict(synth=meta["synth_dec"], upsample_s=meta["upsample_s"], upsample_t=meta["upsample_t"]))
+
+    class PooledEmbedder:   # test scaffolding: a deterministic stand-in for the conditioning embedder (encode(x).mode())
+        def encode(self, x):
+            e = torch.nn.functional.adaptive_avg_pool2d(x, (4, 4)).reshape(x.size(0), -1)[:, :32]
+            e = torch.cat((e, -e), dim=1)[:, :, None, None]
+            return type("D", (), {"mode": lambda self_, e=e: e})()
+
+    st = SupervisedTransformer(flow_in_channels=64, flow_mid_channels=512, flow_hidden_depth=2, n_flows=20,
+                               flow_conditioning_option="None", flow_embedding_channels=64, control=False, dic=None,
+                               embedder=PooledEmbedder())
+    fsd = T(synth.flow_state_dict(**meta["synth_flow"]))
+    st.flow.load_state_dict(fsd)
+    st = st.cuda().eval()
+    g = torch.Generator().manual_seed(17)
+    loader = [{"seq": 2 * torch.rand(b, 17, 3, 64, 64, generator=g) - 1} for b in (2, 1)]
+    seq_gen, seq_orig = aux.sample_prior(loader, st, gen, 64, generator=torch.Generator().manual_seed(5))
+    assert seq_gen.shape == (3, 16, 3, 64, 64) and seq_orig.shape == (3, 16, 3, 64, 64) and not seq_gen.is_cuda
+    assert torch.equal(seq_orig, torch.cat([f["seq"][:, 1:] for f in loader]))
+    dsd = decoder_ref.fold_spectral_norm(T(synth.decoder_state_dict(**meta["synth_dec"])))
+    gr = torch.Generator().manual_seed(5)
+    refs = []
+    for f in loader:
+        x0 = f["seq"][:, 0]
+        res = torch.randn(x0.size(0), 64, generator=gr)
+        emb = PooledEmbedder().encode(x0).mode().reshape(x0.size(0), -1)
+        z = flow_ref.flow_reverse(fsd, res, emb).view(x0.size(0), -1)
+        refs.append(decoder_ref.generator(dsd, x0, z, meta["upsample_s"], meta["upsample_t"], faithful=False))
+    assert rel_l2(seq_gen, torch.cat(refs)) < TOL
 
 
 @pytest.mark.parametrize("norm,size", [("in", 64), ("bn", 128), ("in", 128)])
@@ -441,6 +506,141 @@ def test_full_size_properties_bair_b8():
     lo = gen(x0[:3].cuda().contiguous(), residual[:3].cuda().contiguous())
     hi = gen(x0[3:].cuda().contiguous(), residual[3:].cuda().contiguous())
     assert torch.equal(torch.cat((lo, hi)), out)
+
+
+def test_model_128_t32_vs_golden():
+    """BASELINE cfg5 geometry (128x128, nf = 32, E = 128, vid_length = 32 -> two dependent decoder passes, B = 2) against
+    the reference-generated fixture (get_model.py:65-75 sequence driven with the reference flow + decoder)."""
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    g, meta = load_golden("model_nf32_128_t32")
+    flow = ConditionalFlow(64, 128, 512, 2, 20, conditioning_option="None")
+    flow.load_state_dict(T(synth.flow_state_dict(**meta["synth_flow"])))
+    flow = flow.cuda().eval()
+    gen = _gen(dict(synth=meta["synth_dec"], upsample_s=meta["upsample_s"], upsample_t=meta["upsample_t"]))
+    z = flow(cu(g["r"]), cu(g["e"]), reverse=True).view(2, -1)
+    assert rel_l2(z.cpu(), g["z"]) < TOL
+    x0 = cu(g["x0"])
+    seq = gen(x0, z)
+    while seq.shape[1] < 32:
+        seq = torch.cat((seq, gen(seq[:, -1].contiguous(), z)), dim=1)
+    assert seq.shape == (2, 32, 3, 128, 128) and bool(torch.isfinite(seq).all())
+    assert rel_l2(seq[:, :16, :, ::4, ::4].cpu(), g["out_s4"][:, :16]) < TOL
+    assert rel_l2(seq[:, 16:, :, ::4, ::4].cpu(), g["out_s4"][:, 16:]) < TOL   # second (autoregressive) pass
+
+
+@pytest.mark.parametrize("golden,batch,rows", [("dec_nf64_bair", 64, ((0, 8), (24, 32), (56, 64))),
+                                                ("dec_nf32_128", 32, ((0, 8), (24, 32)))])
+def test_baseline_batch_rows_equal_shards_and_golden(golden, batch, rows):
+    """BASELINE cfg2 (BAIR nf = 64, B = 64) / cfg3 (128x128 nf = 32, B = 32): the full-batch decoder output is what
+    bench.py times.  Its rows must equal the B = 8 shard runs bit for bit (tile selection depends on the batch: samples per
+    brick, channel-tile narrowing, bricks with b0 > 0), and the row that carries the committed golden sample must match
+    the reference-generated frames."""
+    g, meta = load_golden(golden)
+    gen = _gen(meta)
+    size = g["img"].shape[-1]
+    x0, residual, _ = synth.bench_inputs(batch, size, 64)
+    x0[5], residual[5] = torch.from_numpy(g["img"][0]), torch.from_numpy(g["z"][0])
+    x0, z = x0.cuda(), residual.cuda()
+    out = gen(x0, z)
+    assert out.shape == (batch, 16, 3, size, size) and bool(torch.isfinite(out).all()) and float(out.abs().max()) <= 1.0
+    assert rel_l2(out[5:6, ..., ::2, ::2].cpu(), g["out_s2"]) < TOL
+    for lo, hi in rows:
+        shard = gen(x0[lo:hi].contiguous(), z[lo:hi].contiguous())
+        assert torch.equal(shard, out[lo:hi]), (lo, hi, float((shard - out[lo:hi]).abs().max()))
+    assert gen.native().status() == 0
+
+
+def test_flow_large_batches_vs_oracle():
+    """cINN at per-GPU batches above 64 (cfg4 / cfg5 on fewer than 8 GPUs): B = 128 and 256 -- the Bp/64 > 1 grids."""
+    from oracle import flow_ref
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    sd = T(synth.flow_state_dict(seed=7, embedding_dim=128))
+    flow = ConditionalFlow(64, 128, 512, 2, 20, conditioning_option="None")
+    flow.load_state_dict(sd)
+    flow = flow.cuda().eval()
+    _, residual, embed = synth.bench_inputs(256, 64, 128)
+    ref = flow_ref.flow_reverse(sd, residual, embed).reshape(256, 64)
+    for B in (256, 128, 200):
+        z = flow(residual[:B].cuda().contiguous(), embed[:B].cuda().contiguous(), reverse=True).reshape(B, 64)
+        assert rel_l2(z.cpu(), ref[:B]) < TOL, B
+    zt, ld = flow(residual[:128].cuda().contiguous(), embed[:128].cuda().contiguous())
+    ztr, ldr = flow_ref.flow_forward(sd, residual[:128], embed[:128])
+    assert rel_l2(zt.reshape(128, 64).cpu(), ztr.reshape(128, 64)) < TOL and np.allclose(ld.cpu(), ldr, rtol=1e-4, atol=1e-4)
+    # the reference's last_outs / last_logdets side effect (flow_blocks.py:34-35,49-50) is opt-in
+    flow.record_intermediates = True
+    zt2, ld2 = flow(residual[:4].cuda().contiguous(), embed[:4].cuda().contiguous())
+    assert len(flow.last_outs) == 20 and len(flow.last_logdets) == 20
+    assert rel_l2(zt2.reshape(4, 64).cpu(), ztr.reshape(128, 64)[:4]) < TOL and np.allclose(ld2.cpu(), ldr[:4], rtol=1e-4, atol=1e-4)
+    assert np.allclose(sum(flow.last_logdets).cpu(), ldr[:4], rtol=1e-4, atol=1e-4)
+
+
+def test_hl16_range_guard():
+    """A checkpoint whose SPADE (1 + gamma) drives activations past the fp16 range: the split-fp16 path must say so
+    (sticky flag -> I2VError at the next call), the exact-fp32 mode must keep working."""
+    import i2v_native
+    from oracle import decoder_ref
+    from stage1_VAE.modules.decoder import Generator
+    sd = T(synth.decoder_state_dict(seed=5, channel_factor=8))
+    sd["g_2.norm_0.conv_gamma.bias"] = sd["g_2.norm_0.conv_gamma.bias"] * 0 + 3.0e6
+    cfg = {"channel_factor": 8, "z_dim": 64, "upsample_s": [2, 1], "upsample_t": [2, 1], "spectral_norm": True}
+    x0, z, _ = synth.bench_inputs(2, 64, 64)
+    gen = Generator(dict(cfg, mma=1))
+    gen.load_state_dict(sd)
+    gen = gen.cuda().eval()
+    gen(x0.cuda(), z.cuda())                      # enqueues; the flag travels back asynchronously
+    assert gen.native().status() & 1              # on-demand check (synchronises)
+    with pytest.raises(i2v_native.I2VError, match="fp16 range"):
+        gen(x0.cuda(), z.cuda())
+    assert gen.native().status(reset=True) & 1 and gen.native().status() == 0
+    gen0 = Generator(dict(cfg, mma=0))
+    gen0.load_state_dict(sd)
+    out0 = gen0.cuda().eval()(x0.cuda(), z.cuda())
+    ref = decoder_ref.generator(sd, x0, z)
+    assert bool(torch.isfinite(out0).all()) and rel_l2(out0.cpu(), ref) < 1e-3   # (huge activations: looser gate)
+    # and an in-range checkpoint never raises the flag
+    ok = Generator(dict(cfg, mma=1))
+    ok.load_state_dict(T(synth.decoder_state_dict(seed=5, channel_factor=8)))
+    ok = ok.cuda().eval()
+    ok(x0.cuda(), z.cuda())
+    assert ok.native().status() == 0
+
+
+def test_handles_are_bound_to_their_device():
+    """A native handle serves the GPU its module lives on: a tensor from another device is rejected; with one GPU
+    visible the check is exercised through the C ABI's own device test."""
+    import i2v_native
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    flow = ConditionalFlow(64, 64, 512, 2, 2, conditioning_option="None")
+    flow.load_state_dict(T(synth.flow_state_dict(seed=1, n_flows=2, embedding_dim=64)))
+    flow = flow.cuda().eval()
+    x, e = torch.randn(3, 64).cuda(), torch.randn(3, 64).cuda()
+    z = flow(x, e, reverse=True)
+    assert flow.native().device == x.device
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(i2v_native.I2VError):
+            flow(x.to("cuda:1"), e.to("cuda:1"), reverse=True)
+        flow1 = flow.to("cuda:1")       # moving the module rebuilds the handle on the new device
+        with torch.cuda.device(0):      # current device differs from the tensors': the binding switches for the call
+            z1 = flow1(x.to("cuda:1"), e.to("cuda:1"), reverse=True)
+        assert z1.device.index == 1 and torch.equal(z1.cpu(), z.cpu())
+
+
+def test_two_process_rccl_collation(tmp_path):
+    """Two ranks over RCCL ("nccl"), one per GPU: sharded synthesis + overlapped all-gather must reproduce the
+    one-process result bit for bit.  Needs >= 2 GPUs (the driver's multi-GPU box); skipped on a 1-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import subprocess
+    import sys
+    from conftest import REPO
+    script = os.path.join(REPO, "tests", "rccl_worker.py")
+    port = str(29600 + os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(tmp_path)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
 
 
 def test_smoke_entry():

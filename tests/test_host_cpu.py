@@ -105,15 +105,23 @@ def fake_model(x, r, e):   # per-sample function standing in for cINN inverse + 
 out = i2v_dist.synthesize_sharded(fake_model, x0, res, emb)
 ref = fake_model(x0, res, emb)
 assert out.shape == ref.shape and torch.equal(out, ref), (rank, out.shape)
+# embed=None is a legal input of the path (Model computes the embedding itself)
+out_n = i2v_dist.synthesize_sharded(lambda x, r, e: fake_model(x, r, torch.ones(x.shape[0], 5)), x0, res, None)
+assert torch.equal(out_n, fake_model(x0, res, torch.ones(total, 5)))
+# the overlapped collator degrades to the plain all-gather for CPU tensors / ragged shards
+lo, hi = i2v_dist.shard_bounds(total, ws, rank)
+col = i2v_dist.OverlappedCollator(total)
+col.submit(fake_model(x0[lo:hi], res[lo:hi], emb[lo:hi]))   # (a collective: every rank takes part, also with 0 rows)
+assert torch.equal(col.result(), ref)
 dist.destroy_process_group()
 print('ok', rank)
 """
 
 
-@pytest.mark.parametrize("total", [8, 7])
+@pytest.mark.parametrize("total", [8, 7, 1])
 def test_sharded_collation_gloo_world2(total, tmp_path):
     """N > 1 path on CPU: two gloo ranks shard the batch, run a per-sample stand-in model, all-gather; the result must
-    equal the single-process result (even and ragged shards)."""
+    equal the single-process result (even and ragged shards, and total < world size: one rank holds an EMPTY shard)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(pkg=PKG))
     port = str(29500 + (os.getpid() + total) % 2000)
@@ -155,16 +163,23 @@ def test_embed_pos_matches_oracle():
 
 
 def test_bench_evidence_files_parse():
-    """bench.py takes `roofline.traffic` and `roofline_cinn.measured_hbm_bytes_per_pass` from a committed PMC summary:
-    the file must exist and carry the fields bench.py reads (a silent None in the bench line is easy to miss)."""
+    """bench.py takes `roofline.traffic` and `roofline_cinn.measured_hbm_bytes_per_pass` from the newest committed PMC
+    summary and labels them with their source: the file must exist and carry the fields bench.py reads (a silent None in
+    the bench line is easy to miss)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    per_pass = bench.cinn_measured_bytes(True)
+    per_pass, src = bench.cinn_measured_bytes(True)
     assert per_pass is not None and 189e6 < per_pass < 2e9  # at least the parameters, not absurdly more
+    assert src.startswith("static: profiles/") and os.path.exists(os.path.join(REPO, src.split(": ", 1)[1]))
     prof = {"conv3_ms": 10.0, "conv3_flops": 4e12, "conv3_mfma_flops": 1e13, "conv3_launches": 12}
-    r = bench.roofline(prof, 0.06, 1, default_workload=True)
-    assert r["traffic"] is not None and r["traffic"] > 1e9
+    layers = [{"layer": "g_3.conv_0", "kernel": "conv_wino_f16x3", "launches": 2, "ms": 5.0, "flops": 2e12, "mfma_flops": 4e12}]
+    r = bench.roofline(prof, 0.06, 1, default_workload=True, layers=layers, steps=2)
+    assert r["traffic"] is not None and r["traffic"] > 1e9 and r["traffic_source"].startswith("static: profiles/")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["bound"] == "mfma"
-    assert bench.cinn_measured_bytes(False) is None
+    assert r["per_layer"][0]["launches_per_step"] == 1 and abs(r["per_layer"][0]["tflops_algorithmic"] - 400.0) < 1e-9
+    assert bench.cinn_measured_bytes(False) == (None, None)
+    # every BASELINE configuration is a bench workload
+    assert {"bair64", "land128", "dtdb128", "iper128_t32"} <= set(bench.CONFIGS)
+    assert bench.CONFIGS["dtdb128"]["batch"] == 256 and bench.CONFIGS["iper128_t32"]["vid"] == 32

@@ -131,6 +131,17 @@ def test_model_forward_semantics():
     assert list(y20.shape) == list(g["y20_shape"]) == [1, 32, 3, 64, 64]
 
 
+def test_model_128_t32():
+    """cfg5 geometry fixture (128x128, nf = 32, E = 128, two decoder passes): the oracle against the reference's output."""
+    g, meta = load_golden("model_nf32_128_t32")
+    fsd = T(synth.flow_state_dict(**meta["synth_flow"]))
+    dsd = decoder_ref.fold_spectral_norm(T(synth.decoder_state_dict(**meta["synth_dec"])))
+    seq = model_ref.synthesize(fsd, dsd, t(g["x0"])[:1], t(g["r"])[:1], t(g["e"])[:1], 32, meta["upsample_s"], meta["upsample_t"],
+                               faithful=False)
+    assert seq.shape == (1, 32, 3, 128, 128)
+    assert rel_l2(seq[..., ::4, ::4], g["out_s4"][:1]) < TOL
+
+
 def golden_clip(meta, g):
     """Regenerates the encoder fixture's input clip from its seed and checks it against the stored head / checksum."""
     x = 2 * torch.rand(*meta["x_shape"], generator=torch.Generator().manual_seed(meta["x_seed"])) - 1
