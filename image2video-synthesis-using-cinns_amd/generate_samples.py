@@ -54,6 +54,7 @@ def main(argv=None):
     parser.add_argument("-embed_seed", type=int, help="draw synthetic conditioning embeddings with this seed")
     parser.add_argument("-img_path", type=str, help="override ./assets/GT_samples/<dataset>/")
     parser.add_argument("-out_path", type=str, help="override ./assets/results/<dataset>/")
+    parser.add_argument("-seed", type=int, help="seed the CPU generator the latent residuals are drawn from, right before sampling")
     parser.add_argument("-raw_npy", type=str, help="also write the uint8 frame strip [T,H,N*W,3] (the GIF's palette is lossy)")
     args = parser.parse_args(argv)
     os.environ["HIP_VISIBLE_DEVICES"] = args.gpu   # the reference sets CUDA_VISIBLE_DEVICES (generate_samples.py:20)
@@ -81,6 +82,8 @@ def main(argv=None):
     else:
         embeds = None  # Model raises with a clear message unless an embedder object was attached
 
+    if args.seed is not None:
+        torch.manual_seed(args.seed)   # (Model.forward draws torch.randn on the global CPU generator, get_model.py:59)
     bs = args.bs
     length = math.ceil(imgs.size(0) / bs)
     videos = []

@@ -321,10 +321,9 @@ def test_generate_samples_cli(tmp_path, monkeypatch):
     for i in range(5):
         Image.fromarray(rng.integers(0, 255, (48, 72, 3), dtype=np.uint8)).save(img_dir / f"f{i}.png")
     out_dir = tmp_path / "out"
-    torch.manual_seed(123)  # Model draws the residuals from the global CPU generator, like get_model.py:59
     generate_samples.main(["-gpu", os.environ.get("HIP_VISIBLE_DEVICES", "0"), "-dataset", "bair", "-ckpt_path", ckpt,
                            "-bs", "2", "-embed_seed", "1", "-img_path", str(img_dir) + "/", "-out_path", str(out_dir) + "/",
-                           "-raw_npy", str(out_dir / "frames.npy")])
+                           "-raw_npy", str(out_dir / "frames.npy"), "-seed", "123"])
     gif = Image.open(out_dir / "results.gif")
     assert gif.n_frames == 16 and gif.size == (5 * 64, 64)
     # the same computation through the CPU oracle
