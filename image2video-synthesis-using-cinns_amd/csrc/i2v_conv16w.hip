@@ -40,7 +40,7 @@ constexpr int W16_BN = 64;      // output channels per workgroup
 constexpr int W16_KC = 16;      // input channels per K chunk
 constexpr int W16_SLOTS = 8;    // prefetched 16-byte V pieces per thread and chunk
 constexpr int W16_VROWS = W16_SLOTS * 512 / 4;  // staged V rows (64 B each): the halo brick, padded to 1024 rows
-constexpr int W16_WBUF = 2 * 4 * W16_BN * 64;  // bytes per weight stage buffer: 2 taps x 4 x x 64 rows x 64 B
+
 
 struct WinoArgs {
     const char* in;   // V: hl16 [B][T][Cin/16][4][H][J][16 channels = 64 B]

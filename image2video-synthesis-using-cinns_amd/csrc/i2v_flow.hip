@@ -27,6 +27,7 @@
 //   (flow_linear_kernel in i2v_linear.h serves the stand-alone MLP / Linear entry points.)
 #include "i2v_common.h"
 #include "i2v_linear.h"
+#include "i2v_flow_chain.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -232,6 +233,11 @@ struct i2v_flow {
     int S = 0;      // half-steps = 2 * n_flows
     int H = 0, E = 0, ld0 = 0, depth = 0;
     DevBuf W0, W0x, W0e, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;  // W0x: [S][8][2H][4] state part of W0
+    DevBuf an_ld;   // [n_flows] sum log|scale| (device copy for the persistent chain)
+    // persistent XCD-team chain (i2v_flow_chain.hip): used for batches <= 64 of the standard geometry unless it ever aborted
+    bool chain_ok = false;           // opt-in (env I2V_FLOW_CHAIN=1): measured at parity with the launch chain, see DESIGN.md
+    void* chain_ws = nullptr;        // workspace whose exchange / sync area has been zeroed
+    int* chain_flag_host = nullptr;  // pinned mirror of the kernel's abort flag, refreshed asynchronously after every pass
     std::vector<float> an_logdet;
     std::vector<int> step_cond;  // 1: first layer sees only the embedding (mode 'cond')
     size_t param_bytes = 0;
@@ -248,6 +254,7 @@ struct i2v_flow {
     }
 
     ~i2v_flow() {
+        if (chain_flag_host) (void)hipHostFree(chain_flag_host);
         drop_graphs();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
     }
@@ -256,8 +263,13 @@ struct i2v_flow {
 namespace {
 
 struct WsLayout {
-    size_t x, embed, logdet, preT, hA, hB, total;
+    size_t x, embed, logdet, preT, hA, hB, exch, sync, total;
 };
+
+// the persistent chain covers the geometry every shipped config uses: 64 channels, hidden 512, depth 2, <= 40 half-steps
+bool chain_eligible(const i2v_flow* f, int B) {
+    return f->chain_ok && f->H == 512 && f->depth == 2 && f->cfg.in_channels == 64 && f->S <= 64 && B >= 1 && B <= 64;
+}
 
 WsLayout ws_layout(const i2v_flow* f, int B) {
     WsLayout L;
@@ -270,6 +282,8 @@ WsLayout ws_layout(const i2v_flow* f, int B) {
     const size_t Bp = (size_t)(B + 63) / 64 * 64;  // hidden activations are [2H][Bp]
     L.hA = take((size_t)2 * f->H * Bp * 4);
     L.hB = take((size_t)2 * f->H * Bp * 4);
+    L.exch = take(flow_chain_exchange_floats() * 4);
+    L.sync = take((size_t)FLOW_CHAIN_SYNC_INTS * 4);
     L.total = o;
     return L;
 }
@@ -293,6 +307,20 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         hipLaunchKernelGGL(flow_pre_kernel, dim3((R + 255) / 256, (B + PRE_SC - 1) / PRE_SC), dim3(256), 0, st, f->W0e.as<float>(), f->b0.as<float>(), embed,
                            preT, R, f->E, Epad, B);
         I2V_HIP_CHECK(hipGetLastError());
+    }
+    if (chain_eligible(f, B)) {   // one persistent launch instead of the 120 launches below
+        FlowChainArgs c{};
+        c.x = x; c.logdet = reverse ? nullptr : logdet; c.pre = preT; c.pre_stride = (long)S * N2;
+        c.W0x = f->W0x.as<float>(); c.Wmid = f->Wmid.as<float>(); c.bmid = f->bmid.as<float>();
+        c.W3T = f->W3T.as<float>(); c.b3 = f->b3.as<float>();
+        c.an_loc = f->an_loc.as<float>(); c.an_scale = f->an_scale.as<float>(); c.an_logdet = f->an_ld.as<float>();
+        c.shuf_f = f->shuf_f.as<int>(); c.shuf_b = f->shuf_b.as<int>();
+        c.exch = reinterpret_cast<float*>(ws + L.exch); c.sync = reinterpret_cast<int*>(ws + L.sync);
+        c.cond_mask = 0;
+        for (int s2 = 0; s2 < S; ++s2) if (f->step_cond[s2]) c.cond_mask |= 1ull << s2;
+        c.B = B; c.n_flows = f->cfg.n_flows; c.reverse = reverse ? 1 : 0;
+        c.use_an = an ? 1 : 0; c.use_act = act ? 1 : 0; c.use_shuf = sh ? 1 : 0;
+        return flow_chain_launch(c, st);
     }
     // next_step: half-step whose first layer is evaluated at the end of this launch (-1: none)
     auto tail = [&](const float* h, int step, int shuf_block, int an_block, bool lrelu, bool swap, int next_step) -> int {
@@ -391,6 +419,23 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_flow: workspace %zu < required %zu",
                 workspace_bytes, L.total);
     char* ws = static_cast<char*>(workspace);
+    if (f->chain_ok && f->chain_flag_host && *static_cast<volatile int*>(f->chain_flag_host) != 0) {
+        // an earlier pass of the persistent chain gave up (a team barrier timed out, or a team was spread over several XCDs):
+        // its result was invalid.  From now on this handle uses the launch chain.
+        const int why = *f->chain_flag_host;
+        f->chain_ok = false;
+        *f->chain_flag_host = 0;
+        f->drop_graphs();
+        I2V_REQUIRE(false, I2V_E_HIP, "i2v_flow: the persistent cINN chain aborted in an earlier pass (%s); that pass's output is "
+                    "invalid -- this handle now runs the launch chain", why == 2 ? "workgroup placement: a team spans XCDs"
+                                                                                  : "team barrier timed out");
+    }
+    const bool chain = chain_eligible(f, B);
+    if (chain && f->chain_ws != workspace) {
+        // granule tags and the pass epoch of the persistent chain live in the workspace: start them from zero once
+        I2V_HIP_CHECK(hipMemsetAsync(ws + L.exch, 0, flow_chain_exchange_floats() * 4 + (size_t)FLOW_CHAIN_SYNC_INTS * 4 + 256, st));
+        f->chain_ws = workspace;
+    }
     {
         const int na = B * 64, nb = B * f->E;
         hipLaunchKernelGGL(flow_copy2_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, st, xin,
@@ -426,6 +471,13 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
                            logdet, nb);
         I2V_HIP_CHECK(hipGetLastError());
     }
+    if (chain) {
+        if (!f->chain_flag_host) {
+            I2V_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->chain_flag_host), sizeof(int), hipHostMallocDefault));
+            *f->chain_flag_host = 0;
+        }
+        I2V_HIP_CHECK(hipMemcpyAsync(f->chain_flag_host, ws + L.sync, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     return I2V_OK;
 }
 
@@ -452,6 +504,7 @@ int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out) {
     f->E = cfg->embedding_dim;
     f->ld0 = 32 + cfg->embedding_dim;
     f->depth = cfg->hidden_depth;
+    if (const char* e = std::getenv("I2V_FLOW_CHAIN")) f->chain_ok = std::atoi(e) != 0;  // 1: persistent XCD-team chain
     *out = f.release();
     return I2V_OK;
 }
@@ -557,6 +610,7 @@ int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
     if ((rc = f->an_scale.upload(scale.data(), scale.size() * 4))) return rc;
     if ((rc = f->shuf_f.upload(sf.data(), sf.size() * 4))) return rc;
     if ((rc = f->shuf_b.upload(sb.data(), sb.size() * 4))) return rc;
+    if ((rc = f->an_ld.upload(f->an_logdet.data(), f->an_logdet.size() * 4))) return rc;
     f->param_bytes = pbytes;
     f->loaded = true;
     f->drop_graphs();

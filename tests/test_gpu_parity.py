@@ -573,6 +573,38 @@ def test_flow_large_batches_vs_oracle():
     assert np.allclose(sum(flow.last_logdets).cpu(), ldr[:4], rtol=1e-4, atol=1e-4)
 
 
+def test_persistent_flow_chain_vs_golden(monkeypatch):
+    """The opt-in persistent XCD-team cINN chain (csrc/i2v_flow_chain.hip, env I2V_FLOW_CHAIN=1): same goldens, same
+    gates as the default launch chain, every batch size it accepts, forward and inverse, replayed (epoch-tagged granules)."""
+    from oracle import flow_ref
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    monkeypatch.setenv("I2V_FLOW_CHAIN", "1")
+    for name in ("flow_full_e64", "flow_full_ctrl"):
+        g, meta = load_golden(name)
+        a = meta["synth"]
+        flow = ConditionalFlow(64, a["embedding_dim"], 512, 2, 20, conditioning_option="None", control=a["control"])
+        flow.load_state_dict(T(synth.flow_state_dict(**a)))
+        flow = flow.cuda().eval()
+        x, e = cu(g["x"]), cu(g["e"])
+        zt, ld = flow(x, e)
+        assert rel_l2(zt.reshape(8, 64).cpu(), g["fwd"]) < TOL and np.allclose(ld.cpu(), g["logdet"], rtol=1e-4, atol=1e-4)
+        z = flow(x, e, reverse=True)
+        assert rel_l2(z.reshape(8, 64).cpu(), g["rev"]) < TOL
+        for _ in range(3):
+            assert torch.equal(flow(x, e, reverse=True), z)
+    sd = T(synth.flow_state_dict(seed=7, embedding_dim=64))
+    flow = ConditionalFlow(64, 64, 512, 2, 20, conditioning_option="None")
+    flow.load_state_dict(sd)
+    flow = flow.cuda().eval()
+    _, residual, embed = synth.bench_inputs(64, 64, 64)
+    ref = flow_ref.flow_reverse(sd, residual, embed).reshape(64, 64)
+    for B in (64, 1, 5, 37, 8):
+        z = flow(residual[:B].cuda().contiguous(), embed[:B].cuda().contiguous(), reverse=True).reshape(B, 64)
+        assert rel_l2(z.cpu(), ref[:B]) < TOL, B
+    z = flow(residual[:64].cuda(), embed[:64].cuda(), reverse=True)   # a later call would raise if a pass had aborted
+    assert rel_l2(z.reshape(64, 64).cpu(), ref) < TOL
+
+
 def test_hl16_range_guard():
     """A checkpoint whose SPADE (1 + gamma) drives activations past the fp16 range: the split-fp16 path must say so
     (sticky flag -> I2VError at the next call), the exact-fp32 mode must keep working."""
