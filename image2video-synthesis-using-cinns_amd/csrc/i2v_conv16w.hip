@@ -36,7 +36,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // (HIP's float4 is a struct: copies through it become memcpys that pin register arrays in scratch)
 
 constexpr int W16_TILES = 128;  // Winograd tiles per workgroup
-constexpr int W16_BN = 64;      // output channels per workgroup
 constexpr int W16_KC = 16;      // input channels per K chunk
 constexpr int W16_SLOTS = 8;    // prefetched 16-byte V pieces per thread and chunk
 constexpr int W16_VROWS = W16_SLOTS * 512 / 4;  // staged V rows (64 B each): the halo brick, padded to 1024 rows
@@ -58,14 +57,20 @@ struct WinoArgs {
     int wofs, tofs;   // LDS byte offsets of the weight buffers / the index tables
 };
 
-template <int NT>  // (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time-slice (1x3x3)
+// NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time-slice (1x3x3).
+// BN: output channels per workgroup.  64: wave = (x, 32-channel half), all 128 tiles (4 MFMA row blocks); 32 (layers with
+// 32 output channels): wave = (x, tile half), 64 tiles (2 row blocks) -- the two waves of an x load the same B operand.
+template <int NT, int BN>
 __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     constexpr int KT = NT / 3;
+    constexpr int WM = BN == 64 ? 4 : 2;  // MFMA row blocks (32 tiles each) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xi = wave & 3, nh = wave >> 2;  // Winograd position and 32-channel half of this wave
+    const int xi = wave & 3;                      // Winograd position of this wave
+    const int nh = BN == 64 ? wave >> 2 : 0;      // its 32-channel half (BN = 64)
+    const int mh = BN == 64 ? 0 : wave >> 2;      // its tile half (BN = 32)
     const int kg = lane >> 5, l31 = lane & 31;
 
     // tile order / frame-parity placement: as in i2v_conv16.hip (workgroup b runs on XCD b % 8)
@@ -84,14 +89,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     int* tpos = gpos + W16_VROWS;                        // [128] output position of a tile's first column
     int* tres = tpos + W16_TILES;                        // [128][2] residual rows of the tile's two columns
 
-    const int nNt = a.CoutPad / W16_BN;
+    const int nNt = a.CoutPad / BN;
     const int ntile = tile_id % nNt;
     int brick = tile_id / nNt;
     const int bj = brick % a.nbJ; brick /= a.nbJ;
     const int bh = brick % a.nbH; brick /= a.nbH;
     const int bt = brick % a.nbT; brick /= a.nbT;
     const int b0 = brick, t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * a.TJ;
-    const int n0 = ntile * W16_BN;
+    const int n0 = ntile * BN;
 
     if (tid < W16_TILES) {
         int m = tid;
@@ -115,18 +120,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     }
 
     // LDS row of this lane's tile (tap (0,0)) in its x plane, per MFMA row block (4 blocks of 32 tiles)
-    int arow[4];
+    int arow[WM];
 #pragma unroll
-    for (int wm = 0; wm < 4; ++wm) {
-        int m = wm * 32 + l31;
+    for (int wm = 0; wm < WM; ++wm) {
+        int m = mh * 64 + wm * 32 + l31;
         const int ij = m % a.TJ; m /= a.TJ;
         const int ih = m % a.TH; m /= a.TH;
         arow[wm] = xi * plane + (m * HH + ih) * a.TJ + ij;
     }
 
-    f32x16 acc[4];
+    f32x16 acc[WM];
 #pragma unroll
-    for (int wm = 0; wm < 4; ++wm)
+    for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[wm][r] = 0.f;
 
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u)                                                            \
         *reinterpret_cast<f32x4*>(v_lds + (VB) * (W16_VROWS * 64) + vst + u * 8192) = vin[u];
 
-    struct AOps { half8 ah[4], al[4]; };
+    struct AOps { half8 ah[WM], al[WM]; };
     struct BOps { half8 bh, bl; };
     AOps a0, a1;
     BOps bq0, bq1, bq2, bq3, bq4, bq5;  // ring of the B operands of six consecutive taps (requested five taps ahead)
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
 #define W16_LOAD_A(o, TAP, VB)                                                                                       \
     {                                                                                                                \
         const int d_ = (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * W16_VROWS;                                   \
-        _Pragma("unroll") for (int wm = 0; wm < 4; ++wm) {                                                           \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
             const int r_ = arow[wm] + d_;                                                                            \
             const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                        \
             (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                               \
@@ -188,13 +193,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
 #define W16_MFMA(o, q)                                                                                               \
     if (W16_ABLATE & 1) {                                                                                            \
         asm volatile("" :: "v"((o).ah[0]), "v"((o).al[0]), "v"((q).bh), "v"((q).bl), "v"((o).ah[1]), "v"((o).al[1]), \
-                     "v"((o).ah[2]), "v"((o).al[2]), "v"((o).ah[3]), "v"((o).al[3]));                                \
+                     "v"((o).ah[WM - 2]), "v"((o).al[WM - 2]), "v"((o).ah[WM - 1]), "v"((o).al[WM - 1]));            \
     } else {                                                                                                         \
-        _Pragma("unroll") for (int wm = 0; wm < 4; ++wm)                                                             \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
             acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
-        _Pragma("unroll") for (int wm = 0; wm < 4; ++wm)                                                             \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
             acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
-        _Pragma("unroll") for (int wm = 0; wm < 4; ++wm)                                                             \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
             acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
     }
 
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     {                                                                                                                \
         constexpr int cp_ = (U) / NT, t_ = (U) % NT;          /* chunk of the pair, tap of the chunk */             \
         constexpr int un_ = (U) + 5, cn_ = un_ / NT, tn_ = un_ % NT;                                                 \
-        asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[2]), "+v"(arow[3]));                               \
+        asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[WM - 2]), "+v"(arow[WM - 1]));                     \
         if (!(W16_ABLATE & 2)) W16_REQUEST_B(BREQ, tn_, ch + cn_)                                                    \
         if constexpr (t_ == 0 && !(W16_ABLATE & (4 | 16))) W16_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_) \
         /* the eight staged pieces go to LDS two per tap over the last taps in front of the barrier (a burst of 64   \
@@ -259,28 +264,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
 
     // ---- epilogue: the four partial GEMMs of a tile meet in LDS; y0 = M0 + M1 + M2, y1 = M1 - M2 - M3
     __syncthreads();
-    float* E = reinterpret_cast<float*>(smem);  // [4][128 tiles][64 channels]
+    float* E = reinterpret_cast<float*>(smem);  // [4][128 tiles][BN channels]
 #pragma unroll
-    for (int wm = 0; wm < 4; ++wm)
+    for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            E[(xi * W16_TILES + m) * W16_BN + nh * 32 + l31] = acc[wm][r];
+            const int m = mh * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            E[(xi * W16_TILES + m) * BN + nh * 32 + l31] = acc[wm][r];
         }
     __syncthreads();
-    const int n4 = tid & 15;
+    constexpr int NQ = BN / 4;            // float4 channel groups per tile
+    constexpr int TPI = 512 / NQ;         // tiles per pass of the workgroup
+    const int n4 = tid % NQ;
     const int n = n0 + 4 * n4;
     const bool ncol = n < a.Cout;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias && ncol) bias = *reinterpret_cast<const float4*>(a.bias + n);
     double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int tile = (tid >> 4) + 32 * it;
-        const float4 m0 = *reinterpret_cast<const float4*>(E + (0 * W16_TILES + tile) * W16_BN + 4 * n4);
-        const float4 m1 = *reinterpret_cast<const float4*>(E + (1 * W16_TILES + tile) * W16_BN + 4 * n4);
-        const float4 m2 = *reinterpret_cast<const float4*>(E + (2 * W16_TILES + tile) * W16_BN + 4 * n4);
-        const float4 m3 = *reinterpret_cast<const float4*>(E + (3 * W16_TILES + tile) * W16_BN + 4 * n4);
+    for (int it = 0; it < W16_TILES / TPI; ++it) {
+        const int tile = tid / NQ + TPI * it;
+        const float4 m0 = *reinterpret_cast<const float4*>(E + (0 * W16_TILES + tile) * BN + 4 * n4);
+        const float4 m1 = *reinterpret_cast<const float4*>(E + (1 * W16_TILES + tile) * BN + 4 * n4);
+        const float4 m2 = *reinterpret_cast<const float4*>(E + (2 * W16_TILES + tile) * BN + 4 * n4);
+        const float4 m3 = *reinterpret_cast<const float4*>(E + (3 * W16_TILES + tile) * BN + 4 * n4);
         if (!ncol) continue;
         const long p = tpos[tile];
         float y[2][4] = {{m0.x + m1.x + m2.x, m0.y + m1.y + m2.y, m0.z + m1.z + m2.z, m0.w + m1.w + m2.w},
@@ -305,34 +312,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
         }
     }
     if (a.stats) {
-        // fused normalisation statistics.  Lanes l, l^16, l^32, l^48 hold the same four channels -> wavefront shuffles;
-        // the eight waves' partials meet in LDS and ONE wave issues the workgroup's 128 fp64 atomics (2 instructions
-        // covering 8 cache lines each): all workgroups of a sample hit the same few lines of one L2 channel, and the
-        // atomic unit's cost is per (instruction, line) -- per-wave atomics (512 line requests per workgroup) cost
-        // 1.2 ms per launch at B = 8.  fp64 partials keep the totals independent of the tiling.
+        // fused normalisation statistics.  The lanes of a wave that share (lane % NQ) hold the same four channels ->
+        // wavefront shuffles; the eight waves' partials meet in LDS and ONE wave issues the workgroup's 2 * BN fp64 atomics
+        // (2 instructions): all workgroups of a sample hit the same few lines of one L2 channel, and the atomic unit's cost
+        // is per (instruction, line) -- per-wave atomics (512 line requests per workgroup) cost 1.2 ms per launch at
+        // B = 8.  fp64 partials keep the totals independent of the tiling.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ssum[j] += __shfl_xor(ssum[j], 16);
-            ssq[j] += __shfl_xor(ssq[j], 16);
-            ssum[j] += __shfl_xor(ssum[j], 32);
-            ssq[j] += __shfl_xor(ssq[j], 32);
+#pragma unroll
+            for (int off = NQ; off < 64; off <<= 1) {
+                ssum[j] += __shfl_xor(ssum[j], off);
+                ssq[j] += __shfl_xor(ssq[j], off);
+            }
         }
         __syncthreads();  // E is free
-        double* S = reinterpret_cast<double*>(smem);  // [8 waves][64 channels][2]
-        if (lane < 16) {
+        double* S = reinterpret_cast<double*>(smem);  // [8 waves][BN channels][2]
+        if (lane < NQ) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                S[(wave * W16_BN + 4 * lane + j) * 2] = ssum[j];
-                S[(wave * W16_BN + 4 * lane + j) * 2 + 1] = ssq[j];
+                S[(wave * BN + 4 * lane + j) * 2] = ssum[j];
+                S[(wave * BN + 4 * lane + j) * 2 + 1] = ssq[j];
             }
         }
         __syncthreads();
-        if (wave == 0 && n0 + lane < a.Cout) {
+        if (wave == 0 && lane < BN && n0 + lane < a.Cout) {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
-                s0 += S[(w * W16_BN + lane) * 2];
-                s1 += S[(w * W16_BN + lane) * 2 + 1];
+                s0 += S[(w * BN + lane) * 2];
+                s1 += S[(w * BN + lane) * 2 + 1];
             }
             double* dst = a.stats + ((long)b0 * a.Cout + n0 + lane) * 2;
             atomicAdd(dst, s0);
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
 // w3: [nset][Cout][Cin][KT][3][3] already multiplied by `scale`-free fp64 pre-sums; packs U = G g per (kt, kh).
 static int wino_pack_sets(Wino16Weights& o, const std::vector<double>& w3, int nset, int cout, int cin, int kt) {
     o.Cin = cin; o.Cout = cout; o.KT = kt;
-    o.CoutPad = (cout + W16_BN - 1) / W16_BN * W16_BN;
+    o.CoutPad = (cout + 31) / 32 * 32;
     o.nchunk = cin / W16_KC;
     const int NT = kt * 3;
     std::vector<double> u((size_t)nset * cout * cin * NT * 4);
@@ -381,7 +389,7 @@ static int wino_pack_sets(Wino16Weights& o, const std::vector<double>& w3, int n
 }
 
 bool wino16_supported(int cout, int cin, int T, int H, int W) {
-    if (cout % W16_BN || cin % (2 * W16_KC) || W % 8 || H < 8) return false;  // (the kernel's loop body is a chunk pair)
+    if (cout % 32 || cin % (2 * W16_KC) || W % 8 || H < 8) return false;  // (the kernel's loop body is a chunk pair)
     return (long)T * H * (W / 2) >= W16_TILES;
 }
 
@@ -416,9 +424,9 @@ int Wino16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
     return I2V_OK;
 }
 
-template <int NT>
+template <int NT, int BN>
 static int launch_wino(const WinoArgs& a, unsigned nblk, size_t lds, hipStream_t st) {
-    auto kern = conv_wino_f16x3_kernel<NT>;
+    auto kern = conv_wino_f16x3_kernel<NT, BN>;
     static bool attr_set[I2V_MAX_DEV] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(512), lds, st, a);
@@ -461,16 +469,22 @@ int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, con
     I2V_REQUIRE(nrow <= W16_VROWS, I2V_E_INVALID, "wino16: halo brick of %d rows", nrow);
     a.TT = TT; a.TH = TH; a.TJ = TJ; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = J / TJ;
     a.wofs = 0;
-    const int body = std::max(2 * W16_VROWS * 64, 4 * W16_TILES * W16_BN * 4);  // two V bricks; the epilogue's exchange buffer
+    const int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
+    const int body = std::max(2 * W16_VROWS * 64, 4 * W16_TILES * BN * 4);  // two V bricks; the epilogue's exchange buffer
     a.tofs = body;
     const size_t lds = (size_t)body + (size_t)W16_VROWS * 4 + W16_TILES * 12;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino16: LDS %zu bytes", lds);
     I2V_REQUIRE(!stats || (long)TT * TH * TJ <= (long)T * H * J, I2V_E_INVALID, "wino16: fused statistics need bricks inside one sample");
-    const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / W16_BN);
+    const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino16: grid of %ld workgroups", nblk);
-    if (KT == 3) return launch_wino<9>(a, (unsigned)nblk, lds, st);
-    if (KT == 2) return launch_wino<6>(a, (unsigned)nblk, lds, st);
-    return launch_wino<3>(a, (unsigned)nblk, lds, st);
+    if (BN == 64) {
+        if (KT == 3) return launch_wino<9, 64>(a, (unsigned)nblk, lds, st);
+        if (KT == 2) return launch_wino<6, 64>(a, (unsigned)nblk, lds, st);
+        return launch_wino<3, 64>(a, (unsigned)nblk, lds, st);
+    }
+    if (KT == 3) return launch_wino<9, 32>(a, (unsigned)nblk, lds, st);
+    if (KT == 2) return launch_wino<6, 32>(a, (unsigned)nblk, lds, st);
+    return launch_wino<3, 32>(a, (unsigned)nblk, lds, st);
 }
 
 }  // namespace i2v
