@@ -73,12 +73,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     const int mh = BN == 64 ? 0 : wave >> 2;      // its tile half (BN = 32)
     const int kg = lane >> 5, l31 = lane & 31;
 
-    // tile order / frame-parity placement: as in i2v_conv16.hip (workgroup b runs on XCD b % 8)
-    const unsigned nb_ = gridDim.x;
-    const bool pair_ = a.tdup && (nb_ & 15) == 0;
-    const int par = !a.tdup ? 0 : pair_ ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x >= (nb_ >> 1));
-    const int tile_id = !a.tdup ? (int)blockIdx.x
-                        : pair_ ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)(blockIdx.x % (nb_ >> 1));
+    // Tile order and the XCDs.  Workgroup b runs on XCD b % 8 (observed, not promised: only speed depends on it), each XCD
+    // with its own L2.  All workgroups that read the SAME V brick -- the channel tiles of a brick and, in temporal-
+    // duplication mode, its two frame parities -- are given consecutive dispatch slots of ONE XCD, and XCD x owns the
+    // bricks x, x + 8, ...: with 8 bricks per row that is one w-column, whose h- and t-neighbours share their halos in
+    // the same L2.  (Numbering the channel tile fastest put the tiles of a brick on different XCDs: every L2 fetched
+    // the whole V tensor, 2.9x its size from HBM per launch.)
+    const int nNt_ = a.CoutPad / BN;
+    const int npar_ = a.tdup ? 2 : 1;
+    const int per_brick = nNt_ * npar_;
+    const int nbrick = (int)(gridDim.x / per_brick);
+    int par, tile_id;
+    if ((nbrick & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int sub = slot % per_brick, brick_ = (slot / per_brick) * 8 + xcd;
+        par = a.tdup ? sub & 1 : 0;
+        tile_id = brick_ * nNt_ + (a.tdup ? sub >> 1 : sub);
+    } else {
+        par = a.tdup ? (int)(blockIdx.x >= (gridDim.x >> 1)) : 0;
+        tile_id = a.tdup ? (int)(blockIdx.x % (gridDim.x >> 1)) : (int)blockIdx.x;
+    }
     const int pt = a.tdup ? 1 - par : KT / 2;
     const int HT = a.TT + KT - 1, HH = a.TH + 2;
     const int plane = HT * HH * a.TJ;

@@ -5,7 +5,8 @@ Run on the GPU box:   python tools/pmc_hbm_traffic.py gpurun_out/pmc_traffic [--
 Two SEPARATE counter passes (FETCH_SIZE, then WRITE_SIZE) with --kernel-trace only, as MI355X_MICROARCH.md prescribes;
 FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read, so
 read bytes = 2 * FETCH_SIZE * 1024 (the guide's gfx950 correction); WRITE_SIZE is used as reported.
-Writes <outdir>/hbm_traffic.json; copy it to profiles/ (bench.py reads profiles/r01_l_pmc_hbm_traffic.json for `roofline.traffic`)."""
+Writes <outdir>/hbm_traffic.json; copy it to profiles/rNN_<x>_pmc_hbm_traffic.json (bench.py reads the newest such file for the
+static `roofline.traffic` / `roofline_cinn.measured_hbm_bytes_per_pass` figures and names it as their source)."""
 import collections
 import csv
 import json
@@ -17,7 +18,7 @@ import sys
 def one_pass(outdir, counter, extra, parse_only):
     d = os.path.join(outdir, counter.lower())
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-           sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + extra
+           sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"] + extra
     if not parse_only:
         env = dict(os.environ, TMPDIR="/tmp")
         with open(os.path.join(outdir, counter.lower() + ".log"), "w") as log:
@@ -32,16 +33,28 @@ def one_pass(outdir, counter, extra, parse_only):
             if "conv_mfma_f16x3_kernel" in k:
                 conv16.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                 continue
+            if "conv_wino_f16x3_kernel" in k:
+                k = "i2v::conv_wino_f16x3_kernel [3x3x3 Conv3d, Winograd]"
             per[k][0] += 1
             per[k][1] += float(r["Counter_Value"])
-    # every generator block launches the split-fp16 kernel three times, in this order: SPADE gamma/beta (3x3 Conv2d),
-    # conv_0, conv_1 (3x3x3 Conv3d) -- separate the dominant 3x3x3 launches from the small 2-D ones by dispatch order
+    # direct split-fp16 launches of one decoder pass, in dispatch order: per block SPADE conv (3 -> 128) and SPADE
+    # gamma/beta (3x3 Conv2d), then conv_0 / conv_1 for the blocks the Winograd tiling does not cover (head_0, g_0, and
+    # shapes with odd channel counts).  With 6 blocks: 12 SPADE launches; whatever exceeds 2 per block is 3x3x3.
     conv16.sort()
-    assert len(conv16) % 3 == 0, len(conv16)
-    for i, (_, v) in enumerate(conv16):
-        k = "i2v::conv_mfma_f16x3_kernel [SPADE gamma/beta 3x3 Conv2d]" if i % 3 == 0 else "i2v::conv_mfma_f16x3_kernel [3x3x3 Conv3d]"
-        per[k][0] += 1
-        per[k][1] += v
+    n3 = max(len(conv16) - 12, 0)          # 3x3x3 launches on the direct kernel (head_0, g_0: 2 each in the BAIR decoder)
+    per_block = {0: 4, 1: 4}               # blocks whose conv_0 / conv_1 run on the direct kernel -> 4 launches in that block
+    i = 0
+    blk = 0
+    while i < len(conv16):
+        n_here = 4 if (blk in per_block and n3 >= 2 * (len(per_block))) else 2
+        for j in range(n_here):
+            if i + j >= len(conv16):
+                break
+            name = "i2v::conv_mfma_f16x3_kernel [SPADE 3x3 Conv2d]" if j < 2 else "i2v::conv_mfma_f16x3_kernel [3x3x3 Conv3d, direct]"
+            per[name][0] += 1
+            per[name][1] += conv16[i + j][1]
+        i += n_here
+        blk += 1
     return per, " ".join(cmd)
 
 
@@ -57,14 +70,14 @@ def main():
         n = max(rd[k][0], wr[k][0])
         rb, wb = 2.0 * rd[k][1] * 1024.0, wr[k][1] * 1024.0
         kernels[k] = {"launches": n, "read_bytes": rb, "write_bytes": wb, "hbm_bytes_per_launch": (rb + wb) / max(n, 1)}
-    dom = {k: v for k, v in kernels.items() if "[3x3x3 Conv3d]" in k}
+    dom = {k: v for k, v in kernels.items() if "[3x3x3 Conv3d" in k}
     n = sum(v["launches"] for v in dom.values())
     tot = sum(v["read_bytes"] + v["write_bytes"] for v in dom.values())
     out = {"command": cmd + "   (second pass: --pmc WRITE_SIZE)",
            "units": "read bytes = 2 * FETCH_SIZE[KiB] * 1024 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
                     "write bytes = WRITE_SIZE[KiB] * 1024",
            "kernels": dict(sorted(kernels.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]))),
-           "dominant_kernel": {"name": "conv_mfma_f16x3_kernel, the 3x3x3 Conv3d launches (all tile variants)", "launches": n,
+           "dominant_kernel": {"name": "the 3x3x3 Conv3d launches: conv_wino_f16x3_kernel (g_1..g_4) + conv_mfma_f16x3_kernel (head_0, g_0)", "launches": n,
                                "hbm_bytes_per_launch": tot / max(n, 1)}}
     with open(os.path.join(outdir, "hbm_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
