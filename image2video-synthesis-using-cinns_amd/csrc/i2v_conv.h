@@ -74,8 +74,13 @@ struct Conv16Weights {
 // in_hl16: channels-last activations in the hl16 format (4 bytes per element, Cin % 8 == 0); out: fp32 channels-last.
 // T,H,W = OUTPUT geometry (for pack_tdup weights the input tensor has T/2 frames).
 // range_flag (optional, with EPI_HL16): device int set to 1 when a stored value does not fit the fp16 hi part
+// splitk_ws (optional): scratch of splitk_ws_floats floats; a launch too small to fill the chip (and without fused
+// statistics) then splits its K chunks over up to 8 workgroups per tile and sums the partials in a second pass
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st, double* stats = nullptr, int* range_flag = nullptr);
+                   int H, int W, int epi, hipStream_t st, double* stats = nullptr, int* range_flag = nullptr,
+                   float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
+// K-split factor conv16_forward uses when it is given scratch (a function of the layer geometry only)
+int conv16_splitk_factor(long pos_per_sample, int nchunk);
 // true when conv16_forward can accumulate per-(sample, channel) sum / sum-of-squares of its output in the epilogue
 bool conv16_can_fuse_stats(int T, int H, int W);
 

@@ -45,6 +45,9 @@ struct Conv16Args {
     float* out;       // fp32 channels-last [B][T][H][W][Cout]
     double* stats;    // optional [B][Cout][2]: per-(sample, channel) sum / sum of squares of the stored values (TB == 1)
     int* range_flag;  // optional (EPI_HL16): set when a stored value leaves the fp16 range
+    float* part;      // split-K (ksplit > 1): raw partial sums [ksplit][positions][Cout] instead of `out`
+    int ksplit;       // the K chunks are divided over `ksplit` workgroups per tile (blockIdx.y); 1 = off
+    long part_stride; // floats per split slice
     int B, T, H, W, Cin, Cout, CoutPad, nchunk;  // T,H,W: geometry of the INPUT tensor
     int tdup;            // 1: temporal-duplication mode -- the output has 2T frames, two tiles (frame parities) per brick
     long wset_stride;    // bytes between the two parity weight sets (tdup)
@@ -240,7 +243,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
             acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
     }
-    C16_REQUEST_INPUT(0)
+    // split-K (tiny feature maps: few tiles, long K): this workgroup covers the chunks [ch0, ch1)
+    const int ch0 = (int)((long)a.nchunk * blockIdx.y / a.ksplit), ch1 = (int)((long)a.nchunk * (blockIdx.y + 1) / a.ksplit);
+    C16_REQUEST_INPUT(ch0)
     const int nst = ntv / TPS;  // stages per chunk
     constexpr int PF = TPS >= 4 ? 1 : 4 / TPS;
     const int pf_stage = nst > PF ? nst - PF : 0;
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     }
     const long wtap_stride = (long)a.nchunk * slab;
 
-    for (int ch = 0; ch < a.nchunk; ++ch) {
+    for (int ch = ch0; ch < ch1; ++ch) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NSLOT; ++u) {
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
            retires in order, and behind a conditional load the compiler must assume the shortest queue */           \
         _Pragma("unroll") for (int u = 0; u < WLD; ++u) *reinterpret_cast<float4*>(wnext + wdst[u]) = WR[u];         \
         { const int rq_ = (st_) + 3 < nst ? (st_) + 3 : nst - 1; C16_REQUEST_W(WR, rq_) }                            \
-        if ((st_) == pf_stage && ch + 1 < a.nchunk) C16_REQUEST_INPUT(ch + 1)                                        \
+        if ((st_) == pf_stage && ch + 1 < ch1) C16_REQUEST_INPUT(ch + 1)                                             \
         int tnn[TPS]; /* tap offsets of stage st_ + 2 (clamped), needed one stage from now */                        \
         _Pragma("unroll") for (int t = 0; t < TPS; ++t) tnn[t] = tapo[((st_) + 2 < nst ? (st_) + 2 : nst - 1) * TPS + t]; \
         _Pragma("unroll") for (int q = 0; q < 2 * TPS; ++q) {                                                        \
@@ -338,6 +343,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     }
 
     const int HWo = a.H * a.W;
+    if (a.part) {   // split-K: raw partial sums; bias / residual / statistics are applied by the reduction pass
+        float* pp = a.part + (long)blockIdx.y * a.part_stride;
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) {
+            const int n = n0 + wave_n * (32 * WN) + 32 * wn + l31;
+            if (n >= a.Cout) continue;
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = rowpos[wave_m * (32 * WM) + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kg];
+                    if (p >= 0) pp[(long)p * a.Cout + n] = acc[wm][wn][r] * a.oscale;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         const int n = n0 + wave_n * (32 * WN) + 32 * wn + l31;
@@ -474,9 +495,49 @@ static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t 
     auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS>;
     static bool attr_set[I2V_MAX_DEV] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(64 * WAVES_M * WAVES_N), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk, a.ksplit), dim3(64 * WAVES_M * WAVES_N), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
+}
+
+// out[p][c] = act(bias[c] + sum_s part[s][p][c] (+ res[rowres(p)][c])) -- the reduction pass of a split-K launch.
+// Fixed summation order (s = 0, 1, ...): deterministic, and independent of the batch (shards stay bit-identical).
+__global__ void conv16_splitk_reduce_kernel(const float* __restrict__ part, long part_stride, int ksplit,
+                                            const float* __restrict__ bias, const float* __restrict__ res, float* __restrict__ out,
+                                            long npos, int Cout, int T, int H, int W, int rt, int rs, int lrelu) {
+    const int C4 = Cout >> 2;
+    const long total = npos * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / C4;
+        const int c = (int)(i - p * C4) * 4;
+        float4 s = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ksplit; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (long)k * part_stride + p * Cout + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (res) {
+            long q = p;
+            const int w = (int)(q % W); q /= W;
+            const int h = (int)(q % H); q /= H;
+            const int t = (int)(q % T); q /= T;
+            const long rp = ((q * (T / rt) + t / rt) * (H / rs) + h / rs) * (W / rs) + w / rs;
+            const float4 r = *reinterpret_cast<const float4*>(res + rp * Cout + c);
+            s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+        }
+        if (lrelu) {
+            s.x = s.x >= 0.f ? s.x : 0.2f * s.x; s.y = s.y >= 0.f ? s.y : 0.2f * s.y;
+            s.z = s.z >= 0.f ? s.z : 0.2f * s.z; s.w = s.w >= 0.f ? s.w : 0.2f * s.w;
+        }
+        *reinterpret_cast<float4*>(out + p * Cout + c) = s;
+    }
+}
+
+// The split factor depends on the LAYER geometry only (positions per sample, K chunks), never on the batch: the summation
+// order of a sample's outputs must not change when the batch is sharded (shards are bit-identical to the full batch).
+int conv16_splitk_factor(long pos_per_sample, int nchunk) {
+    int s = pos_per_sample <= 16 ? 8 : pos_per_sample <= 128 ? 4 : 1;
+    while (s > 1 && nchunk / s < 2) s /= 2;
+    return s;
 }
 
 bool conv16_can_fuse_stats(int T, int H, int W) {
@@ -485,7 +546,7 @@ bool conv16_can_fuse_stats(int T, int H, int W) {
 }
 
 int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, const float* res, int rt, int rs, int B, int T,
-                   int H, int W, int epi, hipStream_t st, double* stats, int* range_flag) {
+                   int H, int W, int epi, hipStream_t st, double* stats, int* range_flag, float* splitk_ws, size_t splitk_ws_floats) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv16: weights not packed");
     I2V_REQUIRE(wts.Cin % 8 == 0, I2V_E_INVALID, "conv16: Cin %d must be a multiple of 8", wts.Cin);
     Conv16Args a{};
@@ -507,6 +568,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
     a.stats = stats;
     a.range_flag = range_flag;
+    a.ksplit = 1;
     a.oscale = (float)std::ldexp(1.0, -wts.wexp);
     int TW = W < 8 ? W : 8, TH = H < 8 ? H : 8;
     int rem = C16_BM / (TW * TH);
@@ -549,10 +611,33 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "conv16: grid of %ld workgroups", nblk);
+    // split-K: a launch that cannot fill the chip even with the narrowest channel tile (head_0 / g_0 at small batches: a
+    // handful of bricks, K = 9 x 1024) divides its K chunks over several workgroups per tile; the partial sums go to the
+    // caller's scratch and a reduction pass (fixed order) applies bias / residual / activation.
+    const long npos_out = (long)B * (a.tdup ? 2 * T : T) * H * W;
+    int ksplit = 1;
+    if (splitk_ws && !stats && !(epi & (EPI_FRAMES | EPI_HL16)) && a.Cout % 4 == 0) {
+        ksplit = conv16_splitk_factor((long)(a.tdup ? 2 * T : T) * H * W, a.nchunk);
+        I2V_REQUIRE((size_t)ksplit * npos_out * a.Cout <= splitk_ws_floats || ksplit == 1, I2V_E_WORKSPACE,
+                    "conv16: split-K scratch of %zu floats is too small for %d x %ld x %d", splitk_ws_floats, ksplit, npos_out, a.Cout);
+    }
+    if (ksplit > 1) {
+        a.ksplit = ksplit;
+        a.part = splitk_ws;
+        a.part_stride = npos_out * a.Cout;
+    }
     // (a 16-wave variant <8,2,1,2,1> -- 4 waves per SIMD, wave tile 32x64, 128 VGPRs -- was measured 5 % slower)
-    if (BN == 128) return launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
-    if (BN == 64) return launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
-    return launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);
+    int rc;
+    if (BN == 128) rc = launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
+    else if (BN == 64) rc = launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
+    else rc = launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);
+    if (rc || ksplit == 1) return rc;
+    const long total4 = npos_out * (a.Cout / 4);
+    hipLaunchKernelGGL(conv16_splitk_reduce_kernel, dim3((unsigned)std::min<long>((total4 + 255) / 256, 4096)), dim3(256), 0, st,
+                       splitk_ws, a.part_stride, ksplit, a.bias, res, out, npos_out, a.Cout, a.tdup ? 2 * T : T, H, W, a.rt, a.rs,
+                       (epi & EPI_LRELU) ? 1 : 0);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
 }
 
 }  // namespace i2v

@@ -392,7 +392,7 @@ struct i2v_dec {
 namespace {
 
 struct DecWs {
-    size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, total;
+    size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, splitk, splitk_floats, total;
 };
 
 bool want_wino0(const i2v_dec* d, const Block& b, const Level& l);
@@ -425,6 +425,16 @@ DecWs dec_ws(const i2v_dec* d, int B) {
     L.zl = take((size_t)B * d->Nz);
     L.sums1 = take((size_t)B * cmax * 4); L.sums2 = take((size_t)B * cmax * 4);  // doubles: 2 per channel
     L.coef = take((size_t)B * cmax * 2);
+    {   // split-K scratch of the direct conv kernel (the tiny feature maps of head_0 / g_0): its partial copies of the output
+        size_t mx = 0;
+        for (int k = 0; k < 6; ++k) {
+            const long P = (long)d->lvl[k].T * d->lvl[k].H * d->lvl[k].W;
+            const int f = std::max(conv16_splitk_factor(P, (d->blk[k].n_in + 31) / 32), conv16_splitk_factor(P, (d->blk[k].n_mid + 31) / 32));
+            if (f > 1) mx = std::max(mx, (size_t)f * P * std::max(d->blk[k].n_mid, d->blk[k].n_out));
+        }
+        L.splitk_floats = (size_t)B * mx;
+        L.splitk = take(L.splitk_floats);
+    }
     L.total = o;
     return L;
 }
@@ -508,13 +518,13 @@ int conv3(i2v_dec* d, const ConvWeights& w, const float* in, float* out, const f
 }
 
 int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* out, const float* res, int rt, int rs, int B,
-             const Level& l, int epi, hipStream_t st, double* stats = nullptr) {
+             const Level& l, int epi, hipStream_t st, double* stats = nullptr, float* splitk = nullptr, size_t splitk_floats = 0) {
     if (stats) I2V_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * w.Cout * 16, st));
     // algorithmic FLOPs of the reference's 3x3x3 conv; matrix-core FLOPs actually issued = 3 fp16 MFMAs per product, on
     // 18 instead of 27 taps in temporal-duplication mode
     const double fl = 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0;
     ProfScope ps(d, st, fl, 3.0 * fl * (w.tdup ? 18.0 / 27.0 : 1.0));
-    return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats);
+    return conv16_forward(w, in_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats, nullptr, splitk, splitk_floats);
 }
 
 int conv3_w(i2v_dec* d, const Wino16Weights& w, const float* v_hl16, float* out, const float* res, int rt, int rs, int B,
@@ -560,6 +570,8 @@ namespace {
 struct BlockBufs {
     float *a, *dx, *xs_in, *xs_low, *y0, *y1, *gb, *coef;
     double *sums1, *sums2;
+    float* splitk = nullptr;      // split-K scratch of conv16_forward (optional)
+    size_t splitk_floats = 0;
 };
 
 // One GeneratorBlock (decoder.py:33-52) on channels-last tensors: x [B][T/ut][H/us][W/us][n_in] -> xn [B][T][H][W][n_out].
@@ -609,7 +621,7 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     d->prof_cur_layer = 2 * k;
     d->prof_cur_kernel = w0 ? 2 : (f16 ? 1 : 0);
     if (w0) rc = conv3_w(d, b.conv0_w, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
-    else if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
+    else if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr, w.splitk, w.splitk_floats);
     else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
     if (rc) return rc;
     if ((rc = tap(k, 2, dx, (size_t)B * P * b.n_mid))) return rc;
@@ -638,7 +650,8 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     d->prof_cur_layer = 2 * k + 1;
     d->prof_cur_kernel = w1 ? 2 : (f16 ? 1 : 0);
     if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
-    else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
+    else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr,
+                                w.splitk, w.splitk_floats);
     else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
     if (rc) return rc;
     x_stats_ready = fuse_out;
@@ -973,7 +986,7 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     float* x = xA;
     float* xn = xB;
     bool x_stats_ready = false;
-    BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, sums1, sums2};
+    BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, sums1, sums2, F(L.splitk), L.splitk_floats};
     for (int k = 0; k < 6; ++k) {
         if ((rc = block_forward(d, k, d->blk[k], d->lvl[k], x, xn, img, img_h, img_w, zl, d->Nz, B, bufs, x_stats_ready, k == 5, st)))
             return rc;

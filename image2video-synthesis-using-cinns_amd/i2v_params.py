@@ -99,8 +99,12 @@ class NativeBacked(nn.Module):
         own handle (e.g. ``gen.g_0.load_state_dict(...)`` must invalidate ``gen``'s decoder handle too)."""
         m = self
         while m is not None:
-            object.__setattr__(m, "_native", None)
+            m._drop_native()
             m = m.__dict__.get("_native_parent")
+
+    def _drop_native(self):
+        """Forget this module's own handle (subclasses add what else depends on the parameters)."""
+        object.__setattr__(self, "_native", None)
 
     def module_device(self):
         """Device the parameters live on (the device the native handle is created on)."""

@@ -59,10 +59,10 @@ class ConditionalFlow(NativeBacked):
         h = x
         for blk in self.sub_layers:
             h, _ = blk(h[:, :, None, None], embedding[:, :, None, None])
-        super().refresh_native()
+        object.__setattr__(self, "_native", None)   # loc / scale of the blocks changed: rebuild the handle
 
-    def refresh_native(self):
-        super().refresh_native()
+    def _drop_native(self):
+        super()._drop_native()
         object.__setattr__(self, "_init_checked", False)  # parameters may have changed: look at `initialized` again
 
     def _forward_recorded(self, x2, e2):

@@ -80,6 +80,29 @@ def test_no_cpu_fallback():
         ConditionalFlow(64, 64, 512, 2, 2, conditioning_option="parallel")
 
 
+def test_child_load_invalidates_ancestor_handles():
+    """A native handle packs the parameters of the whole sub-tree: loading a state_dict into a CHILD must drop the handles
+    of every NativeBacked ancestor too (the next call rebuilds them), and so must moving the module."""
+    from stage1_VAE.modules.decoder import Generator
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    gen = Generator({"channel_factor": 8, "z_dim": 64, "upsample_s": [2, 1], "upsample_t": [2, 1], "spectral_norm": True})
+    marker = object()
+    for m in (gen, gen.g_0, gen.g_0.norm_0):
+        object.__setattr__(m, "_native", marker)
+    gen.g_0.norm_0.load_state_dict(gen.g_0.norm_0.state_dict())
+    assert gen._native is None and gen.g_0._native is None and gen.g_0.norm_0._native is None
+    object.__setattr__(gen, "_native", marker)
+    object.__setattr__(gen.g_1, "_native", marker)
+    gen.g_1.load_state_dict(gen.g_1.state_dict())
+    assert gen._native is None and gen.g_1._native is None
+    flow = ConditionalFlow(64, 64, 512, 2, 2, conditioning_option="None")
+    object.__setattr__(flow, "_native", marker)
+    object.__setattr__(flow, "_init_checked", True)
+    flow.sub_layers[1].coupling.s[0].load_state_dict(flow.sub_layers[1].coupling.s[0].state_dict())
+    assert flow._native is None and flow._init_checked is False   # Q1: `initialized` is looked at again on the next forward
+    assert flow.module_device().type == "cpu"
+
+
 def test_shard_bounds():
     import i2v_dist
     for total in (1, 7, 8, 64, 65):
