@@ -177,22 +177,58 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
 // The same modulation, written as the Winograd-transformed operand V = B^T d of i2v_conv16w.hip:
 //   V[b][t][c/16][x][h][j][c%16]  (hl16: per 8 channels 8 x fp16 hi | 8 x fp16 lo),  j = output pair (w = 2j, 2j+1),
 //   V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3,  d_k = act(...)[t][h][2j-1+k]  (0 outside the row).
-// One thread = one (h, j, 8-channel group), looping over the frames like modulate_kernel; every activation is evaluated by
-// the two pairs that use it (the kernel is bound by its 2x larger output, not by the FMAs).  Thread order: channel group
-// within a 32-channel (128-byte) input line fastest, then j -- a wave reads whole input lines and writes 1 KB runs of V.
+// One thread = one (h, j, 8-channel group), looping over the frames like modulate_kernel.  It evaluates only its OWN two
+// positions (d1, d2); d0 and d3 are the neighbouring pairs' d2 / d1 and arrive by lane shuffle: thread order = channel
+// group within a 32-channel (128-byte) input line fastest, then j, so lane l +- 4 holds pair j +- 1 of the same channels.
+// Only the first / last pair of a 16-pair wave segment evaluates its outer neighbour itself.  (Evaluating all four
+// positions per thread read every input twice: 9.1 GB instead of 5.5 GB per BAIR step.)
+struct ModPos {   // affine of one position: act(x * a + b), and its source row
+    float a[8], b[8];
+    const float* xp;
+};
+
+__device__ __forceinline__ void mod_pos_init(ModPos& m, const float* ca, const float* cb, const float* xb, const float* gbb, int h, int w,
+                                             int W, int C, int c8, int us, int Wl) {
+    m.xp = xb + ((long)(h / us) * Wl + w / us) * C + 8 * c8;
+    if (gbb) {  // fold SPADE's gamma' / beta of the position into the affine: (x ca + cb) ga + be
+        const float* g = gbb + ((long)h * W + w) * (2 * C) + 8 * c8;
+        const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(g + C), e1 = *reinterpret_cast<const float4*>(g + C + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { m.b[c] = fmaf(cb[c], ga[c], be[c]); m.a[c] = ca[c] * ga[c]; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { m.a[c] = ca[c]; m.b[c] = cb[c]; }
+    }
+}
+
+__device__ __forceinline__ void mod_pos_eval(const ModPos& m, long toff, int lrelu, float* d) {
+    const float* p = m.xp + toff;
+    const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+    const float r0[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float r = fmaf(r0[c], m.a[c], m.b[c]);
+        d[c] = (lrelu && r < 0.f) ? 0.2f * r : r;
+    }
+}
+
 __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
                                                             const float* __restrict__ gb, char* __restrict__ out, int T, int H,
                                                             int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag) {
     bool bad = false;
     const int C8 = C >> 3, J = W >> 1;
     const int b = blockIdx.y;
-    const int per = H * J * C8;  // threads per sample
+    const int per = H * J * C8;  // threads per sample (a multiple of 64: whole waves stay active for the shuffles)
     const int Hl = H / us, Wl = W / us, Tl = T / ut;
     const float2* cp0 = coef + (long)b * C;
     const float* xb = x + (long)b * Tl * Hl * Wl * C;
     const float* gbb = gb ? gb + (long)b * H * W * 2 * C : nullptr;
     const int nchunk = C >> 4;
     const long xstride = (long)Hl * Wl * C;
+    const int lane = threadIdx.x & 63, jj = lane >> 2;   // jj: position of the pair inside the wave's 16-pair segment
     for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
         // i = ((h * (C8/4) + c32) * J + j) * 4 + c8lo   (C8 % 4 == 0: channels are a multiple of 32)
         const int c8lo = i & 3;
@@ -210,46 +246,32 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
                 ca[2 * k] = ab.x; cb[2 * k] = ab.y; ca[2 * k + 1] = ab.z; cb[2 * k + 1] = ab.w;
             }
         }
-        // per-position affine (SPADE's gamma / beta depend on (h, w)); positions outside the row contribute d = 0
-        float pa[4][8], pb[4][8];
-        const float* xp[4];
-        bool ok[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int w = 2 * j - 1 + k;
-            ok[k] = w >= 0 && w < W;
-            const int wc = ok[k] ? w : 0;
-            xp[k] = xb + ((long)(h / us) * Wl + wc / us) * C + 8 * c8;
-            if (gbb) {
-                const float* g = gbb + ((long)h * W + wc) * (2 * C) + 8 * c8;
-                const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
-                const float4 e0 = *reinterpret_cast<const float4*>(g + C), e1 = *reinterpret_cast<const float4*>(g + C + 4);
-                const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { pb[k][c] = fmaf(cb[c], ga[c], be[c]); pa[k][c] = ca[c] * ga[c]; }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { pa[k][c] = ca[c]; pb[k][c] = cb[c]; }
-            }
-        }
-        float d[4][8];
+        // own positions w = 2j, 2j + 1; the outer neighbours 2j - 1 / 2j + 2 come from lane -+ 4 unless this pair opens /
+        // closes the wave's segment (then they are evaluated here) or the row (then they are 0: the conv's zero padding)
+        ModPos m1, m2, me;
+        mod_pos_init(m1, ca, cb, xb, gbb, h, 2 * j, W, C, c8, us, Wl);
+        mod_pos_init(m2, ca, cb, xb, gbb, h, 2 * j + 1, W, C, c8, us, Wl);
+        const bool left_row = j == 0, right_row = j == J - 1;
+        const bool left_own = !left_row && jj == 0, right_own = !right_row && jj == 15;
+        if (left_own || right_own)   // (an edge pair is never both: J >= 4 keeps jj == 0 and jj == 15 apart unless J >= 16)
+            mod_pos_init(me, ca, cb, xb, gbb, h, left_own ? 2 * j - 1 : 2 * j + 2, W, C, c8, us, Wl);
+        const bool both_own = left_own && right_own;   // impossible (jj is 0 or 15), kept for clarity
+        (void)both_own;
+        float d0[8], d1[8], d2[8], d3[8], de[8];
         // V row of (t, chunk, x, h, j): 64 bytes; this thread owns the 32-byte half (c8 & 1)
         char* ob = out + ((((long)b * T * nchunk + (c8 >> 1)) * 4 * H + h) * J + j) * 64 + (c8 & 1) * 32;
         const long ostride_x = (long)H * J * 64, ostride_t = (long)nchunk * 4 * ostride_x;
         for (int t = 0; t < T; ++t) {
             if (t % ut == 0) {
+                const long toff = (long)(t / ut) * xstride;
+                mod_pos_eval(m1, toff, lrelu, d1);
+                mod_pos_eval(m2, toff, lrelu, d2);
+                if (left_own || right_own) mod_pos_eval(me, toff, lrelu, de);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float* p = xp[k] + (long)(t / ut) * xstride;
-                    const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
-                    const float r0[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        float r = fmaf(r0[c], pa[k][c], pb[k][c]);
-                        if (lrelu) r = r >= 0.f ? r : 0.2f * r;
-                        d[k][c] = ok[k] ? r : 0.f;
-                    }
+                for (int c = 0; c < 8; ++c) {
+                    const float up = __shfl_up(d2[c], 4), dn = __shfl_down(d1[c], 4);
+                    d0[c] = left_row ? 0.f : (left_own ? de[c] : up);
+                    d3[c] = right_row ? 0.f : (right_own ? de[c] : dn);
                 }
             }
             char* o = ob + (long)t * ostride_t;
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
                 half8_t hi, lo;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float v = xq == 0 ? d[0][c] - d[2][c] : xq == 1 ? d[1][c] + d[2][c] : xq == 2 ? d[2][c] - d[1][c] : d[1][c] - d[3][c];
+                    const float v = xq == 0 ? d0[c] - d2[c] : xq == 1 ? d1[c] + d2[c] : xq == 2 ? d2[c] - d1[c] : d1[c] - d3[c];
                     const _Float16 hh = (_Float16)v;
                     bad |= !(fabsf(v) <= 65504.f);
                     hi[c] = hh;
@@ -481,6 +503,7 @@ int run_modulate_wino(const float* x, const float* coef, const float* gb, float*
                       int us, int lrelu, hipStream_t st, int* range_flag) {
     I2V_REQUIRE(C % 32 == 0 && W % 2 == 0, I2V_E_INVALID, "modulate (Winograd operand): channels %d / width %d", C, W);
     const long per = (long)H * (W / 2) * (C / 8);
+    I2V_REQUIRE(per % 64 == 0, I2V_E_INVALID, "modulate (Winograd operand): %ld threads per sample (need whole wavefronts)", per);
     I2V_REQUIRE(per * T * 4 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
     hipLaunchKernelGGL(modulate_wino_kernel, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
