@@ -106,6 +106,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
     } while (0)
 
 constexpr int I2V_MAX_DEV = 64;
+// 4 KiB of zeros on the current device (allocated once per device, never freed): conv kernels point the loads of padding
+// rows at it instead of selecting zeros AFTER the load -- a select right behind a prefetch load makes the wave wait for it.
+int zero_page(const char** out);
 inline int ensure_dynamic_lds(const void* kernel, int bytes, bool* done) {
     int dev = 0;
     I2V_HIP_CHECK(hipGetDevice(&dev));

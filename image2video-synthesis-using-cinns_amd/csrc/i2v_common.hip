@@ -12,6 +12,21 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int zero_page(const char** out) {
+    static char* pages[I2V_MAX_DEV] = {};
+    int dev = 0;
+    I2V_HIP_CHECK(hipGetDevice(&dev));
+    I2V_REQUIRE(dev >= 0 && dev < I2V_MAX_DEV, I2V_E_HIP, "zero_page: device index %d", dev);
+    if (!pages[dev]) {
+        void* p = nullptr;
+        I2V_HIP_CHECK(hipMalloc(&p, 4096));
+        I2V_HIP_CHECK(hipMemset(p, 0, 4096));
+        pages[dev] = static_cast<char*>(p);
+    }
+    *out = pages[dev];
+    return I2V_OK;
+}
+
 }  // namespace i2v
 
 extern "C" {

@@ -37,8 +37,11 @@ constexpr int C16_ROW = 144;  // bytes per staged row: 32 channels x 4 B + 16 B 
 constexpr int C16_SLOTS = 12; // prefetched 16-byte input pieces per thread and chunk (768 halo rows); larger bricks
                               // stage the remainder synchronously
 
+typedef float c16_f32x4 __attribute__((ext_vector_type(4)));
+
 struct Conv16Args {
     const char* in;   // hl16 channels-last [B][T][H][W][Cin]
+    const char* zeros;  // >= 16 zero bytes: source of padding pieces (no select behind the prefetch loads)
     const char* wp;   // hl16 weights [tap][chunk][CoutPad][128 B]
     const float* bias;
     const float* res;
@@ -213,9 +216,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
             const int idx = tid + u * NTHR;                                                                          \
             const int q = idx & 7;                                                                                   \
             const bool ok = idx < NPOS * 8 && gp_[u] >= 0 && (ch_) * 4 + (q >> 1) < ngrp;                            \
-            const long off = ok ? (long)gp_[u] * in_row + (long)(ch_) * 128 + q * 16 : 0;                            \
-            const float4 v = *reinterpret_cast<const float4*>(a.in + off);                                           \
-            vin[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+            const c16_f32x4 t_ = *reinterpret_cast<const c16_f32x4*>(                                                  \
+                ok ? a.in + (long)gp_[u] * in_row + (long)(ch_) * 128 + q * 16 : a.zeros);                          \
+            vin[u] = make_float4(t_[0], t_[1], t_[2], t_[3]);                                                        \
         }                                                                                                            \
     }
     struct Ops { half8 ah[WM], al[WM], bh[WN], bl[WN]; };
@@ -368,6 +371,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         // of the batch (which may pick a narrower tile) would not reproduce the full batch bit for bit
         double ssum = 0.0, ssq = 0.0;
         bool bad = false;
+        // residual values first, all of them in flight together: inside the store loop each load would wait for the
+        // previous store (`res` may alias `out` as far as the compiler knows; vmcnt counts stores too)
+        float rv[WM][16];
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wave_m * (32 * WM) + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                rv[wm][r] = (a.res && ncol && rowpos[m] >= 0) ? a.res[(long)rowres[m] * a.Cout + n] : 0.f;
+            }
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) {
 #pragma unroll
@@ -375,8 +388,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                 const int m = wave_m * (32 * WM) + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 const int p = rowpos[m];
                 if (p < 0 || !ncol) continue;
-                float v = fmaf(acc[wm][wn][r], a.oscale, bias);
-                if (a.res) v += a.res[(long)rowres[m] * a.Cout + n];
+                float v = fmaf(acc[wm][wn][r], a.oscale, bias) + rv[wm][r];
                 ssum += (double)v;
                 ssq = fma((double)v, (double)v, ssq);
                 if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
@@ -550,6 +562,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv16: weights not packed");
     I2V_REQUIRE(wts.Cin % 8 == 0, I2V_E_INVALID, "conv16: Cin %d must be a multiple of 8", wts.Cin);
     Conv16Args a{};
+    if (int rc0 = zero_page(&a.zeros)) return rc0;
     a.in = static_cast<const char*>(in_hl16); a.wp = wts.w.as<char>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
     a.B = B; a.T = T; a.H = H; a.W = W; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
     a.KT = wts.KT; a.KH = wts.KH; a.KW = wts.KW; a.tap_base = 0;

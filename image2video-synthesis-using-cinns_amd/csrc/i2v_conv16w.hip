@@ -43,6 +43,7 @@ constexpr int W16_VROWS = W16_SLOTS * 512 / 4;  // staged V rows (64 B each): th
 
 struct WinoArgs {
     const char* in;   // V: hl16 [B][T][Cin/16][4][H][J][16 channels = 64 B]
+    const char* zeros;  // >= 64 zero bytes: source of the padding rows (no select behind the prefetch loads)
     const char* wp;   // U: [parity][tap][chunk][4][CoutPad][64 B]
     const float* bias;
     const float* res;
@@ -56,6 +57,17 @@ struct WinoArgs {
     float oscale;
     int wofs, tofs;   // LDS byte offsets of the weight buffers / the index tables
 };
+
+// number of taps U - k, k = 0 .. R - 1, that are tap `h` of their chunk (t = U % NT)
+constexpr int w16_count(int t, int R, int NT, int h) {
+    int n = 0;
+    for (int k = 0; k < R; ++k) n += ((t - k - h) % NT + NT) % NT == 0;
+    return n;
+}
+
+#ifndef W16_RING9
+#define W16_RING9 1   // measurement builds: 0 = six-slot B ring for the 9-tap kernel too
+#endif
 
 // NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time-slice (1x3x3).
 // BN: output channels per workgroup.  64: wave = (x, 32-channel half), all 128 tiles (4 MFMA row blocks); 32 (layers with
@@ -155,32 +167,42 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     const long wtap_stride = (long)a.nchunk * cstride;
     const char* wlane = a.wp + (long)par * a.wset_stride + ((long)xi * (a.CoutPad >> 5) + (n0 >> 5) + nh) * 2048 + lane * 16;
 
-    // V staging: piece idx = tid + 512 u (u < 8) -> LDS row (tid >> 2) + 128 u, 16-byte piece tid & 3; the swizzle term
-    // ((row >> 2) & 3) == ((tid >> 4) & 3) does not depend on u, so one base register + immediates address every piece
-    const int vst = ((tid >> 2) << 6) + (((tid & 3) ^ ((tid >> 4) & 3)) << 4);
+    // V staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  Piece idx = tid + 512 u
+    // (u < 8) -> LDS row (tid >> 2) + 128 u; a wave's instruction fills 1 KB = 16 rows, lane i at base + 16 i, so the LDS
+    // image is lane-linear and the XOR swizzle is applied on the SOURCE side: physical piece (tid & 3) of a row holds its
+    // logical piece (tid & 3) ^ ((row >> 2) & 3), and ((row >> 2) & 3) == ((tid >> 4) & 3) does not depend on u.
+    // Padding rows read the zero page.  hipcc does not count asm memory operations, so EVERY wait of the tap loop is
+    // written by hand (W16_WAIT_B, the wait in front of the chunk barrier).
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
     const int* gq = gpos + (tid >> 2);
-    const long vpiece = (long)(tid & 3) * 16;
+    const long vpiece = (long)((tid & 3) ^ ((tid >> 4) & 3)) * 16;
     const long vchunk = (long)4 * a.H * a.J * 64;  // bytes between the K chunks of one frame
-    f32x4 vin[W16_SLOTS];
-#define W16_REQUEST_V(ch_)                                                                                           \
+#define W16_GLDS(src_, dst_)                                                                                         \
     {                                                                                                                \
-        int gp_[W16_SLOTS];                                                                                          \
-        _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u) gp_[u] = gq[128 * u];                                  \
+        unsigned keep_;                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                              \
+    }
+    // half HF (0 / 1) of a brick: pieces u = 4 HF .. 4 HF + 3 (two batches of four keep the address registers few)
+#define W16_REQUEST_V(ch_, VB, HF)                                                                                   \
+    {                                                                                                                \
+        int gp_[4];                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) gp_[u] = gq[128 * (4 * (HF) + u)];                             \
         const char* vb_ = a.in + (long)(ch_) * vchunk + vpiece;                                                      \
-        _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u) {                                                      \
-            const bool ok = gp_[u] >= 0;                                                                             \
-            const f32x4 v = *reinterpret_cast<const f32x4*>(vb_ + (ok ? (long)gp_[u] * 64 : 0));                     \
-            vin[u] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                              \
+            const char* s_ = gp_[u] >= 0 ? vb_ + (long)((W16_ABLATE & 16) ? gp_[u] & 0xfff : gp_[u]) * 64 : a.zeros; \
+            W16_GLDS(s_, vdst + (unsigned)((VB) * (W16_VROWS * 64) + (4 * (HF) + u) * 8192))                         \
         }                                                                                                            \
     }
-#define W16_WRITE_V(VB)                                                                                              \
-    _Pragma("unroll") for (int u = 0; u < W16_SLOTS; ++u)                                                            \
-        *reinterpret_cast<f32x4*>(v_lds + (VB) * (W16_VROWS * 64) + vst + u * 8192) = vin[u];
 
     struct AOps { half8 ah[WM], al[WM]; };
     struct BOps { half8 bh, bl; };
     AOps a0, a1;
-    BOps bq0, bq1, bq2, bq3, bq4, bq5;  // ring of the B operands of six consecutive taps (requested five taps ahead)
+    // ring of the B operands of R consecutive taps (requested R - 1 taps ahead).  R = 9 for the 9-tap kernel: no B request
+    // younger than a chunk's V request is consumed before the chunk's barrier, so the V brick has the whole chunk to land.
+    constexpr int R = (NT == 9 && W16_RING9) ? 9 : 6;
+    BOps bq0, bq1, bq2, bq3, bq4, bq5, bq6, bq7, bq8;
     // A operands of tap TAP (compile-time) from V brick VB
 #define W16_LOAD_A(o, TAP, VB)                                                                                       \
     {                                                                                                                \
@@ -197,11 +219,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     {                                                                                                                \
         const int c_ = (CH) < a.nchunk ? (CH) : a.nchunk - 1;                                                        \
         const char* p_ = wlane + (long)(TAP) * wtap_stride + (long)c_ * cstride;                                     \
-        (q).bh = *reinterpret_cast<const half8*>(p_);                                                                \
-        (q).bl = *reinterpret_cast<const half8*>(p_ + 1024);                                                         \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"((q).bh) : "v"(p_));                                   \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=&v"((q).bl) : "v"(p_));                       \
     }
+    // B operands of the current tap have landed when at most N younger loads are outstanding (loads return in order)
+#define W16_WAIT_B(q, N) asm volatile("s_waitcnt vmcnt(%2)" : "+v"((q).bh), "+v"((q).bl) : "n"(N));
+#define W16_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #ifndef W16_ABLATE
-#define W16_ABLATE 0   // measurement builds only (tools/conv16w_check): 1 no MFMAs, 2 no weight traffic, 4 no V staging (16: no V requests, 32: no V LDS writes), 8 no barriers
+#define W16_ABLATE 0   // measurement builds only (tools/conv16w_check): 1 no MFMAs, 2 no weight traffic, 4 no V staging, 8 no barriers, 16 V rows wrapped into a 256 KB window per chunk (L2 hits)
 #endif
 #define W16_SYNC() { if (!(W16_ABLATE & 8)) __syncthreads(); }
 #define W16_MFMA(o, q)                                                                                               \
@@ -218,45 +243,51 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     }
 
     __syncthreads();  // tables
-    W16_REQUEST_V(0)
+    W16_REQUEST_V(0, 0, 0)
+    W16_REQUEST_V(0, 0, 1)
     W16_REQUEST_B(bq0, 0 % NT, 0 / NT)
     W16_REQUEST_B(bq1, 1 % NT, 1 / NT)
     W16_REQUEST_B(bq2, 2 % NT, 2 / NT)
     W16_REQUEST_B(bq3, 3 % NT, 3 / NT)
     W16_REQUEST_B(bq4, 4 % NT, 4 / NT)
-    W16_WRITE_V(0)
+    if constexpr (R == 9) {
+        W16_REQUEST_B(bq5, 5 % NT, 5 / NT)
+        W16_REQUEST_B(bq6, 6 % NT, 6 / NT)
+        W16_REQUEST_B(bq7, 7 % NT, 7 / NT)
+    }
+    W16_WAIT_VM(2 * (R - 1))   // the V brick of chunk 0 (the B loads behind it stay in flight)
     __syncthreads();
     W16_LOAD_A(a0, 0, 0)
 
     // The loop body is a PAIR of chunks = 2 NT taps, numbered U = 0 .. 2 NT - 1 (a multiple of 6).  Tap U multiplies the A
-    // operands in register set U & 1 (read from LDS during the previous tap) with the B operands in ring slot U % 6
-    // (requested five taps ago); meanwhile it requests the B operands of tap U + 5 and reads the A operands of tap U + 1.
-    // The V brick is double-buffered: chunk c reads buffer c & 1; the next chunk's pieces are requested at the chunk's
-    // first tap, written into the other buffer two taps before its end and published by the chunk's ONE barrier, which
-    // sits in front of the last tap's MFMAs (the first A read of the next chunk follows it).  Everything is compile-time
-    // and branch-free; after the last chunk the stream re-requests / re-writes harmlessly.
+    // operands in register set U & 1 (read from LDS during the previous tap) with the B operands in ring slot U % R
+    // (requested R - 1 taps ago); meanwhile it requests the B operands of tap U + R - 1 and reads the A operands of tap U + 1.
+    // The V brick is double-buffered: chunk c reads buffer c & 1; the next chunk's brick is requested (LDS-DMA) at the
+    // chunk's first tap and published by the chunk's ONE barrier, which sits in front of the last tap's MFMAs (the first A
+    // read of the next chunk follows it).  Everything is compile-time and branch-free; after the last chunk the stream
+    // re-requests harmlessly.
+    // Wait counts (loads return in order).  B(U) was requested at tap U - (R - 1); younger than it are the B requests of taps
+    // U - R + 2 .. U (2 (R - 1) loads) and the V half-brick requests (4 each) of every chunk's taps 0 and 1 in
+    // U - (R - 1) .. U.  In front of the chunk barrier the V brick requested at taps 0 and 1 must have landed: younger
+    // than it are the B requests of taps 2 .. NT - 1.
 #define W16_TAP(U, ACUR, ANXT, BCUR, BREQ)                                                                           \
     {                                                                                                                \
         constexpr int cp_ = (U) / NT, t_ = (U) % NT;          /* chunk of the pair, tap of the chunk */             \
-        constexpr int un_ = (U) + 5, cn_ = un_ / NT, tn_ = un_ % NT;                                                 \
+        constexpr int un_ = (U) + R - 1, cn_ = un_ / NT, tn_ = un_ % NT;                                             \
+        constexpr int ng_ = w16_count(t_, R, NT, 0) + w16_count(t_, R, NT, 1 % NT);   /* V half-requests among them */ \
+        constexpr int nb_ = ((W16_ABLATE & 2) ? 0 : 2 * (R - 1)) + ((W16_ABLATE & 4) ? 0 : 4 * ng_);                 \
         asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[WM - 2]), "+v"(arow[WM - 1]));                     \
         if (!(W16_ABLATE & 2)) W16_REQUEST_B(BREQ, tn_, ch + cn_)                                                    \
-        if constexpr (t_ == 0 && !(W16_ABLATE & (4 | 16))) W16_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_) \
-        /* the eight staged pieces go to LDS two per tap over the last taps in front of the barrier (a burst of 64   \
-           ds_write_b128 per workgroup stalls the A operand reads queued behind it) */                              \
-        if constexpr (!(W16_ABLATE & 4)) {                                                                           \
-            constexpr int w0_ = NT >= 6 ? NT - 5 : 1, nw_ = NT >= 6 ? 2 : 8;                                         \
-            if constexpr (t_ >= w0_ && t_ < w0_ + 8 / nw_) {                                                         \
-                _Pragma("unroll") for (int u = (t_ - w0_) * nw_; u < (t_ - w0_ + 1) * nw_; ++u)                      \
-                    *reinterpret_cast<f32x4*>(v_lds + (1 - cp_) * (W16_VROWS * 64) + vst + u * 8192) = vin[u];       \
-            }                                                                                                        \
-        }                                                                                                            \
+        if constexpr (t_ < 2 && !(W16_ABLATE & 4))                                                                   \
+            W16_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_, 1 - cp_, t_)                            \
         if constexpr (t_ < NT - 1) {                                                                                 \
             W16_LOAD_A(ANXT, t_ + 1, cp_)                                                                            \
         } else {                                                                                                     \
+            W16_WAIT_VM((W16_ABLATE & 2) ? 0 : 2 * (NT - 2))                                                         \
             W16_SYNC()                                                                                               \
             W16_LOAD_A(ANXT, 0, 1 - cp_)                                                                             \
         }                                                                                                            \
+        if (!(W16_ABLATE & 2)) W16_WAIT_B(BCUR, nb_)                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         W16_MFMA(ACUR, BCUR)                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -270,13 +301,73 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
         W16_TAP((U0) + 4, a0, a1, bq4, bq3)                                                                          \
         W16_TAP((U0) + 5, a1, a0, bq5, bq4)                                                                          \
     }
+#define W16_TAP18R9()                                                                                                \
+    {                                                                                                                \
+        W16_TAP(0, a0, a1, bq0, bq8)                                                                                 \
+        W16_TAP(1, a1, a0, bq1, bq0)                                                                                 \
+        W16_TAP(2, a0, a1, bq2, bq1)                                                                                 \
+        W16_TAP(3, a1, a0, bq3, bq2)                                                                                 \
+        W16_TAP(4, a0, a1, bq4, bq3)                                                                                 \
+        W16_TAP(5, a1, a0, bq5, bq4)                                                                                 \
+        W16_TAP(6, a0, a1, bq6, bq5)                                                                                 \
+        W16_TAP(7, a1, a0, bq7, bq6)                                                                                 \
+        W16_TAP(8, a0, a1, bq8, bq7)                                                                                 \
+        W16_TAP(9, a1, a0, bq0, bq8)                                                                                 \
+        W16_TAP(10, a0, a1, bq1, bq0)                                                                                \
+        W16_TAP(11, a1, a0, bq2, bq1)                                                                                \
+        W16_TAP(12, a0, a1, bq3, bq2)                                                                                \
+        W16_TAP(13, a1, a0, bq4, bq3)                                                                                \
+        W16_TAP(14, a0, a1, bq5, bq4)                                                                                \
+        W16_TAP(15, a1, a0, bq6, bq5)                                                                                \
+        W16_TAP(16, a0, a1, bq7, bq6)                                                                                \
+        W16_TAP(17, a1, a0, bq8, bq7)                                                                                \
+    }
     for (int ch = 0; ch < a.nchunk; ch += 2) {
-        W16_TAP6(0)
-        if constexpr (NT >= 6) W16_TAP6(6)
-        if constexpr (NT >= 9) W16_TAP6(12)
+        if constexpr (R == 9) {
+            W16_TAP18R9()
+        } else {
+            W16_TAP6(0)
+            if constexpr (NT >= 6) W16_TAP6(6)
+            if constexpr (NT >= 9) W16_TAP6(12)
+        }
+    }
+
+    // The stream's harmless last requests (LDS-DMA included) must land before LDS and the ring's registers are reused: the
+    // compiler does not know that the ring slots are still being written, so they stay operands of the wait.
+    if constexpr (R == 9) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
+                       "+v"(bq3.bl), "+v"(bq4.bh), "+v"(bq4.bl), "+v"(bq5.bh), "+v"(bq5.bl), "+v"(bq6.bh), "+v"(bq6.bl),
+                       "+v"(bq7.bh), "+v"(bq7.bl), "+v"(bq8.bh), "+v"(bq8.bl)
+                     :
+                     : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
+                       "+v"(bq3.bl), "+v"(bq4.bh), "+v"(bq4.bl), "+v"(bq5.bh), "+v"(bq5.bl)
+                     :
+                     : "memory");
     }
 
     // ---- epilogue: the four partial GEMMs of a tile meet in LDS; y0 = M0 + M1 + M2, y1 = M1 - M2 - M3
+    constexpr int NQ = BN / 4;            // float4 channel groups per tile
+    constexpr int TPI = 512 / NQ;         // tiles per pass of the workgroup
+    constexpr int NIT = W16_TILES / TPI;
+    const int n4 = tid % NQ;
+    const int n = n0 + 4 * n4;
+    const bool ncol = n < a.Cout;
+    // The residual rows are requested FIRST, all of them, so that their latency hides behind the LDS exchange: left inside
+    // the store loop every load would wait for the previous store (`res` may alias `out` as far as the compiler knows;
+    // vmcnt counts stores too), eight serialised memory round trips per workgroup.
+    f32x4 rres[NIT][2];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            rres[it][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.res && ncol)
+                rres[it][c] = *reinterpret_cast<const f32x4*>(a.res + (long)tres[2 * (tid / NQ + TPI * it) + c] * a.Cout + n);
+        }
     __syncthreads();
     float* E = reinterpret_cast<float*>(smem);  // [4][128 tiles][BN channels]
 #pragma unroll
@@ -287,42 +378,40 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
             E[(xi * W16_TILES + m) * BN + nh * 32 + l31] = acc[wm][r];
         }
     __syncthreads();
-    constexpr int NQ = BN / 4;            // float4 channel groups per tile
-    constexpr int TPI = 512 / NQ;         // tiles per pass of the workgroup
-    const int n4 = tid % NQ;
-    const int n = n0 + 4 * n4;
-    const bool ncol = n < a.Cout;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias && ncol) bias = *reinterpret_cast<const float4*>(a.bias + n);
     double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
+    // all values first (in place of the residuals), then the stores in one predicated block: a per-iteration `if (ncol)`
+    // makes the compiler re-synchronise vmcnt(0) -- i.e. wait for the previous stores -- at every join
 #pragma unroll
-    for (int it = 0; it < W16_TILES / TPI; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int tile = tid / NQ + TPI * it;
         const float4 m0 = *reinterpret_cast<const float4*>(E + (0 * W16_TILES + tile) * BN + 4 * n4);
         const float4 m1 = *reinterpret_cast<const float4*>(E + (1 * W16_TILES + tile) * BN + 4 * n4);
         const float4 m2 = *reinterpret_cast<const float4*>(E + (2 * W16_TILES + tile) * BN + 4 * n4);
         const float4 m3 = *reinterpret_cast<const float4*>(E + (3 * W16_TILES + tile) * BN + 4 * n4);
-        if (!ncol) continue;
-        const long p = tpos[tile];
-        float y[2][4] = {{m0.x + m1.x + m2.x, m0.y + m1.y + m2.y, m0.z + m1.z + m2.z, m0.w + m1.w + m2.w},
-                         {m1.x - m2.x - m3.x, m1.y - m2.y - m3.y, m1.z - m2.z - m3.z, m1.w - m2.w - m3.w}};
+        const float y[2][4] = {{m0.x + m1.x + m2.x, m0.y + m1.y + m2.y, m0.z + m1.z + m2.z, m0.w + m1.w + m2.w},
+                               {m1.x - m2.x - m3.x, m1.y - m2.y - m3.y, m1.z - m2.z - m3.z, m1.w - m2.w - m3.w}};
         const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float rv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.res) {
-                const float4 r4 = *reinterpret_cast<const float4*>(a.res + (long)tres[2 * tile + c] * a.Cout + n);
-                rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
-            }
-            float v[4];
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = fmaf(y[c][j], a.oscale, bv[j]) + rv[j];
-                ssum[j] += (double)v[j];
-                ssq[j] = fma((double)v[j], (double)v[j], ssq[j]);
-                if (a.epi & EPI_LRELU) v[j] = v[j] >= 0.f ? v[j] : 0.2f * v[j];
+                float v = fmaf(y[c][j], a.oscale, bv[j]) + rres[it][c][j];
+                if (ncol) {
+                    ssum[j] += (double)v;
+                    ssq[j] = fma((double)v, (double)v, ssq[j]);
+                }
+                if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
+                rres[it][c][j] = v;
             }
-            *reinterpret_cast<float4*>(a.out + (p + c) * a.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (ncol) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const long p = tpos[tid / NQ + TPI * it];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4*>(a.out + (p + c) * a.Cout + n) = rres[it][c];
         }
     }
     if (a.stats) {
@@ -453,6 +542,7 @@ int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, con
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "wino16: weights not packed");
     I2V_REQUIRE((epi & ~EPI_LRELU) == 0, I2V_E_INVALID, "wino16: unsupported epilogue %d", epi);
     WinoArgs a{};
+    if (int rc0 = zero_page(&a.zeros)) return rc0;
     a.in = static_cast<const char*>(v_hl16); a.wp = wts.w.as<char>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
     a.stats = stats;
     a.B = B; a.H = H; a.W = W; a.J = W / 2; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
