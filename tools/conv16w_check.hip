@@ -40,6 +40,10 @@ int main(int argc, char** argv) {
         v = (rand() / (float)RAND_MAX - 0.3f) * 2.f;
         if (v < 0) v *= 0.2f;  // leaky-relu-like distribution
     }
+    // power probe: I2V_CHECK_DATA=zero (all-zero activations), =pow2 (powers of two: empty lo parts)
+    if (const char* e = getenv("I2V_CHECK_DATA")) {
+        for (auto& v : a) v = e[0] == 'z' ? 0.f : (v == 0.f ? 0.f : std::ldexp(1.f, (int)std::floor(std::log2(std::fabs(v)))));
+    }
     std::vector<_Float16> hl(npi * Cin * 2), V((size_t)B * Ti * H * J * 4 * Cin * 2);
     for (size_t p = 0; p < npi; ++p)
         for (int c = 0; c < Cin; ++c) {
