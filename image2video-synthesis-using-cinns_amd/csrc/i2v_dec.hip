@@ -221,7 +221,10 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
     bool bad = false;
     const int C8 = C >> 3, J = W >> 1;
     const int b = blockIdx.y;
-    const int per = H * J * C8;  // threads per sample (a multiple of 64: whole waves stay active for the shuffles)
+    // Thread = (h, chunk, j, piece p): piece p of a 64-byte V row is [hi | lo] (p & 1) of the 8 channels c8 = 2 chunk + (p >> 1).
+    // The hi and the lo lane of a channel group compute the same values (the x loads coalesce; the kernel is HBM-bound),
+    // so that every store instruction of a wave writes 16 whole rows = 1 KB contiguous.
+    const int per = H * J * C8 * 2;  // threads per sample (a multiple of 64: whole waves stay active for the shuffles)
     const int Hl = H / us, Wl = W / us, Tl = T / ut;
     const float2* cp0 = coef + (long)b * C;
     const float* xb = x + (long)b * Tl * Hl * Wl * C;
@@ -230,13 +233,14 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
     const long xstride = (long)Hl * Wl * C;
     const int lane = threadIdx.x & 63, jj = lane >> 2;   // jj: position of the pair inside the wave's 16-pair segment
     for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
-        // i = ((h * (C8/4) + c32) * J + j) * 4 + c8lo   (C8 % 4 == 0: channels are a multiple of 32)
-        const int c8lo = i & 3;
+        // i = ((h * nchunk + chunk) * J + j) * 4 + p
+        const int p = i & 3;
         int q = i >> 2;
         const int j = q % J; q /= J;
-        const int c32 = q % (C8 >> 2);
-        const int h = q / (C8 >> 2);
-        const int c8 = c32 * 4 + c8lo;
+        const int chunk = q % nchunk;
+        const int h = q / nchunk;
+        const int c8 = chunk * 2 + (p >> 1);
+        const bool is_lo = p & 1;
         float ca[8], cb[8];
         {
             const float4* cp = reinterpret_cast<const float4*>(cp0 + 8 * c8);
@@ -258,8 +262,8 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
         const bool both_own = left_own && right_own;   // impossible (jj is 0 or 15), kept for clarity
         (void)both_own;
         float d0[8], d1[8], d2[8], d3[8], de[8];
-        // V row of (t, chunk, x, h, j): 64 bytes; this thread owns the 32-byte half (c8 & 1)
-        char* ob = out + ((((long)b * T * nchunk + (c8 >> 1)) * 4 * H + h) * J + j) * 64 + (c8 & 1) * 32;
+        // V row of (t, chunk, x, h, j): 64 bytes; this thread owns its 16-byte piece p
+        char* ob = out + ((((long)b * T * nchunk + chunk) * 4 * H + h) * J + j) * 64 + p * 16;
         const long ostride_x = (long)H * J * 64, ostride_t = (long)nchunk * 4 * ostride_x;
         for (int t = 0; t < T; ++t) {
             if (t % ut == 0) {
@@ -277,17 +281,15 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
             char* o = ob + (long)t * ostride_t;
 #pragma unroll
             for (int xq = 0; xq < 4; ++xq) {
-                half8_t hi, lo;
+                half8_t piece;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float v = xq == 0 ? d0[c] - d2[c] : xq == 1 ? d1[c] + d2[c] : xq == 2 ? d2[c] - d1[c] : d1[c] - d3[c];
                     const _Float16 hh = (_Float16)v;
                     bad |= !(fabsf(v) <= 65504.f);
-                    hi[c] = hh;
-                    lo[c] = (_Float16)(v - (float)hh);
+                    piece[c] = is_lo ? (_Float16)(v - (float)hh) : hh;
                 }
-                *reinterpret_cast<half8_t*>(o + xq * ostride_x) = hi;
-                *reinterpret_cast<half8_t*>(o + xq * ostride_x + 16) = lo;
+                *reinterpret_cast<half8_t*>(o + xq * ostride_x) = piece;
             }
         }
     }
@@ -369,6 +371,7 @@ struct Block {
     ConvWeights conv0, conv1, convs, sp_conv, sp_gb;
     Conv16Weights sp_conv16;  // SPADE's Conv2d(3, 128, 3) with the 3 input channels zero-padded to 8 (split-fp16 mode)
     Conv16Weights conv0_16, conv1_16, sp_gb16;  // split-fp16 variants (cfg.mma == 1)
+    Conv16Weights convs16;      // the learned shortcut's 1x1x1 conv on split-fp16 operands (pointwise16_forward)
     Wino16Weights conv0_w, conv1_w;             // Winograd F(2,3) variants of conv_0 / conv_1 (packed where the shape allows)
     bool tdup0 = false;                          // conv_0 runs on the half-rate tensor (x2 temporal up-sampling in front)
     DevBuf gn_w, gn_b;
@@ -389,6 +392,7 @@ struct i2v_dec {
     ConvImgWeights conv_img_v;  // vector-ALU variant (used when the output geometry tiles into 4x8x8 bricks)
     int Nz = 0;
     int wino = 1;  // 1: 3x3x3 convs whose shape allows it use the Winograd kernel (env I2V_DEC_WINO=0 disables)
+    int pw16 = 1;  // 1: split-fp16 mode runs the shortcut convs on split-fp16 operands too (env I2V_DEC_PW16=0: exact-fp32 MFMA)
     int device = 0;             // the device the packed weights live on
     int* status_dev = nullptr;  // sticky range flag of the hl16 producers (device) ...
     int* status_host = nullptr; // ... and its pinned host mirror, refreshed asynchronously at the end of every forward
@@ -502,7 +506,7 @@ int run_modulate(const float* x, const float* coef, const float* gb, float* out,
 int run_modulate_wino(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
                       int us, int lrelu, hipStream_t st, int* range_flag) {
     I2V_REQUIRE(C % 32 == 0 && W % 2 == 0, I2V_E_INVALID, "modulate (Winograd operand): channels %d / width %d", C, W);
-    const long per = (long)H * (W / 2) * (C / 8);
+    const long per = (long)H * (W / 2) * (C / 8) * 2;
     I2V_REQUIRE(per % 64 == 0, I2V_E_INVALID, "modulate (Winograd operand): %ld threads per sample (need whole wavefronts)", per);
     I2V_REQUIRE(per * T * 4 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
@@ -662,7 +666,9 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
             return rc;
         // Norm3D folded into the 1x1x1 conv's loads (no padding taps -> exact): no normalised copy of x is written
         (void)xs_in;
-        if ((rc = conv_forward(b.convs, x, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, st, coef))) return rc;
+        if (b.convs16.w.p) rc = pointwise16_forward(b.convs16, x, xs_low, nullptr, (long)B * Pl, Pl, EPI_NONE, st, coef, d->status_dev);
+        else rc = conv_forward(b.convs, x, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, st, coef);
+        if (rc) return rc;
         res = xs_low;
         if ((rc = tap(k, 4, xs_low, (size_t)B * Pl * b.n_out))) return rc;
     }
@@ -782,6 +788,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     auto d = std::make_unique<i2v_dec>();
     d->cfg = *cfg;
     if (const char* e = std::getenv("I2V_DEC_WINO")) d->wino = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_PW16")) d->pw16 = std::atoi(e) != 0;
     if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
     const char* names[6] = {"head_0", "g_0", "g_1", "g_2", "g_3", "g_4"};
@@ -853,6 +860,7 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         }
         if (b.learned) {
             if ((rc = sn_pack(sd, p + "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs))) return rc;
+            if (d->cfg.mma == 1 && d->pw16 && (rc = sn_pack(sd, p + "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs16))) return rc;
             const float* gw = sd.f32(p + "norm_s.bn.weight", b.n_in);
             const float* gb = sd.f32(p + "norm_s.bn.bias", b.n_in);
             if (!gw || !gb) return I2V_E_MISSING;
@@ -1096,6 +1104,7 @@ int i2v_gblock_create(int32_t n_in, int32_t n_out, int32_t z_dim, int32_t spectr
     g->ctx.cfg.spectral_norm = spectral_norm;
     g->ctx.cfg.z_dim = z_dim;
     if (const char* e = std::getenv("I2V_DEC_WINO")) g->ctx.wino = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_PW16")) g->ctx.pw16 = std::atoi(e) != 0;
     if (int rc = init_status(&g->ctx)) return rc;
     g->z_dim = z_dim;
     Block& b = g->b;
@@ -1134,6 +1143,7 @@ int i2v_gblock_load(i2v_gblock* g, const i2v_tensor* tensors, int32_t n_tensors)
             if ((rc = sn_pack(sd, "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
         }
         if (b.learned && (rc = sn_pack(sd, "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs))) return rc;
+        if (b.learned && f16 && g->ctx.pw16 && (rc = sn_pack(sd, "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs16))) return rc;
         g->has_convs = true;
     }
     if (sd.has("norm_s.bn.weight")) {
