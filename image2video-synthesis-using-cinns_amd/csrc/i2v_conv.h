@@ -80,9 +80,10 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
                    int H, int W, int epi, hipStream_t st, double* stats = nullptr, int* range_flag = nullptr,
                    float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
 // 1x1x1 conv / Linear on split-fp16 operands (i2v_pointwise.hip): in fp32 [M][Cin] (split on the fly, optional per-(sample,
-// channel) affine `coef` [M / P][Cin][2] folded in), weights = Conv16Weights packed with kt = kh = kw = 1, out fp32 [M][Cout].
+// channel) affine `coef` [M / P][Cin][2] folded in), weights = Conv16Weights packed with kt = kh = kw = 1, out fp32 [M][Cout]
+// (transposed: [Cout][M], no residual / affine).
 int pointwise16_forward(const Conv16Weights& wts, const float* in, float* out, const float* res, long M, long P, int epi,
-                        hipStream_t st, const float* coef = nullptr, int* range_flag = nullptr);
+                        hipStream_t st, const float* coef = nullptr, int* range_flag = nullptr, bool transposed = false);
 // K-split factor conv16_forward uses when it is given scratch (a function of the layer geometry only)
 int conv16_splitk_factor(long pos_per_sample, int nchunk);
 // true when conv16_forward can accumulate per-(sample, channel) sum / sum-of-squares of its output in the epilogue

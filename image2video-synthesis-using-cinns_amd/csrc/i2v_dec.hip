@@ -296,6 +296,44 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
     if (bad && range_flag) atomicOr(range_flag, 1);
 }
 
+// conv_img (decoder.py:117: Conv3d(nf, 3, 3, padding 1) + tanh) in split-fp16 mode.  With three output channels a tiled
+// implicit GEMM wastes the matrix cores (N padded to 32) and the vector-ALU kernel is LDS-bound; instead the conv is split
+// into a 1x1x1 GEMM Y[tap * 3 + n][pos] = sum_c x[pos][c] w[n][c][tap] (81 planes, written transposed by
+// pointwise16_forward: HBM-bound) and this gather: out[n][pos] = tanh(bias[n] + sum_tap Y[tap * 3 + n][pos + delta_tap]),
+// zero padding = skipped taps.  Consecutive lanes = consecutive w: every load and store is coalesced.
+// out: frames [B][T][3][H][W].
+__global__ __launch_bounds__(256) void conv_img_gather_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                              float* __restrict__ out, long total, int T, int H, int W) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int w = (int)(i % W);
+    long q = i / W;
+    const int h = (int)(q % H); q /= H;
+    const int t = (int)(q % T);
+    const long b = q / T;
+    float s0 = bias[0], s1 = bias[1], s2 = bias[2];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+        const int tt = t + kt - 1;
+        if ((unsigned)tt >= (unsigned)T) continue;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+            if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = w + kw - 1;
+                if ((unsigned)ww >= (unsigned)W) continue;
+                const float* p = y + (long)(((kt * 3 + kh) * 3 + kw) * 3) * total + (((b * T + tt) * H + hh) * W + ww);
+                s0 += p[0]; s1 += p[total]; s2 += p[2 * total];
+            }
+        }
+    }
+    const long hw = (long)h * W + w, HW = (long)H * W;
+    float* o = out + ((b * T + t) * 3) * HW + hw;
+    o[0] = tanhf(s0); o[HW] = tanhf(s1); o[2 * HW] = tanhf(s2);
+}
+
 // F.interpolate(img, size=(h,w), mode='bilinear', align_corners=True) (normalization_layer.py:20), written
 // channels-last with the 3 colour channels zero-padded to 16 (the conv kernel's K chunk).
 __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
@@ -390,8 +428,11 @@ struct i2v_dec {
     Level lvl[6];
     ConvWeights fc, zlin, conv_img;
     ConvImgWeights conv_img_v;  // vector-ALU variant (used when the output geometry tiles into 4x8x8 bricks)
+    Conv16Weights conv_img16;   // split-fp16 mode: the 81-column 1x1x1 GEMM of conv_img_gather_kernel
+    DevBuf conv_img_bias;
     int Nz = 0;
     int wino = 1;  // 1: 3x3x3 convs whose shape allows it use the Winograd kernel (env I2V_DEC_WINO=0 disables)
+    int img16 = 1;  // 1: split-fp16 mode runs conv_img as 1x1x1 GEMM + gather (env I2V_DEC_IMG16=0: vector-ALU kernel)
     int pw16 = 1;  // 1: split-fp16 mode runs the shortcut convs on split-fp16 operands too (env I2V_DEC_PW16=0: exact-fp32 MFMA)
     int device = 0;             // the device the packed weights live on
     int* status_dev = nullptr;  // sticky range flag of the hl16 producers (device) ...
@@ -441,6 +482,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
         mx_gb = std::max(mx_gb, (size_t)l.H * l.W * 2 * b.n_in);
         cmax = std::max(cmax, std::max(b.n_in, b.n_mid));
     }
+    if (d->cfg.mma == 1 && d->img16) mx_a = std::max(mx_a, (size_t)d->lvl[5].T * d->lvl[5].H * d->lvl[5].W * 81);  // conv_img's Y
     DecWs L;
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o = align_up(o + floats * 4, 256); return r; };
@@ -789,6 +831,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     d->cfg = *cfg;
     if (const char* e = std::getenv("I2V_DEC_WINO")) d->wino = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_PW16")) d->pw16 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e) != 0;
     if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
     const char* names[6] = {"head_0", "g_0", "g_1", "g_2", "g_3", "g_4"};
@@ -904,6 +947,14 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         if (!w || !b) return I2V_E_MISSING;
         if ((rc = d->conv_img.pack(w, b, 3, nf, 3, 3, 3, 1.0))) return rc;
         if ((rc = d->conv_img_v.pack(w, b, nf))) return rc;
+        if (d->cfg.mma == 1 && d->img16 && nf % 4 == 0) {
+            std::vector<float> w81((size_t)81 * nf);   // row tap * 3 + n = w[n][:][tap]
+            for (int n = 0; n < 3; ++n)
+                for (int c = 0; c < nf; ++c)
+                    for (int tap = 0; tap < 27; ++tap) w81[(size_t)(tap * 3 + n) * nf + c] = w[((size_t)n * nf + c) * 27 + tap];
+            if ((rc = d->conv_img16.pack(w81.data(), nullptr, 81, nf, 1, 1, 1, 1.0))) return rc;
+            if ((rc = d->conv_img_bias.upload(b, 3 * 4))) return rc;
+        }
     }
     d->loaded = true;
     return I2V_OK;
@@ -1025,7 +1076,14 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     }
     {
         const Level& l = d->lvl[5];
-        if (conv_img_supported(l.T, l.H, l.W, d->nf)) rc = conv_img_forward(d->conv_img_v, x, out, B, l.T, l.H, l.W, st);
+        if (d->conv_img16.w.p) {
+            const long P = (long)l.T * l.H * l.W, tot = (long)B * P;
+            I2V_REQUIRE((tot + 255) / 256 < (1L << 31), I2V_E_INVALID, "conv_img: %ld positions", tot);
+            if ((rc = pointwise16_forward(d->conv_img16, x, a, nullptr, tot, P, EPI_NONE, st, nullptr, d->status_dev, true))) return rc;
+            hipLaunchKernelGGL(conv_img_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a,
+                               d->conv_img_bias.as<float>(), out, tot, l.T, l.H, l.W);
+            I2V_HIP_CHECK(hipGetLastError());
+        } else if (conv_img_supported(l.T, l.H, l.W, d->nf)) rc = conv_img_forward(d->conv_img_v, x, out, B, l.T, l.H, l.W, st);
         else rc = conv_forward(d->conv_img, x, d->nf, out, nullptr, 1, 1, B, l.T, l.H, l.W, EPI_FRAMES, st);
         if (rc) return rc;
     }

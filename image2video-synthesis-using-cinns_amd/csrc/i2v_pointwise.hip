@@ -220,7 +220,10 @@ struct Pw16Args {
     float oscale;
 };
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool HAS_COEF>
+// TRANS: the output is written transposed, out[n][m] (row stride M): the MFMA operands are swapped, so a lane holds one
+// position and its registers the output channels, and every store instruction writes 128 contiguous bytes per half-wave
+// (conv_img's 81-column GEMM, whose gather pass then reads coalesced planes).  No residual in this mode.
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool HAS_COEF, bool TRANS = false>
 __global__ __launch_bounds__(256, 2) void pw_mfma_f16x3_kernel(Pw16Args a) {
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
@@ -332,15 +335,37 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_f16x3_kernel(Pw16Args a) {
             for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
                 for (int wn = 0; wn < WN; ++wn) {
-                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[wm], bh[wn], acc[wm][wn], 0, 0, 0);
-                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[wm], bl[wn], acc[wm][wn], 0, 0, 0);
-                    acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[wm], bh[wn], acc[wm][wn], 0, 0, 0);
+                    if (TRANS) {
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[wn], al[wm], acc[wm][wn], 0, 0, 0);
+                    } else {
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[wm], bh[wn], acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[wm], bl[wn], acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[wm], bh[wn], acc[wm][wn], 0, 0, 0);
+                    }
                 }
         }
     }
     if (bad && a.range_flag) atomicOr(a.range_flag, 1);
 
     // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (TRANS) {
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+            const long m = m0 + wave_m * (32 * WM) + 32 * wm + l31;
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wave_n * (32 * WN) + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    float v = fmaf(acc[wm][wn][r], a.oscale, (a.bias && n < a.Cout) ? a.bias[n] : 0.f);
+                    if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
+                    if (n < a.Cout && m < a.M) a.out[(long)n * a.M + m] = v;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         const int n = n0 + wave_n * (32 * WN) + 32 * wn + l31;
@@ -367,31 +392,30 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_f16x3_kernel(Pw16Args a) {
 
 namespace {
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-int pw16_launch(const Pw16Args& a, hipStream_t st) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool HAS_COEF, bool TRANS>
+int pw16_launch1(const Pw16Args& a, hipStream_t st) {
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     const size_t lds = (size_t)2 * (BM + BN) * PW16_ROW;
     const long nblk = (a.M + BM - 1) / BM * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 31), I2V_E_INVALID, "pointwise conv: grid of %ld workgroups", nblk);
-    if (a.coef) {
-        auto kern = pw_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, true>;
-        static bool attr_set[I2V_MAX_DEV] = {};
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 96 * 1024, attr_set)) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
-    } else {
-        auto kern = pw_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, false>;
-        static bool attr_set[I2V_MAX_DEV] = {};
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 96 * 1024, attr_set)) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
-    }
+    auto kern = pw_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, HAS_COEF, TRANS>;
+    static bool attr_set[I2V_MAX_DEV] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 96 * 1024, attr_set)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+int pw16_launch(const Pw16Args& a, hipStream_t st) {
+    return a.coef ? pw16_launch1<WAVES_M, WAVES_N, WM, WN, true, false>(a, st)
+                  : pw16_launch1<WAVES_M, WAVES_N, WM, WN, false, false>(a, st);
 }
 
 }  // namespace
 
 int pointwise16_forward(const Conv16Weights& wts, const float* in, float* out, const float* res, long M, long P, int epi,
-                        hipStream_t st, const float* coef, int* range_flag) {
+                        hipStream_t st, const float* coef, int* range_flag, bool transposed) {
     I2V_REQUIRE(wts.w.p && wts.KT == 1 && wts.KH == 1 && wts.KW == 1 && !wts.tdup, I2V_E_STATE, "pointwise16: needs 1x1x1 split-fp16 weights");
     I2V_REQUIRE(wts.Cin % 4 == 0 && (epi & ~EPI_LRELU) == 0 && M > 0, I2V_E_INVALID, "pointwise16: Cin %d / epilogue %d", wts.Cin, epi);
     Pw16Args a{};
@@ -399,6 +423,11 @@ int pointwise16_forward(const Conv16Weights& wts, const float* in, float* out, c
     a.range_flag = range_flag;
     a.M = M; a.P = P; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk; a.epi = epi;
     a.oscale = (float)std::ldexp(1.0, -wts.wexp);
+    if (transposed) {
+        I2V_REQUIRE(!res && !coef && a.CoutPad % 32 == 0, I2V_E_INVALID, "pointwise16: transposed output takes no residual / affine");
+        I2V_REQUIRE(a.CoutPad % 128 == 0, I2V_E_INVALID, "pointwise16: transposed output needs CoutPad %% 128 == 0 (have %d)", a.CoutPad);
+        return pw16_launch1<2, 2, 2, 2, false, true>(a, st);                     // 128 x 128: the rows are read once
+    }
     int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
     int BM = 128;
     auto blocks = [&](int bm, int bn) { return (M + bm - 1) / bm * (a.CoutPad / bn); };
