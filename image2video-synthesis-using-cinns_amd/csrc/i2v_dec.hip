@@ -482,7 +482,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
         mx_gb = std::max(mx_gb, (size_t)l.H * l.W * 2 * b.n_in);
         cmax = std::max(cmax, std::max(b.n_in, b.n_mid));
     }
-    if (d->cfg.mma == 1 && d->img16) mx_a = std::max(mx_a, (size_t)d->lvl[5].T * d->lvl[5].H * d->lvl[5].W * 81);  // conv_img's Y
+    if (d->cfg.mma == 1 && d->img16 && d->nf >= 64) mx_a = std::max(mx_a, (size_t)d->lvl[5].T * d->lvl[5].H * d->lvl[5].W * 81);  // conv_img's Y
     DecWs L;
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o = align_up(o + floats * 4, 256); return r; };
@@ -947,7 +947,9 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         if (!w || !b) return I2V_E_MISSING;
         if ((rc = d->conv_img.pack(w, b, 3, nf, 3, 3, 3, 1.0))) return rc;
         if ((rc = d->conv_img_v.pack(w, b, nf))) return rc;
-        if (d->cfg.mma == 1 && d->img16 && nf % 4 == 0) {
+        // (measured: 1.3 vs 1.7 ms per B = 64 BAIR pass at nf = 64, but 0.8 ms SLOWER than the vector-ALU kernel per B = 32
+        //  128x128 pass at nf = 32, where the 81 planes outweigh the 32-channel input)
+        if (d->cfg.mma == 1 && d->img16 && nf >= 64 && nf % 4 == 0) {
             std::vector<float> w81((size_t)81 * nf);   // row tap * 3 + n = w[n][:][tap]
             for (int n = 0; n < 3; ++n)
                 for (int c = 0; c < nf; ++c)

@@ -3,16 +3,16 @@
 export TMPDIR=/tmp
 out=${1:-gpurun_out/evidence}
 mkdir -p $out
-python bench.py --per-layer $out/conv16_per_layer_bair64.csv 2>$out/bench_bair64.err | tail -1 > $out/bench_bair64.json
-python bench.py --config land128 --steps 10 --warmup 3 --no-cpu-baseline --per-layer $out/conv16_per_layer_land128.csv 2>/dev/null | tail -1 > $out/bench_land128_b32.json
-for b in 4 8 16; do python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_bair64_b$b.json; done
-python bench.py --config dtdb128 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_dtdb128_strong_b256.json
-python bench.py --config iper128_t32 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_iper128_t32_strong_b128.json
-python bench.py --config dtdb128 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $out/bench_dtdb128_b32.json
-python bench.py --config iper128_t32 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $out/bench_iper128_t32_b16.json
+timeout 300 python bench.py --per-layer $out/conv16_per_layer_bair64.csv 2>$out/bench_bair64.err | tail -1 > $out/bench_bair64.json
+timeout 300 python bench.py --config land128 --steps 10 --warmup 3 --no-cpu-baseline --per-layer $out/conv16_per_layer_land128.csv 2>/dev/null | tail -1 > $out/bench_land128_b32.json
+for b in 4 8 16; do timeout 200 python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_bair64_b$b.json; done
+timeout 300 python bench.py --config dtdb128 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_dtdb128_strong_b256.json
+timeout 300 python bench.py --config iper128_t32 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_iper128_t32_strong_b128.json
+timeout 300 python bench.py --config dtdb128 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $out/bench_dtdb128_b32.json
+timeout 300 python bench.py --config iper128_t32 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $out/bench_iper128_t32_b16.json
 # kernel traces of the timed steps only (--no-extras: no post-timing measurement loops in the trace)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bair -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/prof_bair.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_land -o bench -- python bench.py --config land128 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/prof_land.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bair -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/prof_bair.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_land -o bench -- python bench.py --config land128 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/prof_land.log 2>&1
 rm -f $out/prof_*/bench_kernel_trace.csv
-python tools/pmc_hbm_traffic.py $out/pmc_traffic > $out/pmc_traffic.log 2>&1
+timeout 400 python tools/pmc_hbm_traffic.py $out/pmc_traffic > $out/pmc_traffic.log 2>&1
 rm -rf $out/pmc_traffic/fetch_size $out/pmc_traffic/write_size
