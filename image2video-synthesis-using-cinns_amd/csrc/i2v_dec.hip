@@ -781,6 +781,7 @@ int sn_pack_tdup(const StateDict& sd, const std::string& name, bool spectral, in
 // device binding + the sticky range flag (device word and pinned host mirror)
 int init_status(i2v_dec* d) {
     I2V_HIP_CHECK(hipGetDevice(&d->device));
+    { const char* zp = nullptr; if (int rcz = zero_page(&zp)) return rcz; }  // the conv kernels' zero page: allocated here, not inside a forward
     I2V_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->status_dev), sizeof(int)));
     I2V_HIP_CHECK(hipMemset(d->status_dev, 0, sizeof(int)));
     I2V_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->status_host), sizeof(int), hipHostMallocDefault));

@@ -193,6 +193,7 @@ int i2v_embedder_create(int32_t z_dim, int32_t use_batchnorm, i2v_embedder** out
     e->E = z_dim;
     e->bn = use_batchnorm ? 1 : 0;
     I2V_HIP_CHECK(hipGetDevice(&e->device));
+    { const char* zp = nullptr; if (int rcz = zero_page(&zp)) return rcz; }  // allocated here, not inside a forward
     *out = e.release();
     return I2V_OK;
 }

@@ -248,6 +248,7 @@ int i2v_encoder3d_create(const i2v_encoder3d_cfg* cfg, i2v_encoder3d** out) {
     auto e = std::make_unique<i2v_encoder3d>();
     e->cfg = *cfg;
     I2V_HIP_CHECK(hipGetDevice(&e->device));
+    { const char* zp = nullptr; if (int rcz = zero_page(&zp)) return rcz; }  // allocated here, not inside a forward
     *out = e.release();
     return I2V_OK;
 }

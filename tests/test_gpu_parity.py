@@ -241,6 +241,19 @@ def test_both_matrix_core_modes_agree():
         assert rel_l2(gen.cuda().eval()(cu(g["img"]), cu(g["z"])).cpu(), g["out"]) < TOL
 
 
+@pytest.mark.parametrize("env", ["I2V_DEC_WINO", "I2V_DEC_PW16", "I2V_DEC_IMG16"])
+def test_decoder_alternative_kernel_paths(env, monkeypatch):
+    """The kernels the split-fp16 mode picks by default each have a tested fallback behind an env switch read when the
+    handle is created (direct instead of Winograd 3x3x3 convs; exact-fp32 MFMA shortcut GEMM; vector-ALU conv_img): the
+    full-width BAIR decoder must reproduce the golden frames either way."""
+    g, meta = load_golden("dec_nf64_bair")
+    ref = _gen(meta)(cu(g["img"]), cu(g["z"]))
+    monkeypatch.setenv(env, "0")
+    alt = _gen(meta)(cu(g["img"]), cu(g["z"]))
+    assert rel_l2(alt[..., ::2, ::2].cpu(), g["out_s2"]) < TOL
+    assert rel_l2(alt.cpu(), ref.cpu()) < 1e-5 and not torch.equal(alt, ref)   # a different kernel really ran
+
+
 def _write_checkpoints(tmp_path, meta, with_embedder=False, with_encoder=False):
     """Checkpoint tree as get_model.Model expects it (get_model.py:15-43): <stage2>/config_stage2.yaml + cINN.pth,
     <stage1>/config_stage1.yaml + best_PFVD_GEN.pth."""

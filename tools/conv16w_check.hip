@@ -28,9 +28,19 @@ int main(int argc, char** argv) {
     for (auto& v : bias) v = rand() / (float)RAND_MAX - 0.5f;
     Conv16Weights cw;
     Wino16Weights ww;
-    int rc = tdup ? cw.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : cw.pack(w.data(), bias.data(), Cout, Cin, 3, 3, 3, 0.7);
-    if (rc) { printf("pack16: %s\n", i2v_last_error()); return 1; }
-    rc = tdup ? ww.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : ww.pack(w.data(), bias.data(), Cout, Cin, 3, 0.7);
+    int rc;
+    if (T == 1 && !tdup) {   // single frame: only the middle temporal slice ever meets data -> 1x3x3 kernels (the 3-tap variant)
+        std::vector<float> w1((size_t)Cout * Cin * 9);
+        for (size_t nc = 0; nc < (size_t)Cout * Cin; ++nc)
+            for (int k = 0; k < 9; ++k) w1[nc * 9 + k] = w[nc * 27 + 9 + k];
+        rc = cw.pack(w1.data(), bias.data(), Cout, Cin, 1, 3, 3, 0.7);
+        if (rc) { printf("pack16: %s\n", i2v_last_error()); return 1; }
+        rc = ww.pack(w1.data(), bias.data(), Cout, Cin, 1, 0.7);
+    } else {
+        rc = tdup ? cw.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : cw.pack(w.data(), bias.data(), Cout, Cin, 3, 3, 3, 0.7);
+        if (rc) { printf("pack16: %s\n", i2v_last_error()); return 1; }
+        rc = tdup ? ww.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : ww.pack(w.data(), bias.data(), Cout, Cin, 3, 0.7);
+    }
     if (rc) { printf("packw: %s\n", i2v_last_error()); return 1; }
     if (!wino16_supported(Cout, Cin, Ti, H, W)) { printf("shape not supported by the Winograd kernel\n"); return 1; }
 
