@@ -206,3 +206,40 @@ def test_bench_evidence_files_parse():
     # every BASELINE configuration is a bench workload
     assert {"bair64", "land128", "dtdb128", "iper128_t32"} <= set(bench.CONFIGS)
     assert bench.CONFIGS["dtdb128"]["batch"] == 256 and bench.CONFIGS["iper128_t32"]["vid"] == 32
+
+
+def test_winograd_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
+    """The Winograd conv kernel issues its loads as inline asm (LDS-DMA for the V brick, plain loads into the weight ring)
+    and counts every `s_waitcnt vmcnt(n)` by hand.  That arithmetic only holds while the compiler adds no VMEM operation of
+    its own inside the tap loop -- a register spill would (scratch accesses count in vmcnt).  Cross-compile the file and
+    check, per instantiation: no scratch, no spills, and inside the loop exactly the loads the macros issue."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(PKG, "csrc", "i2v_conv16w.hip")
+    asm = tmp_path / "w.s"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", src,
+                    "-o", str(asm)], check=True, capture_output=True, timeout=600)
+    text = asm.read_text()
+    kernels = re.findall(r"^(_ZN3i2v22conv_wino_f16x3_kernelILi(\d)ELi(\d+)EEEvNS_8WinoArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+                         flags=re.S | re.M)
+    assert len(kernels) == 6, [k[0] for k in kernels]
+    for name, nt, bn, whole in kernels:
+        nt = int(nt)
+        assert "scratch_" not in whole and "buffer_store" not in whole, name
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", whole), name
+        # the tap loop = the one backward branch whose body holds MFMAs; one body = a pair of chunks = 2 NT taps
+        loops = [mm for mm in re.finditer(r"^(\.LBB\d+_\d+):[^\n]*\n((?:(?!^\.LBB).)*?)s_cbranch_\w+ \1\n", whole, flags=re.S | re.M)
+                 if "v_mfma" in mm.group(2)]
+        assert len(loops) == 1, (name, len(loops))
+        loop = loops[0].group(2)
+        taps = 2 * nt
+        wm_wn = 4 if bn == "64" else 2
+        assert loop.count("v_mfma_f32_32x32x16_f16") == taps * 3 * wm_wn, name
+        assert loop.count("global_load_lds_dwordx4") == 2 * 8, name                      # one V brick (8 pieces) per chunk
+        assert len(re.findall(r"global_load_dwordx4", loop)) == taps * 2, name           # hi + lo weight fragment per tap
+        assert loop.count("s_barrier") == 2, name                                        # one barrier per chunk
+        # every MFMA block is preceded by a counted wait, none of them a full drain
+        waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)]
+        assert len(waits) >= taps and min(waits) >= 2, (name, waits)
