@@ -243,3 +243,23 @@ def test_winograd_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
         # every MFMA block is preceded by a counted wait, none of them a full drain
         waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)]
         assert len(waits) >= taps and min(waits) >= 2, (name, waits)
+    # replay every compiled tap loop against a model of the in-order VMEM queue (tools/check_asm_waits.py): no instruction
+    # may touch a register a load can still be writing, no barrier may be crossed with an LDS-DMA load in flight ...
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_asm_waits as caw
+    checked = 0
+    for name, loops in caw.kernel_loops(text, "conv_wino_f16x3_kernel"):
+        assert len(loops) == 1
+        assert caw.check_loop(loops[0]) == [], name
+        # ... and the counts are tight: one more outstanding operation at either kind of wait is a detected hazard
+        b_wait, bar_wait = max(waits_of(loops[0])), min(waits_of(loops[0]))
+        # (3-tap kernels: the chunk barrier's wait, every third tap, already covers the weight ring -- only it is tight)
+        for w in ((b_wait, bar_wait) if "ILi3E" not in name else (bar_wait,)):
+            mutated = re.sub(r"s_waitcnt vmcnt\(%d\)" % w, "s_waitcnt vmcnt(%d)" % (w + 1), loops[0])
+            assert caw.check_loop(mutated) != [], (name, w)
+        checked += 1
+    assert checked == 6
+
+
+def waits_of(loop):
+    return [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)]
