@@ -2,8 +2,12 @@
 """Benchmark of the hot path: cINN inverse + stage-1 decoder, synthesized frames/sec (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (plain shell: re-executes itself under torch.distributed.run,
+                                                            one process per GPU, 127.0.0.1 rendezvous on a free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--config dtdb128 --scaling strong]
+    python bench.py --gpus 2 --dry                          (CPU / gloo: launch path, sharding, collation and the JSON line
+                                                            with a stand-in step -- no kernels, `value` is meaningless)
 
 A "step" = one Model.synthesize-equivalent call on synthetic inputs already resident in HBM: cINN inverse on the
 rank's shard of the globally drawn residual/embedding, the decoder pass(es) (16 frames per sample and pass; vid_length 32 =
@@ -74,7 +78,14 @@ def main():
                     help="skip the post-timing measurements (cINN latency loop, MFMA probe, embedder / encoder latency): use "
                          "under rocprofv3 so that the kernel trace holds the timed steps only")
     ap.add_argument("--per-layer", type=str, help="write the per-layer table of the 3x3x3 conv launches (CSV) here")
+    ap.add_argument("--dry", action="store_true",
+                    help="CPU / gloo rehearsal of the launch path (self-launch, sharding, collation, JSON line); the step is a "
+                         "stand-in without kernels and the line says so")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    if args.dry:
+        return dry_run(args)
 
     import i2v_dist
     import i2v_native
@@ -90,8 +101,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a {world}-process job (WORLD_SIZE): the two must agree")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -246,6 +257,74 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE): re-execute under torch.distributed.run, one process per
+    GPU, 127.0.0.1 rendezvous on a free port; the children's stdout (rank 0's JSON line) passes straight through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Rehearsal of everything around the kernels on CPU tensors over gloo: rank/world from the launcher's environment,
+    global draw + contiguous shards, a stand-in step (the shard's start frames repeated over T), collation, the max-over-
+    ranks timing and rank 0's single JSON line.  No native code is touched; `value` carries no meaning."""
+    import i2v_dist
+    import i2v_synth as synth
+    cfg = CONFIGS[args.config]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a {world}-process job (WORLD_SIZE): the two must agree")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = (args.batch or 8) * (world if args.scaling == "weak" else 1)
+    x0, residual, embed = synth.bench_inputs(total, cfg["img"], cfg["emb"])
+    lo, hi = i2v_dist.shard_bounds(total, world, rank)
+    collator = i2v_dist.OverlappedCollator(total)
+
+    def step():
+        seq = x0[lo:hi, None].expand(-1, 16, -1, -1, -1).contiguous()
+        collator.submit(seq)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    out = collator.result()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ok = bool(torch.equal(out, x0[:, None].expand(-1, 16, -1, -1, -1)))
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN (CPU / gloo stand-in step, no kernels): launch path only", "value": out.shape[0] * 16 * args.steps / dt,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+                          "vs_baseline": None, "dtype": "none", "data": "synthetic", "dry": True,
+                          "config": {"workload": "dry run", "global_batch": total, "per_gpu_batch": hi - lo},
+                          "ranks_seen": dist.get_world_size() if world > 1 else 1, "collation_ok": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def _latest_traffic_file():
@@ -422,4 +501,4 @@ def cpu_baseline():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -263,3 +263,23 @@ def test_winograd_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
 
 def waits_of(loop):
     return [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)]
+
+
+def test_bench_self_launches_multi_gpu_jobs_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must re-execute itself under torch.distributed.run (the driver's
+    scaling runs call it exactly like that); --dry rehearses the launch path, sharding, collation and the JSON line on
+    CPU over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry", "--steps", "2", "--warmup", "1",
+                        "--batch", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints exactly ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["collation_ok"] and line["dry"]
+    assert line["config"]["global_batch"] == 6 and line["config"]["per_gpu_batch"] == 3
+    # inside a launcher-made job a mismatching --gpus is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--dry"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr
