@@ -78,6 +78,9 @@ def main():
                     help="skip the post-timing measurements (cINN latency loop, MFMA probe, embedder / encoder latency): use "
                          "under rocprofv3 so that the kernel trace holds the timed steps only")
     ap.add_argument("--per-layer", type=str, help="write the per-layer table of the 3x3x3 conv launches (CSV) here")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
+                    help="1 (default): the cINN pass of step k+1 runs on a side stream underneath the decoder of step k "
+                         "(i2v_pipeline.LatentPrefetcher; every step still has its own pass, the first one is exposed); 0: serial")
     ap.add_argument("--dry", action="store_true",
                     help="CPU / gloo rehearsal of the launch path (self-launch, sharding, collation, JSON line); the step is a "
                          "stand-in without kernels and the line says so")
@@ -133,28 +136,53 @@ def main():
     x0_d, res_d, emb_d = x0[lo:hi].to(dev), residual[lo:hi].to(dev), embed[lo:hi].to(dev)
     collator = i2v_dist.OverlappedCollator(total)
 
-    def step():
-        z = flow(res_d, emb_d, reverse=True).view(hi - lo, -1)
+    import i2v_pipeline
+    prefetch = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True), device=dev, enabled=bool(args.pipeline))
+
+    def decode(z):
+        z = z.view(hi - lo, -1)
         seq = gen(x0_d, z)
         while seq.shape[1] < vid_length:
             seq = torch.cat((seq, gen(seq[:, -1].contiguous(), z)), dim=1)
         collator.submit(seq)   # N > 1: all-gather on a side stream, overlapping the next step; N = 1: keeps the tensor
         return seq
 
+    def run_steps(n):
+        """n steps = n cINN inverse passes + n decoder runs.  Pipelined like the batching loop of generate_samples.py: the
+        pass of step k+1 is enqueued (side stream) before the decoder of step k; the first pass is exposed."""
+        if n <= 0:
+            return
+        ticket = prefetch.submit(res_d, emb_d)
+        for k in range(n):
+            z = prefetch.get(ticket)
+            if k + 1 < n:
+                ticket = prefetch.submit(res_d, emb_d)
+            decode(z)
+
+    def single_call_ms():
+        """One serial call: cINN pass, then the decoder (the latency of ONE Model.synthesize, nothing overlapped)."""
+        ts = []
+        for _ in range(3):
+            barrier()
+            t = time.perf_counter()
+            decode(flow(res_d, emb_d, reverse=True))
+            collator.result()
+            barrier()
+            ts.append((time.perf_counter() - t) * 1e3)
+        return float(np.median(ts))
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     if args.warmup:
         collator.result()
     barrier()
     gen.native().set_profile(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     out = collator.result()    # the current stream waits for the last gather; the barrier below covers it
     barrier()
     dt = time.perf_counter() - t0
@@ -180,6 +208,7 @@ def main():
                     "mean_abs": float(od.abs().mean()), "shape": list(out.shape)}
 
     nb = hi - lo
+    single_ms = None if args.no_extras else single_call_ms()   # (every rank: the collation inside is a collective)
     # cINN pass latency (device-timed, median of 100 after 10 warm-ups: SURVEY §8d), rank 0 only
     cinn = {}
     if rank == 0 and not args.no_extras:
@@ -216,6 +245,11 @@ def main():
                                    "20-block cINN inverse + decoder pass(es)" + (" + RCCL all-gather (overlapped)" if world > 1 else ""),
                        "global_batch": total, "per_gpu_batch": nb, "frames_per_step": frames_per_step,
                        "parallelism": f"batch-shard x{world}"},
+            "pipeline": {"cinn_of_next_step_under_decoder": bool(args.pipeline),
+                         "single_call_ms": single_ms,
+                         "note": "value counts `steps` cINN passes + `steps` decoder runs inside the timed region; with pipelining "
+                                 "the pass of step k+1 overlaps the decoder of step k (first pass exposed); single_call_ms = one "
+                                 "serial call (median of 3)"},
             "ranks_seen": dist.get_world_size() if world > 1 else 1,
             "rccl_version": list(torch.cuda.nccl.version()) if world > 1 else None,
             "output_check": output_check,
@@ -320,7 +354,12 @@ def dry_run(args):
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                           "vs_baseline": None, "dtype": "none", "data": "synthetic", "dry": True,
                           "config": {"workload": "dry run", "global_batch": total, "per_gpu_batch": hi - lo},
-                          "ranks_seen": dist.get_world_size() if world > 1 else 1, "collation_ok": ok}), flush=True)
+                          "pipeline": {"cinn_of_next_step_under_decoder": bool(args.pipeline),
+                         "single_call_ms": single_ms,
+                         "note": "value counts `steps` cINN passes + `steps` decoder runs inside the timed region; with pipelining "
+                                 "the pass of step k+1 overlaps the decoder of step k (first pass exposed); single_call_ms = one "
+                                 "serial call (median of 3)"},
+            "ranks_seen": dist.get_world_size() if world > 1 else 1, "collation_ok": ok}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -15,7 +15,13 @@
 //
 //   W0x / W0e    state part [S][8][2H][4] and embedding part [R/64][E/4][64][4] of the first layers: every wave load 1 KB
 //
-// Kernels (121 launches per pass, replayed from one hipGraph per direction)
+// Two implementations of the launch chain, both replayed from one hipGraph per direction:
+//   * i2v_flow_tile.hip (default for the shipped geometry: 64 channels, hidden 128..512, depth >= 1): every Linear on
+//     16 x 16 tiles of v_mfma_f32_16x16x4_f32, tile-major activations, last layer fused into the last hidden layer,
+//     L2 warming of the next launch's weights;
+//   * the generic vector-ALU kernels below (any hidden_dim that is a multiple of 64, depth 0; I2V_FLOW_TILE=0 selects them
+//     for A/B measurements).
+// Generic kernels (121 launches per pass)
 //   flow_pre_kernel    : embedding part of all 80 first layers at once, off the dependent chain, sample-major output
 //   flow_hidden_kernel : (i2v_linear.h) hidden Linear + LeakyReLU, s- and t-net in one launch; rows split over
 //                        workgroups, K over the waves of a workgroup (LDS reduce), float4 = 4 samples per lane
@@ -27,7 +33,7 @@
 //   (flow_linear_kernel in i2v_linear.h serves the stand-alone MLP / Linear entry points.)
 #include "i2v_common.h"
 #include "i2v_linear.h"
-#include "i2v_flow_chain.h"
+#include "i2v_flow_tile.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -233,11 +239,8 @@ struct i2v_flow {
     int S = 0;      // half-steps = 2 * n_flows
     int H = 0, E = 0, ld0 = 0, depth = 0;
     DevBuf W0, W0x, W0e, b0, Wmid, bmid, W3T, b3, an_loc, an_scale, shuf_f, shuf_b;  // W0x: [S][8][2H][4] state part of W0
-    DevBuf an_ld;   // [n_flows] sum log|scale| (device copy for the persistent chain)
-    // persistent XCD-team chain (i2v_flow_chain.hip): used for batches <= 64 of the standard geometry unless it ever aborted
-    bool chain_ok = false;           // opt-in (env I2V_FLOW_CHAIN=1): measured at parity with the launch chain, see DESIGN.md
-    void* chain_ws = nullptr;        // workspace whose exchange / sync area has been zeroed
-    int* chain_flag_host = nullptr;  // pinned mirror of the kernel's abort flag, refreshed asynchronously after every pass
+    FlowTilePack tile;               // matrix-core tile chain (i2v_flow_tile.hip); tile.ok: packed and selected
+    bool tile_wanted = true;         // env I2V_FLOW_TILE=0: generic vector-ALU chain
     std::vector<float> an_logdet;
     std::vector<int> step_cond;  // 1: first layer sees only the embedding (mode 'cond')
     size_t param_bytes = 0;
@@ -254,7 +257,6 @@ struct i2v_flow {
     }
 
     ~i2v_flow() {
-        if (chain_flag_host) (void)hipHostFree(chain_flag_host);
         drop_graphs();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
     }
@@ -263,13 +265,8 @@ struct i2v_flow {
 namespace {
 
 struct WsLayout {
-    size_t x, embed, logdet, preT, hA, hB, exch, sync, total;
+    size_t x, embed, logdet, preT, hA, hB, total;
 };
-
-// the persistent chain covers the geometry every shipped config uses: 64 channels, hidden 512, depth 2, <= 40 half-steps
-bool chain_eligible(const i2v_flow* f, int B) {
-    return f->chain_ok && f->H == 512 && f->depth == 2 && f->cfg.in_channels == 64 && f->S <= 64 && B >= 1 && B <= 64;
-}
 
 WsLayout ws_layout(const i2v_flow* f, int B) {
     WsLayout L;
@@ -282,9 +279,8 @@ WsLayout ws_layout(const i2v_flow* f, int B) {
     const size_t Bp = (size_t)(B + 63) / 64 * 64;  // hidden activations are [2H][Bp]
     L.hA = take((size_t)2 * f->H * Bp * 4);
     L.hB = take((size_t)2 * f->H * Bp * 4);
-    L.exch = take(flow_chain_exchange_floats() * 4);
-    L.sync = take((size_t)FLOW_CHAIN_SYNC_INTS * 4);
     L.total = o;
+    if (f->tile.ok) L.total = std::max(L.total, flow_tile_ws(f->tile, B).total);  // either chain may use the buffer
     return L;
 }
 
@@ -307,20 +303,6 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
         hipLaunchKernelGGL(flow_pre_kernel, dim3((R + 255) / 256, (B + PRE_SC - 1) / PRE_SC), dim3(256), 0, st, f->W0e.as<float>(), f->b0.as<float>(), embed,
                            preT, R, f->E, Epad, B);
         I2V_HIP_CHECK(hipGetLastError());
-    }
-    if (chain_eligible(f, B)) {   // one persistent launch instead of the 120 launches below
-        FlowChainArgs c{};
-        c.x = x; c.logdet = reverse ? nullptr : logdet; c.pre = preT; c.pre_stride = (long)S * N2;
-        c.W0x = f->W0x.as<float>(); c.Wmid = f->Wmid.as<float>(); c.bmid = f->bmid.as<float>();
-        c.W3T = f->W3T.as<float>(); c.b3 = f->b3.as<float>();
-        c.an_loc = f->an_loc.as<float>(); c.an_scale = f->an_scale.as<float>(); c.an_logdet = f->an_ld.as<float>();
-        c.shuf_f = f->shuf_f.as<int>(); c.shuf_b = f->shuf_b.as<int>();
-        c.exch = reinterpret_cast<float*>(ws + L.exch); c.sync = reinterpret_cast<int*>(ws + L.sync);
-        c.cond_mask = 0;
-        for (int s2 = 0; s2 < S; ++s2) if (f->step_cond[s2]) c.cond_mask |= 1ull << s2;
-        c.B = B; c.n_flows = f->cfg.n_flows; c.reverse = reverse ? 1 : 0;
-        c.use_an = an ? 1 : 0; c.use_act = act ? 1 : 0; c.use_shuf = sh ? 1 : 0;
-        return flow_chain_launch(c, st);
     }
     // next_step: half-step whose first layer is evaluated at the end of this launch (-1: none)
     auto tail = [&](const float* h, int step, int shuf_block, int an_block, bool lrelu, bool swap, int next_step) -> int {
@@ -411,6 +393,40 @@ int enqueue_chain(i2v_flow* f, bool reverse, char* ws, int B, hipStream_t st) {
     return I2V_OK;
 }
 
+// Matrix-core tile chain: the caller's tensors are read / written by the chain's own first / last launches through the
+// handle's FlowIo block, so the replayed graph needs no copy kernels around it.
+int run_pass_tile(i2v_flow* f, bool reverse, const float* xin, const float* embed, float* xout, float* logdet, char* ws, int B,
+                  hipStream_t st) {
+    FlowTileChain c{};
+    c.pack = &f->tile;
+    c.b0 = f->b0.as<float>(); c.bmid = f->bmid.as<float>(); c.b3 = f->b3.as<float>();
+    c.an_loc = f->an_loc.as<float>(); c.an_scale = f->an_scale.as<float>(); c.an_logdet_host = f->an_logdet.data();
+    c.shuf_f = f->shuf_f.as<int>(); c.shuf_b = f->shuf_b.as<int>(); c.step_cond = f->step_cond.data();
+    c.n_flows = f->cfg.n_flows;
+    c.use_an = !f->cfg.skip_actnorm; c.use_act = f->cfg.activation != 0; c.use_shuf = !f->cfg.skip_shuffle;
+    int rc = flow_tile_set_io(f->tile, FlowIo{xin, embed, xout, reverse ? nullptr : logdet}, st);
+    if (rc) return rc;
+    if (!f->cfg.use_graph) return flow_tile_enqueue(c, reverse, ws, B, st);
+    const int d = reverse ? 1 : 0;
+    if (!(f->gexec[d] && f->g_B[d] == B && f->g_ws[d] == ws)) {
+        if (f->gexec[d]) { (void)hipGraphExecDestroy(f->gexec[d]); f->gexec[d] = nullptr; }
+        if (!f->cap_stream) I2V_HIP_CHECK(hipStreamCreateWithFlags(&f->cap_stream, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        I2V_HIP_CHECK(hipStreamBeginCapture(f->cap_stream, hipStreamCaptureModeThreadLocal));
+        rc = flow_tile_enqueue(c, reverse, ws, B, f->cap_stream);
+        hipError_t e = hipStreamEndCapture(f->cap_stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        I2V_HIP_CHECK(e);
+        e = hipGraphInstantiate(&f->gexec[d], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        I2V_HIP_CHECK(e);
+        f->g_B[d] = B;
+        f->g_ws[d] = ws;
+    }
+    I2V_HIP_CHECK(hipGraphLaunch(f->gexec[d], st));
+    return I2V_OK;
+}
+
 int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, float* xout, float* logdet,
              void* workspace, size_t workspace_bytes, int B, hipStream_t st) {
     I2V_REQUIRE(f && f->loaded, I2V_E_STATE, "i2v_flow: weights not loaded");
@@ -419,23 +435,7 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_flow: workspace %zu < required %zu",
                 workspace_bytes, L.total);
     char* ws = static_cast<char*>(workspace);
-    if (f->chain_ok && f->chain_flag_host && *static_cast<volatile int*>(f->chain_flag_host) != 0) {
-        // an earlier pass of the persistent chain gave up (a team barrier timed out, or a team was spread over several XCDs):
-        // its result was invalid.  From now on this handle uses the launch chain.
-        const int why = *f->chain_flag_host;
-        f->chain_ok = false;
-        *f->chain_flag_host = 0;
-        f->drop_graphs();
-        I2V_REQUIRE(false, I2V_E_HIP, "i2v_flow: the persistent cINN chain aborted in an earlier pass (%s); that pass's output is "
-                    "invalid -- this handle now runs the launch chain", why == 2 ? "workgroup placement: a team spans XCDs"
-                                                                                  : "team barrier timed out");
-    }
-    const bool chain = chain_eligible(f, B);
-    if (chain && f->chain_ws != workspace) {
-        // granule tags and the pass epoch of the persistent chain live in the workspace: start them from zero once
-        I2V_HIP_CHECK(hipMemsetAsync(ws + L.exch, 0, flow_chain_exchange_floats() * 4 + (size_t)FLOW_CHAIN_SYNC_INTS * 4 + 256, st));
-        f->chain_ws = workspace;
-    }
+    if (f->tile.ok) return run_pass_tile(f, reverse, xin, embed, xout, logdet, ws, B, st);
     {
         const int na = B * 64, nb = B * f->E;
         hipLaunchKernelGGL(flow_copy2_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, st, xin,
@@ -471,13 +471,6 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
                            logdet, nb);
         I2V_HIP_CHECK(hipGetLastError());
     }
-    if (chain) {
-        if (!f->chain_flag_host) {
-            I2V_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->chain_flag_host), sizeof(int), hipHostMallocDefault));
-            *f->chain_flag_host = 0;
-        }
-        I2V_HIP_CHECK(hipMemcpyAsync(f->chain_flag_host, ws + L.sync, sizeof(int), hipMemcpyDeviceToHost, st));
-    }
     return I2V_OK;
 }
 
@@ -504,7 +497,7 @@ int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out) {
     f->E = cfg->embedding_dim;
     f->ld0 = 32 + cfg->embedding_dim;
     f->depth = cfg->hidden_depth;
-    if (const char* e = std::getenv("I2V_FLOW_CHAIN")) f->chain_ok = std::atoi(e) != 0;  // 1: persistent XCD-team chain
+    if (const char* e = std::getenv("I2V_FLOW_TILE")) f->tile_wanted = std::atoi(e) != 0;  // 0: generic vector-ALU chain
     *out = f.release();
     return I2V_OK;
 }
@@ -610,7 +603,10 @@ int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
     if ((rc = f->an_scale.upload(scale.data(), scale.size() * 4))) return rc;
     if ((rc = f->shuf_f.upload(sf.data(), sf.size() * 4))) return rc;
     if ((rc = f->shuf_b.upload(sb.data(), sb.size() * 4))) return rc;
-    if ((rc = f->an_ld.upload(f->an_logdet.data(), f->an_logdet.size() * 4))) return rc;
+    f->tile.ok = false;
+    if (f->tile_wanted && flow_tile_geometry_ok(f->cfg.in_channels, H, D, E)) {
+        if ((rc = flow_tile_pack(f->tile, S, H, D, E, W0.data(), Wmid.data(), W3T.data()))) return rc;
+    }
     f->param_bytes = pbytes;
     f->loaded = true;
     f->drop_graphs();

@@ -1,0 +1,579 @@
+// cINN coupling chain on the fp32 matrix cores of gfx950 (reference: stage2_cINN/modules/flow_blocks.py:63-139,
+// stage2_cINN/modules/modules.py:9-30).
+//
+// One pass = 40 coupling half-steps, each an s-net and a t-net of four Linear layers (modules.py:14-24, called at
+// flow_blocks.py:90-91,103).  Every Linear is evaluated as 16 x 16 tiles of v_mfma_f32_16x16x4_f32 (exact fp32): 16 output
+// rows x 16 samples per tile, tiles stored as the accumulator fragment (see i2v_flow_tile.h) so that one layer's output
+// IS the next layer's B operand.  Launches per pass: 1 (embedding part of all 80 first layers) + 41 + 80:
+//
+//   flow_pre_tile_kernel   pre[step][st][rt] = b0 + W0[:, 32:] . embed      (the dense conditioning GEMM, off the chain)
+//   flow_tail_tile_kernel  per sample tile: sum the last layer's 2 x 32 partial tiles -> (s, t) -> affine coupling
+//                          x*exp(s)+t / (x-t)*exp(-s) (flow_blocks.py:91,103) and log-det (:93) -> Shuffle / ActNorm /
+//                          InvLeakyRelu / half swap of the block boundary -> first Linear of the NEXT half-step (K = 32)
+//   flow_hid_tile_kernel   hidden Linear + LeakyReLU(0.01), s- and t-net in one launch: workgroup = 16 rows x NS sample
+//                          tiles, K split over the 8 waves (LDS reduce in fixed order); the LAST hidden layer never
+//                          writes its output: it multiplies its 16 x 16 tile straight into the final Linear (H -> 32)
+//                          and writes the 32 x 16 partial product instead.
+//
+// The summation order of every output element is fixed by the layer geometry alone, so results do not depend on the
+// batch size, the sample-tile grouping NS or the position of a sample in the batch (shards == full batch, bit for bit).
+//
+// L2 warming: the first 64 workgroups of every chain launch (8 per XCD; workgroup b runs on XCD b % 8 -- speed only,
+// nothing depends on it) do nothing but touch the weight tiles that the workgroups of the SAME XCD will read in the NEXT
+// launch (weights do not depend on the chain), so the dependent launch finds them in its L2 instead of in HBM.
+#include "i2v_flow_tile.h"
+
+#include <cstdlib>
+#include <vector>
+
+namespace i2v {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NPF = 64;  // prefetch workgroups per launch: 8 per XCD
+
+struct PfSeg {
+    const char* base;     // null: unused
+    unsigned tile_bytes;  // multiple of 16
+    int count;            // tiles; mode 0: XCD x owns tiles x, x + 8, ...   mode 1: every XCD < xlimit wants all of them
+    int mode, xlimit;
+};
+struct PfDesc {
+    PfSeg seg[2];
+    float* sink;
+};
+
+__device__ __forceinline__ v4f ld4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
+__device__ __forceinline__ void st4(float* p, v4f v) { *reinterpret_cast<v4f*>(p) = v; }
+__device__ __forceinline__ v4f lrelu4(v4f v, float slope) {
+    v4f o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = v[r] >= 0.f ? v[r] : v[r] * slope;
+    return o;
+}
+
+// Touch the next launch's weight tiles of this XCD.  Plain loads whose sum feeds a store that (practically) never
+// happens: all requests of a thread are in flight together and the wave retires when they have landed.
+__device__ __forceinline__ void prefetch_wg(const PfDesc& d) {
+    const int x = blockIdx.x & 7, p = blockIdx.x >> 3;
+    constexpr int MAXL = 8;  // 8 x 16 B x 512 threads x 8 workgroups = 512 KB per XCD and segment
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const PfSeg g = d.seg[s];
+        if (!g.base) continue;
+        const int nt = g.mode ? (x < g.xlimit ? g.count : 0) : (x < g.count ? (g.count - x + 7) >> 3 : 0);
+        const unsigned total = (unsigned)nt * g.tile_bytes;
+        v4f v[MAXL];
+#pragma unroll
+        for (int i = 0; i < MAXL; ++i) {
+            const unsigned off = ((unsigned)(i * 8 + p) * 512u + threadIdx.x) * 16u;
+            const bool ok = off < total;
+            const unsigned o = ok ? off : 0u;
+            const unsigned t = o / g.tile_bytes, w = o - t * g.tile_bytes;
+            const char* a = g.base + (size_t)(g.mode ? t : (unsigned)x + 8u * t) * g.tile_bytes + w;
+            v[i] = (ok && total) ? *reinterpret_cast<const v4f*>(a) : acc;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXL; ++i) acc += v[i];
+    }
+    const float sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (__float_as_uint(sum) == 0x7fc5a5a5u) d.sink[0] = sum;  // keeps the loads alive
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// embedding part of ALL first layers (modules.py:14 with dim = 32 + E, columns 32..): pre = b0 + W0e . embed
+struct PreTileArgs {
+    const float* W0E;  // [Rtiles][KE16][256]
+    const float* b0;   // [Rtiles * 16]
+    const FlowIo* io;
+    float* pre;        // [S][NST][NRT][256]
+    int NRT, NST, KE16, E, B, Rtiles, nblk;
+};
+
+constexpr int PRE_SC = 4;        // sample tiles per workgroup: the weight fragments stay in registers across them
+constexpr int PRE_LD = 128 + 4;  // LDS row stride (floats): 16-byte aligned rows, 16 rows hit 16 distinct bank quads
+
+// workgroup = 8 row tiles (one per wave) x PRE_SC sample tiles; the embeddings of the 64 samples are staged in LDS with
+// coalesced loads (rows of E floats) and read back as B fragments (lane (q, n), j -> embed[n][16 i + 4 q + j])
+__global__ __launch_bounds__(512) void flow_pre_tile_kernel(PreTileArgs a) {
+    __shared__ __attribute__((aligned(16))) float es[PRE_SC * 16][PRE_LD];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, n = lane & 15;
+    const int sc = blockIdx.x / a.nblk, blk = blockIdx.x - sc * a.nblk;
+    const int R = blk * 8 + w;
+    const bool rok = R < a.Rtiles;
+    const int Rc = rok ? R : 0;
+    const int step = Rc / a.NRT, rt = Rc - step * a.NRT;
+    const float* wp = a.W0E + ((size_t)Rc * a.KE16) * 256 + lane * 4;
+    v4f A[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[i] = i < a.KE16 ? ld4(wp + i * 256) : v4f{0.f, 0.f, 0.f, 0.f};
+    const v4f bias = ld4(a.b0 + (size_t)Rc * 16 + q * 4);
+    const float* emb = a.io->embed;
+    const int b0 = sc * PRE_SC * 16, K = a.KE16 * 16;
+    for (int i = threadIdx.x; i < PRE_SC * 16 * K; i += 512) {   // K = E rounded up to 16: the pad columns are zeros
+        const int r = i / K, k = i - r * K;
+        es[r][k] = (b0 + r < a.B && k < a.E) ? emb[(size_t)(b0 + r) * a.E + k] : 0.f;
+    }
+    __syncthreads();
+    if (!rok) return;
+#pragma unroll
+    for (int t = 0; t < PRE_SC; ++t) {
+        const int st = sc * PRE_SC + t;
+        if (st >= a.NST) break;
+        v4f D = bias;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < a.KE16) {
+                const v4f bx = ld4(&es[t * 16 + n][16 * i + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][j], bx[j], D, 0, 0, 0);
+            }
+        st4(a.pre + (((size_t)step * a.NST + st) * a.NRT + rt) * 256 + lane * 4, D);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// hidden Linear(H, H) + LeakyReLU(0.01) (modules.py:19-22), optionally fused with the final Linear(H, 32) (:24)
+struct HidTileArgs {
+    const float* WT;    // this layer [NRT][HB][256]
+    const float* bias;  // [2H]
+    const float* in;    // [NST][NRT][256]
+    float* out;         // [NST][NRT][256] or null (last hidden layer)
+    const float* W3P;   // [NRT][2][256] or null
+    float* P;           // [NST][NRT][2][256] partial products of the final Linear
+    int NRT, NST, npf;
+    PfDesc pf;
+};
+
+template <int KPW, int NS>
+__global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
+    __shared__ v4f red[8][NS][64];
+    if ((int)blockIdx.x < a.npf) { prefetch_wg(a.pf); return; }
+    constexpr int HB = 8 * KPW;
+    const int id = blockIdx.x - a.npf;
+    const int sg = id / a.NRT, rt = id - sg * a.NRT, st0 = sg * NS;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int net = rt / HB;
+    // operand requests: this wave's K slice (k16 blocks w*KPW ...) of the weight tile row and of NS activation tiles
+    v4f A[KPW], Bv[NS][KPW];
+    const float* wp = a.WT + ((size_t)rt * HB + w * KPW) * 256 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) A[i] = ld4(wp + i * 256);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int st = st0 + s < a.NST ? st0 + s : a.NST - 1;
+        const float* bp = a.in + ((size_t)st * a.NRT + net * HB + w * KPW) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) Bv[s][i] = ld4(bp + i * 256);
+    }
+    // epilogue operands of the waves that finish a tile: (sample tile es, column block cb of the final Linear)
+    const int es = w >> 1, cb = w & 1;
+    const bool epi = w < 2 * NS;
+    v4f bias4 = {0.f, 0.f, 0.f, 0.f}, A3 = {0.f, 0.f, 0.f, 0.f};
+    if (epi) {
+        bias4 = ld4(a.bias + rt * 16 + (lane >> 4) * 4);
+        if (a.W3P) A3 = ld4(a.W3P + ((size_t)rt * 2 + cb) * 256 + lane * 4);
+    }
+    v4f D[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) D[s] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) D[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][j], Bv[s][i][j], D[s], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) red[w][s][lane] = D[s];
+    __syncthreads();
+    if (!epi) return;
+    const int st = st0 + es;
+    if (st >= a.NST) return;
+    v4f h = bias4;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) h += red[v][es][lane];
+    h = lrelu4(h, 0.01f);
+    if (a.out && cb == 0) st4(a.out + ((size_t)st * a.NRT + rt) * 256 + lane * 4, h);
+    if (a.W3P) {
+        // this tile's share of the final Linear: the accumulator fragment h IS the B operand (k = 16 rt + 4 q + j)
+        v4f d3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[j], h[j], d3, 0, 0, 0);
+        st4(a.P + (((size_t)st * a.NRT + rt) * 2 + cb) * 256 + lane * 4, d3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct TailTileArgs {
+    const float* P;     // [NST][NRT][2][256] or null (launch in front of the first half-step: no coupling)
+    const float* b3;    // [64]: s bias 0..31, t bias 32..63
+    float* x;           // workspace state [NST * 16][64]
+    float* logdet;      // workspace [NST * 16] or null (reverse pass)
+    const FlowIo* io;
+    int io_in, io_out;  // read the caller's x instead of the workspace state / also write the caller's outputs
+    int ld_init;        // log-det: start from 0 instead of accumulating
+    int B, NST, NRT, HB2, reverse;
+    // elementwise ops between the coupling and the next half-step
+    const int* shuf;        // [64] gather indices or null
+    const float* an_loc;    // [64] or null
+    const float* an_scale;
+    float an_logdet;
+    int do_lrelu, do_swap;
+    // first layer of the NEXT half-step: 0 none, 1 K = 32 state channels, 2 K = 0 (mode 'cond', flow_blocks.py:89,102)
+    int l1;
+    const float* W0T;   // [NRT][2][256]
+    const float* pre;   // [NST][NRT][256]
+    float* h0;          // [NST][NRT][256]
+    int npf;
+    PfDesc pf;
+};
+
+__global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
+    __shared__ v4f ps[8][64];
+    __shared__ __attribute__((aligned(16))) float xs[16][68];
+    __shared__ __attribute__((aligned(16))) float xs2[16][68];
+    __shared__ float ld[2][16];
+    __shared__ float anl[64], ans[64];
+    __shared__ int sidx[64];
+    if ((int)blockIdx.x < a.npf) { prefetch_wg(a.pf); return; }
+    const int id = blockIdx.x - a.npf;
+    // all row groups of a sample tile on one XCD (they sum the same 2 x 32 partial tiles)
+    const int st = (id >> 6) * 8 + (id & 7), rq = (id >> 3) & 7;
+    if (st >= a.NST) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, n = lane & 15;
+    const int HB = 2 * a.HB2;
+    // ---- requests: partial tiles of the final Linear: wave = (net, column block, half of the 2 HB2 row tiles)
+    v4f pp[16];
+    if (a.P) {
+        const int net = w >> 2, cb = (w >> 1) & 1, half = w & 1;
+        const float* base = a.P + (((size_t)st * a.NRT + net * HB + half * a.HB2) * 2 + cb) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < a.HB2) pp[i] = ld4(base + (size_t)i * 512);
+    }
+    const int rpg = a.NRT >> 3;  // row tiles of the next first layer per row group
+    const bool l0 = a.l1 != 0 && w < rpg;
+    const int rt = rq * rpg + w;
+    v4f A0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, D = {0.f, 0.f, 0.f, 0.f};
+    if (l0) {
+        if (a.l1 == 1) {
+            A0[0] = ld4(a.W0T + ((size_t)rt * 2) * 256 + lane * 4);
+            A0[1] = ld4(a.W0T + ((size_t)rt * 2 + 1) * 256 + lane * 4);
+        }
+        D = ld4(a.pre + ((size_t)st * a.NRT + rt) * 256 + lane * 4);
+    }
+    v4f bs = {0.f, 0.f, 0.f, 0.f}, bt = bs;
+    if (a.P && w < 2) { bs = ld4(a.b3 + 16 * w + 4 * q); bt = ld4(a.b3 + 32 + 16 * w + 4 * q); }
+    if (tid < 256) {  // old state of the 16 samples -> LDS
+        const int nn = tid >> 4, c4 = tid & 15, b = st * 16 + nn;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (a.io_in) { if (b < a.B) v = ld4(a.io->xin + (size_t)b * 64 + 4 * c4); }
+        else v = ld4(a.x + (size_t)b * 64 + 4 * c4);
+        st4(&xs[nn][4 * c4], v);
+    } else if (tid < 320) {
+        const int c = tid - 256;
+        anl[c] = a.an_loc ? a.an_loc[c] : 0.f;
+        ans[c] = a.an_loc ? a.an_scale[c] : 1.f;
+    } else if (tid < 384) {
+        const int c = tid - 320;
+        sidx[c] = a.shuf ? a.shuf[c] : c;
+    }
+    if (a.P) {
+        v4f s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < a.HB2) s += pp[i];
+        ps[w][lane] = s;
+    }
+    __syncthreads();
+    // ---- affine coupling of the transformed half x[32..63] (flow_blocks.py:91-93 / 103): waves 0, 1 = channel blocks
+    if (a.P && w < 2) {
+        const int cb = w;
+        const v4f s = (bs + ps[cb * 2][lane]) + ps[cb * 2 + 1][lane];
+        const v4f t = (bt + ps[4 + cb * 2][lane]) + ps[4 + cb * 2 + 1][lane];
+        v4f xv = ld4(&xs[n][32 + 16 * cb + 4 * q]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[r] = a.reverse ? (xv[r] - t[r]) * expf(-s[r]) : fmaf(xv[r], expf(s[r]), t[r]);
+        st4(&xs[n][32 + 16 * cb + 4 * q], xv);
+        if (a.logdet && !a.reverse) {  // log-det of the coupling: sum of s over the 32 channels (wavefront shuffles)
+            float l = (s[0] + s[1]) + (s[2] + s[3]);
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            if (q == 0) ld[cb][n] = l;
+        }
+    }
+    __syncthreads();
+    // ---- block boundary: Shuffle gather (:152-154), ActNorm (modules.py:80/100), InvLeakyRelu (:180-187), half swap (:86,99)
+    {
+        const int nn = tid >> 5, e2 = (tid & 31) * 2, b = st * 16 + nn;
+        float o[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int cp = e2 + e;
+            const int c1 = a.do_swap ? cp ^ 32 : cp;
+            const int c0 = sidx[c1];
+            float v = xs[nn][c0];
+            if (!a.reverse) {
+                if (a.an_loc) v = ans[c1] * (v + anl[c1]);
+                if (a.do_lrelu) v = v * (v >= 0.f ? 1.0f : 0.9f);
+            } else {
+                if (a.do_lrelu) v = v / (v >= 0.f ? 1.0f : 0.9f);
+                if (a.an_loc) v = v / ans[c0] - anl[c0];
+            }
+            o[e] = v;
+        }
+        *reinterpret_cast<float2*>(&xs2[nn][e2]) = make_float2(o[0], o[1]);
+        if (rq == 0) {
+            *reinterpret_cast<float2*>(a.x + (size_t)b * 64 + e2) = make_float2(o[0], o[1]);
+            if (a.io_out && b < a.B) *reinterpret_cast<float2*>(a.io->xout + (size_t)b * 64 + e2) = make_float2(o[0], o[1]);
+        }
+        if (rq == 0 && a.logdet && tid < 16) {
+            const int bb = st * 16 + tid;
+            float v = a.ld_init ? 0.f : a.logdet[bb];
+            if (a.P) v += ld[0][tid] + ld[1][tid];
+            if (a.an_loc) v += a.an_logdet;  // ActNorm.forward: sum log|scale| (modules.py:86-87, H = W = 1)
+            a.logdet[bb] = v;
+            if (a.io_out && bb < a.B && a.io->logdet_out) a.io->logdet_out[bb] = v;
+        }
+    }
+    if (!a.l1) return;  // (uniform)
+    __syncthreads();
+    // ---- first Linear of the next half-step (modules.py:14-17, slope 0.01): K = the 32 passive state channels
+    if (l0) {
+        if (a.l1 == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const v4f bx = ld4(&xs2[n][16 * i + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) D = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[i][j], bx[j], D, 0, 0, 0);
+            }
+        }
+        st4(a.h0 + ((size_t)st * a.NRT + rt) * 256 + lane * 4, lrelu4(D, 0.01f));
+    }
+}
+
+__global__ void flow_set_io_kernel(FlowIo* dst, FlowIo v) { *dst = v; }
+
+template <int KPW>
+void launch_hid(const HidTileArgs& a, int ns, int groups, hipStream_t st) {
+    const dim3 grid(a.npf + a.NRT * groups), block(512);
+    if (ns == 1) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 1>), grid, block, 0, st, a);
+    else if (ns == 2) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 4>), grid, block, 0, st, a);
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e && *e ? std::atoi(e) : dflt;
+}
+
+}  // namespace
+
+int flow_tile_pack(FlowTilePack& p, int S, int H, int depth, int E, const float* W0, const float* Wmid, const float* W3T) {
+    p.ok = false;
+    p.S = S; p.H = H; p.depth = depth; p.E = E;
+    p.HB = H / 16; p.NRT = 2 * p.HB; p.KE16 = (E + 15) / 16;
+    const int HB = p.HB, NRT = p.NRT, KE16 = p.KE16, N2 = 2 * H, ld0 = 32 + E;
+    std::vector<float> wt((size_t)S * depth * NRT * HB * 256), w3((size_t)S * NRT * 2 * 256), w0t((size_t)S * NRT * 2 * 256),
+        w0e((size_t)S * NRT * KE16 * 256, 0.f);
+    for (int l = 0; l < S * depth; ++l)
+        for (int rt = 0; rt < NRT; ++rt)
+            for (int kb = 0; kb < HB; ++kb) {
+                float* dst = &wt[(((size_t)l * NRT + rt) * HB + kb) * 256];
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int q = lane >> 4, m = lane & 15;
+                    const float* src = Wmid + ((size_t)l * N2 + 16 * rt + m) * H + 16 * kb + 4 * q;
+                    for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = src[j];
+                }
+            }
+    for (int s = 0; s < S; ++s)
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int net = rt / HB, rtn = rt % HB;
+            for (int cb = 0; cb < 2; ++cb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int q = lane >> 4, m = lane & 15;
+                    for (int j = 0; j < 4; ++j)
+                        w3[((((size_t)s * NRT + rt) * 2 + cb) * 64 + lane) * 4 + j] =
+                            W3T[((size_t)s * H + 16 * rtn + 4 * q + j) * 64 + net * 32 + 16 * cb + m];
+                }
+            for (int lane = 0; lane < 64; ++lane) {
+                const int q = lane >> 4, m = lane & 15;
+                const float* row = W0 + ((size_t)s * N2 + 16 * rt + m) * ld0;
+                for (int kb = 0; kb < 2; ++kb)
+                    for (int j = 0; j < 4; ++j) w0t[((((size_t)s * NRT + rt) * 2 + kb) * 64 + lane) * 4 + j] = row[16 * kb + 4 * q + j];
+                for (int kb = 0; kb < KE16; ++kb)
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 16 * kb + 4 * q + j;
+                        w0e[((((size_t)s * NRT + rt) * KE16 + kb) * 64 + lane) * 4 + j] = k < E ? row[32 + k] : 0.f;
+                    }
+            }
+        }
+    int rc;
+    if ((rc = p.WT.upload(wt.data(), wt.size() * 4))) return rc;
+    if ((rc = p.W3P.upload(w3.data(), w3.size() * 4))) return rc;
+    if ((rc = p.W0T.upload(w0t.data(), w0t.size() * 4))) return rc;
+    if ((rc = p.W0E.upload(w0e.data(), w0e.size() * 4))) return rc;
+    FlowIo zero{};
+    if ((rc = p.io.upload(&zero, sizeof(zero)))) return rc;
+    p.io_host = zero;
+    p.ok = true;
+    return I2V_OK;
+}
+
+FlowTileWs flow_tile_ws(const FlowTilePack& p, int B) {
+    FlowTileWs L;
+    const size_t NST = (size_t)(B + 15) / 16;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, 256); return r; };
+    L.x = take(NST * 16 * 64 * 4);
+    L.logdet = take(NST * 16 * 4);
+    L.pre = take((size_t)p.S * NST * p.NRT * 1024);
+    L.hA = take(NST * p.NRT * 1024);
+    L.hB = take(NST * p.NRT * 1024);
+    L.P = take(NST * p.NRT * 2 * 1024);
+    L.sink = take(256);
+    L.total = o;
+    return L;
+}
+
+int flow_tile_set_io(FlowTilePack& p, const FlowIo& io, hipStream_t st) {
+    if (io.xin == p.io_host.xin && io.embed == p.io_host.embed && io.xout == p.io_host.xout && io.logdet_out == p.io_host.logdet_out)
+        return I2V_OK;
+    hipLaunchKernelGGL(flow_set_io_kernel, dim3(1), dim3(1), 0, st, p.io.as<FlowIo>(), io);
+    I2V_HIP_CHECK(hipGetLastError());
+    p.io_host = io;
+    return I2V_OK;
+}
+
+int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hipStream_t st) {
+    const FlowTilePack& p = *c.pack;
+    const FlowTileWs L = flow_tile_ws(p, B);
+    const int NST = (B + 15) / 16, NRT = p.NRT, HB = p.HB, S = p.S, D = p.depth, N2 = 2 * p.H, nf = c.n_flows;
+    float* x = reinterpret_cast<float*>(ws + L.x);
+    float* logdet = reinterpret_cast<float*>(ws + L.logdet);
+    float* pre = reinterpret_cast<float*>(ws + L.pre);
+    float* hA = reinterpret_cast<float*>(ws + L.hA);
+    float* hB = reinterpret_cast<float*>(ws + L.hB);
+    float* P = reinterpret_cast<float*>(ws + L.P);
+    float* sink = reinterpret_cast<float*>(ws + L.sink);
+    const FlowIo* io = p.io.as<FlowIo>();
+    const int npf = env_int("I2V_FLOW_PF", 0) ? NPF : 0;
+    int ns = NST <= 4 ? 1 : NST <= 8 ? 2 : 4;   // sample tiles per hidden-layer workgroup: keep ~256 workgroups
+    if (const int e = env_int("I2V_FLOW_NS", 0)) ns = e >= 4 ? 4 : e >= 2 ? 2 : 1;
+    const int groups = (NST + ns - 1) / ns;
+    const bool samew = env_int("I2V_FLOW_SAMEW", 0) != 0;  // TIMING EXPERIMENT ONLY (wrong results): every layer reads step 0's weights
+
+    {   // embedding part of every first layer of the pass
+        PreTileArgs a{};
+        a.W0E = p.W0E.as<float>(); a.b0 = c.b0; a.io = io; a.pre = pre;
+        a.NRT = NRT; a.NST = NST; a.KE16 = p.KE16; a.E = p.E; a.B = B; a.Rtiles = S * NRT; a.nblk = (a.Rtiles + 7) / 8;
+        hipLaunchKernelGGL(flow_pre_tile_kernel, dim3(a.nblk * ((NST + PRE_SC - 1) / PRE_SC)), dim3(512), 0, st, a);
+        I2V_HIP_CHECK(hipGetLastError());
+    }
+    // what a launch reads that does not depend on the chain -> prefetch descriptor for the launch in front of it
+    auto pf_for_hidden = [&](int step, int d) {
+        PfDesc f{};
+        f.sink = sink;
+        f.seg[0] = PfSeg{reinterpret_cast<const char*>(p.WT.as<float>() + ((size_t)step * D + d) * NRT * HB * 256), (unsigned)HB * 1024u, NRT, 0, 0};
+        if (d == D - 1) f.seg[1] = PfSeg{reinterpret_cast<const char*>(p.W3P.as<float>() + (size_t)step * NRT * 512), 2048u, NRT, 0, 0};
+        return f;
+    };
+    auto pf_for_tail = [&](int next_step) {   // the tail launch that evaluates the first layer of `next_step`
+        PfDesc f{};
+        f.sink = sink;
+        if (next_step < 0) return f;
+        if (!c.step_cond[next_step])
+            f.seg[0] = PfSeg{reinterpret_cast<const char*>(p.W0T.as<float>() + (size_t)next_step * NRT * 512), (unsigned)NRT * 2048u, 1, 1, NST < 8 ? NST : 8};
+        f.seg[1] = PfSeg{reinterpret_cast<const char*>(pre + (size_t)next_step * NST * NRT * 256), (unsigned)NRT * 1024u, NST, 0, 0};
+        return f;
+    };
+    auto step_of = [&](int it) {  // forward visits (fl, i) = (0,0),(0,1),(1,0)...; reverse visits (nf-1,1),(nf-1,0),(nf-2,1)...
+        const int fl = reverse ? nf - 1 - it / 2 : it / 2;
+        const int i = reverse ? 1 - it % 2 : it % 2;
+        return fl * 2 + i;
+    };
+    auto tail = [&](bool coupling, int step, int shuf_block, int an_block, bool lrelu, bool swap, int next_step, bool first, bool last) -> int {
+        TailTileArgs t{};
+        t.P = coupling ? P : nullptr;
+        t.b3 = c.b3 + (size_t)step * 64;
+        t.x = x;
+        t.logdet = reverse ? nullptr : logdet;
+        t.io = io; t.io_in = first ? 1 : 0; t.io_out = last ? 1 : 0; t.ld_init = first ? 1 : 0;
+        t.B = B; t.NST = NST; t.NRT = NRT; t.HB2 = HB / 2; t.reverse = reverse ? 1 : 0;
+        t.shuf = shuf_block >= 0 ? (reverse ? c.shuf_b : c.shuf_f) + shuf_block * 64 : nullptr;
+        t.an_loc = an_block >= 0 ? c.an_loc + an_block * 64 : nullptr;
+        t.an_scale = an_block >= 0 ? c.an_scale + an_block * 64 : nullptr;
+        t.an_logdet = an_block >= 0 ? c.an_logdet_host[an_block] : 0.f;
+        t.do_lrelu = lrelu ? 1 : 0; t.do_swap = swap ? 1 : 0;
+        if (next_step >= 0) {
+            t.l1 = c.step_cond[next_step] ? 2 : 1;
+            t.W0T = p.W0T.as<float>() + (size_t)next_step * NRT * 512;
+            t.pre = pre + (size_t)next_step * NST * NRT * 256;
+            t.h0 = hA;
+            t.pf = pf_for_hidden(next_step, 0);
+        } else {
+            t.pf.sink = sink;
+        }
+        t.npf = (npf && next_step >= 0) ? npf : 0;
+        hipLaunchKernelGGL(flow_tail_tile_kernel, dim3(t.npf + (NST + 7) / 8 * 64), dim3(512), 0, st, t);
+        I2V_HIP_CHECK(hipGetLastError());
+        return I2V_OK;
+    };
+    const bool act = c.use_act, an = c.use_an, sh = c.use_shuf;
+    int rc;
+    if (!reverse) rc = tail(false, 0, -1, an ? 0 : -1, act, false, step_of(0), true, false);
+    else rc = tail(false, 0, sh ? nf - 1 : -1, -1, false, false, step_of(0), true, false);
+    if (rc) return rc;
+    for (int it = 0; it < S; ++it) {
+        const int fl = reverse ? nf - 1 - it / 2 : it / 2;
+        const int i = reverse ? 1 - it % 2 : it % 2;
+        const int step = fl * 2 + i;
+        const int next_step = it + 1 < S ? step_of(it + 1) : -1;
+        float* cur = hA;
+        float* nxt = hB;
+        for (int d = 0; d < D; ++d) {
+            HidTileArgs m{};
+            m.WT = p.WT.as<float>() + (samew ? 0 : ((size_t)step * D + d) * NRT * HB * 256);
+            m.bias = c.bmid + ((size_t)step * D + d) * N2;
+            m.in = cur;
+            m.out = d == D - 1 ? nullptr : nxt;
+            m.W3P = d == D - 1 ? p.W3P.as<float>() + (size_t)step * NRT * 512 : nullptr;
+            m.P = P;
+            m.NRT = NRT; m.NST = NST; m.npf = npf;
+            m.pf = d == D - 1 ? pf_for_tail(next_step) : pf_for_hidden(step, d + 1);
+            switch (HB / 8) {
+                case 1: launch_hid<1>(m, ns, groups, st); break;
+                case 2: launch_hid<2>(m, ns, groups, st); break;
+                case 3: launch_hid<3>(m, ns, groups, st); break;
+                default: launch_hid<4>(m, ns, groups, st); break;
+            }
+            I2V_HIP_CHECK(hipGetLastError());
+            std::swap(cur, nxt);
+        }
+        int shuf_block = -1, an_block = -1;
+        bool lrelu = false, swap = false;
+        if (!reverse) {
+            if (i == 0) swap = true;  // before half-step 1: cat(chunk[::-1]), flow_blocks.py:86
+            else {
+                if (sh) shuf_block = fl;
+                if (fl + 1 < nf) { if (an) an_block = fl + 1; lrelu = act; }
+            }
+        } else {
+            if (i == 1) swap = true;  // before half-step 0 (flow_blocks.py:98-99)
+            else {
+                lrelu = act;
+                if (an) an_block = fl;
+                if (fl - 1 >= 0 && sh) shuf_block = fl - 1;
+            }
+        }
+        if ((rc = tail(true, step, shuf_block, an_block, lrelu, swap, next_step, false, it == S - 1))) return rc;
+    }
+    return I2V_OK;
+}
+
+}  // namespace i2v

@@ -87,11 +87,24 @@ def main(argv=None):
     bs = args.bs
     length = math.ceil(imgs.size(0) / bs)
     videos = []
+    from i2v_pipeline import LatentPrefetcher
     with torch.no_grad():
-        for i in range(length):
+        # the cINN pass of batch i + 1 runs on a side stream underneath the decoder of batch i; the residual draws keep
+        # the order of the reference's loop (generate_samples.py:44-54)
+        def inputs(i):
             batch = imgs[i * bs:(i + 1) * bs].cuda()
-            emb = embeds[i * bs:(i + 1) * bs].cuda() if embeds is not None else None
-            videos.append(model(batch, embed=emb).cpu())
+            return batch, (embeds[i * bs:(i + 1) * bs].cuda() if embeds is not None else None)
+        pf = LatentPrefetcher(lambda b, e: model.sample_latent(b, embed=e))
+        batch, emb = inputs(0)
+        ticket = pf.submit(batch, emb)
+        for i in range(length):
+            z = pf.get(ticket)
+            cur = batch
+            if i + 1 < length:
+                batch, emb = inputs(i + 1)
+                ticket = pf.submit(batch, emb)
+            videos.append(model.decode(cur, z)[:model.vid_length].cpu())   # [:vid_length]: the BATCH slice of get_model.py:75 (Q3)
+            model.check()   # the .cpu() above synchronised: a range overflow of this batch is reported now, not a call later
     videos = torch.cat(videos)
 
     save_path = args.out_path or f"./assets/results/{path_ds}/"

@@ -58,6 +58,7 @@ def main(argv=None):
             for i in range(length):
                 batch = videos[i * bs:(i + 1) * bs, 0].cuda()
                 transfer.append(model.transfer(query[None, :].cuda(), batch).cpu())
+                model.check()   # (synchronised by .cpu(): a range overflow of the split-fp16 operands is reported for THIS call)
         transfer = torch.cat(transfer)
         t = min(transfer.shape[1], query.shape[0])
         transfer = torch.cat((query[None, :t], transfer[:, :t]), dim=0)

@@ -53,17 +53,33 @@ class Model(torch.nn.Module):
         self.config = opt
 
     @torch.no_grad()
-    def synthesize(self, x_0, cond=None, residual=None, embed=None):
-        """[B,3,H,W] -> [B, 16*ceil(vid_length/16), 3, H, W]; no batch slice."""
+    def sample_latent(self, x_0, cond=None, residual=None, embed=None):
+        """First half of ``forward`` (get_model.py:59-66): draw the residual, cINN inverse -> z [B, z_dim]."""
         if residual is None:
             residual = torch.randn(x_0.size(0), self.z_dim).cuda()  # CPU generator, like get_model.py:59
-        cond = [x_0, cond]
-        z = self.flow(residual, cond, reverse=True, embed=embed).view(x_0.size(0), -1)
+        return self.flow(residual, [x_0, cond], reverse=True, embed=embed).view(x_0.size(0), -1)
+
+    @torch.no_grad()
+    def decode(self, x_0, z):
+        """Second half (get_model.py:68-73): decoder pass(es), autoregressive on the last frame with the same z."""
         seq = self.decoder(x_0, z)
         while seq.shape[1] < self.vid_length:
             seq1 = self.decoder(seq[:, -1].contiguous(), z)
             seq = torch.cat((seq, seq1), dim=1)
         return seq
+
+    @torch.no_grad()
+    def synthesize(self, x_0, cond=None, residual=None, embed=None):
+        """[B,3,H,W] -> [B, 16*ceil(vid_length/16), 3, H, W]; no batch slice."""
+        return self.decode(x_0, self.sample_latent(x_0, cond, residual, embed))
+
+    def check(self):
+        """Raises if the decoder's split-fp16 operands left the fp16 range in any call since the last check (sticky device
+        flag, i2v_dec_status).  Synchronises: call it where the results are brought to the host anyway."""
+        flags = self.decoder.native().status()
+        if flags:
+            raise RuntimeError(f"decoder status flags {flags}: activations left the fp16 range of the split-fp16 conv operands -- "
+                               "the frames of this call are invalid; use Generator(dic['mma'] = 0) / I2V_DEC_MMA=0 for this checkpoint")
 
     def forward(self, x_0, cond=None, residual=None, embed=None):
         """Input: x_0 (start frame) of shape (BS, C, H, W).  Output as the reference: ``seq[:vid_length]`` --

@@ -1,0 +1,48 @@
+"""Two-stage pipelining of the sampling path over a stream of batches (generate_samples.py:44-54 loops over batches of
+start frames): the cINN inverse pass of batch k+1 -- a 122-launch dependent chain that leaves most of the chip idle --
+runs on a high-priority side stream underneath the decoder pass(es) of batch k.
+
+    pf = LatentPrefetcher(lambda res, emb: flow(res, emb, reverse=True))
+    t = pf.submit(res_0, emb_0)
+    for k in range(n):
+        z = pf.get(t)
+        if k + 1 < n: t = pf.submit(res_{k+1}, emb_{k+1})     # enqueued before the decoder of batch k
+        frames_k = decoder(x0_k, z)
+
+Every batch still gets exactly one cINN pass and one decoder run; only the order of enqueueing changes, and the latent
+draws keep the order of the serial loop."""
+import torch
+
+
+class LatentPrefetcher:
+    def __init__(self, latent_fn, device=None, enabled=True):
+        self.latent_fn = latent_fn
+        self.enabled = bool(enabled) and torch.cuda.is_available()
+        self.stream = torch.cuda.Stream(device=device, priority=-1) if self.enabled else None
+
+    def submit(self, *args, **kwargs):
+        """Enqueue ``latent_fn(*args)`` on the side stream (after everything already enqueued on the current stream, so
+        the arguments are complete).  Returns a ticket for ``get``."""
+        if not self.enabled:
+            return (self.latent_fn(*args, **kwargs), None)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            z = self.latent_fn(*args, **kwargs)
+            done = torch.cuda.Event()
+            done.record()
+        for a in args:
+            if torch.is_tensor(a) and a.is_cuda:
+                a.record_stream(self.stream)      # the caller may drop its reference while the side stream still reads it
+        return (z, done)
+
+    def get(self, ticket):
+        """The latent of a ticket, usable on the current stream."""
+        z, done = ticket
+        if done is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done)
+            if torch.is_tensor(z):
+                z.record_stream(cur)
+        return z

@@ -39,5 +39,8 @@ def sample_prior(dloader, cINN, decoder, z_dim, control=False, generator=None):
         cond = [x_0, file["cond"]] if control else [x_0]
         z = cINN(res, cond, reverse=True).view(b, -1)
         gen.append(decoder(x_0, z).cpu())
+        if hasattr(decoder, "native") and decoder.native().status():   # (.cpu() synchronised) range guard of the split-fp16 operands
+            raise RuntimeError("sample_prior: the decoder's activations left the fp16 range of the split-fp16 conv operands "
+                               "(use mma = 0 for this checkpoint)")
         orig.append(seq[:, 1:].cpu())
     return torch.cat(gen, dim=0), torch.cat(orig, dim=0)

@@ -586,12 +586,14 @@ def test_flow_large_batches_vs_oracle():
     assert np.allclose(sum(flow.last_logdets).cpu(), ldr[:4], rtol=1e-4, atol=1e-4)
 
 
-def test_persistent_flow_chain_vs_golden(monkeypatch):
-    """The opt-in persistent XCD-team cINN chain (csrc/i2v_flow_chain.hip, env I2V_FLOW_CHAIN=1): same goldens, same
-    gates as the default launch chain, every batch size it accepts, forward and inverse, replayed (epoch-tagged granules)."""
+def test_generic_flow_chain_and_other_geometries(monkeypatch):
+    """The two implementations of the cINN launch chain: the matrix-core tile chain (csrc/i2v_flow_tile.hip, the default
+    for the shipped geometry) and the generic vector-ALU chain (I2V_FLOW_TILE=0; also what hidden_dim % 128 != 0 or
+    depth 0 fall back to).  Same goldens, same gates; hidden widths 128 / 256 / 384 (1, 2, 3 k-blocks per wave of the
+    tile kernels), depth 1 and 3, a width only the generic chain covers (192), and every sample-tile grouping NS."""
     from oracle import flow_ref
     from stage2_cINN.modules.flow_blocks import ConditionalFlow
-    monkeypatch.setenv("I2V_FLOW_CHAIN", "1")
+    monkeypatch.setenv("I2V_FLOW_TILE", "0")
     for name in ("flow_full_e64", "flow_full_ctrl"):
         g, meta = load_golden(name)
         a = meta["synth"]
@@ -603,19 +605,35 @@ def test_persistent_flow_chain_vs_golden(monkeypatch):
         assert rel_l2(zt.reshape(8, 64).cpu(), g["fwd"]) < TOL and np.allclose(ld.cpu(), g["logdet"], rtol=1e-4, atol=1e-4)
         z = flow(x, e, reverse=True)
         assert rel_l2(z.reshape(8, 64).cpu(), g["rev"]) < TOL
-        for _ in range(3):
-            assert torch.equal(flow(x, e, reverse=True), z)
+    monkeypatch.delenv("I2V_FLOW_TILE")
+    _, residual, embed = synth.bench_inputs(70, 64, 64)
+    for hidden, depth, nfl in ((128, 2, 3), (256, 1, 3), (384, 3, 2), (192, 2, 2)):
+        sd = T(synth.flow_state_dict(seed=3, embedding_dim=64, n_flows=nfl, hidden_dim=hidden, hidden_depth=depth))
+        flow = ConditionalFlow(64, 64, hidden, depth, nfl, conditioning_option="None")
+        flow.load_state_dict(sd)
+        flow = flow.cuda().eval()
+        for B in (70, 16, 3):
+            ref = flow_ref.flow_reverse(sd, residual[:B], embed[:B], n_flows=nfl, depth=depth).reshape(B, 64)
+            z = flow(residual[:B].cuda().contiguous(), embed[:B].cuda().contiguous(), reverse=True).reshape(B, 64)
+            assert rel_l2(z.cpu(), ref) < TOL, (hidden, depth, B)
+        ztr, ldr = flow_ref.flow_forward(sd, residual[:21], embed[:21], n_flows=nfl, depth=depth)
+        zt, ld = flow(residual[:21].cuda().contiguous(), embed[:21].cuda().contiguous())
+        assert rel_l2(zt.reshape(21, 64).cpu(), ztr.reshape(21, 64)) < TOL and np.allclose(ld.cpu(), ldr, rtol=1e-4, atol=1e-4)
+    # sample-tile grouping of the hidden-layer workgroups: any NS gives the same bits
     sd = T(synth.flow_state_dict(seed=7, embedding_dim=64))
+    outs = []
+    for ns in ("1", "2", "4"):
+        monkeypatch.setenv("I2V_FLOW_NS", ns)
+        flow = ConditionalFlow(64, 64, 512, 2, 20, conditioning_option="None")
+        flow.load_state_dict(sd)
+        flow = flow.cuda().eval()
+        outs.append(flow(residual.cuda(), embed.cuda(), reverse=True))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    monkeypatch.setenv("I2V_FLOW_PF", "0")   # without the L2-warming workgroups
     flow = ConditionalFlow(64, 64, 512, 2, 20, conditioning_option="None")
     flow.load_state_dict(sd)
     flow = flow.cuda().eval()
-    _, residual, embed = synth.bench_inputs(64, 64, 64)
-    ref = flow_ref.flow_reverse(sd, residual, embed).reshape(64, 64)
-    for B in (64, 1, 5, 37, 8):
-        z = flow(residual[:B].cuda().contiguous(), embed[:B].cuda().contiguous(), reverse=True).reshape(B, 64)
-        assert rel_l2(z.cpu(), ref[:B]) < TOL, B
-    z = flow(residual[:64].cuda(), embed[:64].cuda(), reverse=True)   # a later call would raise if a pass had aborted
-    assert rel_l2(z.reshape(64, 64).cpu(), ref) < TOL
+    assert torch.equal(flow(residual.cuda(), embed.cuda(), reverse=True), outs[0])
 
 
 def test_hl16_range_guard():
