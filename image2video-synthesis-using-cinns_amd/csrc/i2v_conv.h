@@ -106,7 +106,8 @@ struct Wino16Weights {
     int pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale);  // from a 3x3x3 kernel
 };
 // T = frames of the tensor V was built from (half the output frames for pack_tdup weights)
-bool wino16_supported(int cout, int cin, int T, int H, int W);
+// KT: temporal taps of the packed weights (3; 2 = temporal-duplication pair; 1 = single time slice).  False = use the direct kernel.
+bool wino16_supported(int cout, int cin, int T, int H, int W, int KT = 3);
 // T,H,W = OUTPUT geometry; epi: EPI_NONE or EPI_LRELU; stats as conv16_forward
 int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T,
                    int H, int W, int epi, hipStream_t st, double* stats = nullptr);

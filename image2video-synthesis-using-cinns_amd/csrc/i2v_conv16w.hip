@@ -14,15 +14,21 @@
 // hi*hi + hi*lo + lo*hi of i2v_conv16.hip; the output transform A^T M runs in fp32 in the epilogue.
 //
 // Workgroup = 512 threads = 8 wavefronts: 128 tiles (256 output positions, TT x TH x 2TJ brick) x 64 output channels for
-// all four x.  Wave w owns x = w & 3 and the tile half w >> 2: a 64 x 64 accumulator block (2 x 2 MFMA tiles of
-// v_mfma_f32_32x32x16_f16), so no two waves ever add into the same accumulator; the four partial results of a tile meet
-// in the epilogue (through LDS).  K chunk = 16 channels = one MFMA k-step per tap.  LDS rows are 64 B (2 groups x (8 hi |
-// 8 lo)) WITHOUT padding; the 16-byte piece p of row r sits at p ^ ((r >> 2) & 3), which makes every ds_read_b128 lane
-// group (16 rows distinct mod 16) hit 16 distinct bank quads.  V halo brick: [x][TT+KT-1][TH+2][TJ] rows (no halo along
-// w -- it is inside V), single-buffered, the next chunk's pieces requested a few taps before the chunk ends.  Weights:
-// stages of two taps x 4 x x 64 channels (32 KB) double-buffered in LDS, requested two stages ahead into registers in
-// ONE continuous stream across the chunk boundaries (the stream never drains; requests are unconditional because the
-// vmcnt queue retires in order).  One barrier per stage plus one per chunk.
+// all four x.  Wave w owns x = w & 3 and the 32-channel half w >> 2: four MFMA row blocks (32 tiles each) x one column block
+// of v_mfma_f32_32x32x16_f16 = 64 accumulator registers, so no two waves ever add into the same accumulator; the four
+// partial results of a tile meet in the epilogue (through LDS).  K chunk = 16 channels = one MFMA k-step per tap.
+//   * V halo brick [x][TT+KT-1][TH+2][TJ] (no halo along w -- it is inside V) of 64-byte rows (2 groups x (8 hi | 8 lo)),
+//     DOUBLE-buffered in LDS, unpadded: the 16-byte piece p of row r sits at p ^ ((r >> 2) & 3), which makes every
+//     ds_read_b128 lane group hit 16 distinct bank quads.  The brick arrives by LDS-DMA (global_load_lds_dwordx4: no staging
+//     registers, no ds_write pass; the swizzle is applied to the per-lane SOURCE address, padding rows read a zero page);
+//     the next chunk's brick is requested in two halves at the chunk's first two taps and published by the chunk's ONE
+//     barrier.
+//   * Weights never touch LDS: fragment-major U, each wave loads the B operand of a tap with two coalesced 1 KB loads into
+//     a register ring (nine slots = eight taps ahead in the 9-tap kernel, six elsewhere), one continuous stream across the
+//     chunk boundaries.
+//   * The loop body is a pair of chunks (ring slot, A register set and V buffer are all compile-time, the body is
+//     branch-free); the loads are asm statements and EVERY wait is counted by hand (tools/check_asm_waits.py replays the
+//     compiled loops against the in-order VMEM queue).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -491,9 +497,25 @@ static int wino_pack_sets(Wino16Weights& o, const std::vector<double>& w3, int n
     return o.w.upload(p.data(), p.size() * 2);
 }
 
-bool wino16_supported(int cout, int cin, int T, int H, int W) {
-    if (cout % 32 || cin % (2 * W16_KC) || W % 8 || H < 8) return false;  // (the kernel's loop body is a chunk pair)
-    return (long)T * H * (W / 2) >= W16_TILES;
+// Brick of 128 Winograd tiles = TT frames x TH rows x TJ = 4 output pairs (the only brick width every shipped and tested
+// shape uses: an MFMA row block is then 8 consecutive rows of one frame).  False when [T, H, W] with a KT-tap temporal
+// kernel cannot be tiled that way or its halo brick does not fit the staged rows -- the caller then runs the direct kernel.
+static bool wino16_tiling(int T, int H, int W, int KT, int* TT_, int* TH_, int* TJ_) {
+    if (T < 1 || W % 8 || H < 8) return false;
+    const int J = W / 2, TJ = 4;
+    int TT = 1;
+    while (TT < 4 && T % (TT * 2) == 0) TT *= 2;
+    const int TH = W16_TILES / (TT * TJ);
+    if (TH > H || H % TH || J % TJ || TH * TJ % 32) return false;
+    if (4 * (TT + KT - 1) * (TH + 2) * TJ > W16_VROWS) return false;   // halo brick, 64-byte rows
+    *TT_ = TT; *TH_ = TH; *TJ_ = TJ;
+    return true;
+}
+
+bool wino16_supported(int cout, int cin, int T, int H, int W, int KT) {
+    if (cout % 32 || cin % (2 * W16_KC)) return false;  // (the kernel's loop body is a chunk pair)
+    int TT, TH, TJ;
+    return wino16_tiling(T, H, W, KT, &TT, &TH, &TJ);
 }
 
 int Wino16Weights::pack(const float* w_src, const float* bias_src, int cout, int cin, int kt, double scale) {
@@ -553,24 +575,13 @@ int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, con
         T /= 2;
     }
     a.T = T;
-    I2V_REQUIRE(!(T == 1 && wts.KT == 3), I2V_E_INVALID, "wino16: single-frame inputs need weights packed with kt = 1");
-    I2V_REQUIRE(wino16_supported(wts.Cout, wts.Cin, T, H, W), I2V_E_INVALID, "wino16: unsupported shape [%d,%d,%d] %d -> %d", T, H, W,
-                wts.Cin, wts.Cout);
+    I2V_REQUIRE(wino16_supported(wts.Cout, wts.Cin, T, H, W, wts.KT), I2V_E_INVALID, "wino16: unsupported shape [%d,%d,%d] %d -> %d (kt = %d)",
+                T, H, W, wts.Cin, wts.Cout, wts.KT);
     a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
     a.oscale = (float)std::ldexp(1.0, -wts.wexp);
-    // brick: TT x TH x TJ tiles = 128, TH * TJ a multiple of 32 (an MFMA row block = consecutive LDS rows of one frame)
-    const int J = W / 2;
-    int TT = 1;
-    while (TT < 4 && T % (TT * 2) == 0) TT *= 2;
-    int TJ = 4, TH = W16_TILES / (TT * TJ);
-    while (TH > H || H % TH) {  // small maps: widen the brick along w instead
-        TJ *= 2; TH /= 2;
-        I2V_REQUIRE(TH >= 1 && TJ <= J && J % TJ == 0, I2V_E_INVALID, "wino16: cannot tile [T=%d,H=%d,W=%d]", T, H, W);
-    }
-    I2V_REQUIRE(J % TJ == 0 && TH * TJ % 32 == 0 && TT * TH * TJ == W16_TILES, I2V_E_INVALID, "wino16: cannot tile [T=%d,H=%d,W=%d]", T, H, W);
-    const int KT = wts.KT;
-    const int nrow = 4 * (TT + KT - 1) * (TH + 2) * TJ;
-    I2V_REQUIRE(nrow <= W16_VROWS, I2V_E_INVALID, "wino16: halo brick of %d rows", nrow);
+    const int J = W / 2, KT = wts.KT;
+    int TT = 1, TH = 1, TJ = 4;
+    (void)wino16_tiling(T, H, W, KT, &TT, &TH, &TJ);
     a.TT = TT; a.TH = TH; a.TJ = TJ; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = J / TJ;
     a.wofs = 0;
     const int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup

@@ -608,10 +608,11 @@ int conv3_w(i2v_dec* d, const Wino16Weights& w, const float* v_hl16, float* out,
 
 // which kernel conv_0 / conv_1 of a block use at this geometry (want_*: by shape; use_*: and the weights are packed for it)
 bool want_wino0(const i2v_dec* d, const Block& b, const Level& l) {
-    return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_mid, b.n_in, l.ut == 2 ? l.T / 2 : l.T, l.H, l.W);
+    const bool tdup = l.ut == 2;   // conv_0 behind a x2 temporal up-sampling: pair kernels on the half-rate tensor (Block::tdup0)
+    return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_mid, b.n_in, tdup ? l.T / 2 : l.T, l.H, l.W, tdup ? 2 : 3);
 }
 bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
-    return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_out, b.n_mid, l.T, l.H, l.W);
+    return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
 }
 bool use_wino0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_w.w.p && want_wino0(d, b, l); }
 bool use_wino1(const i2v_dec* d, const Block& b, const Level& l) { return b.conv1_w.w.p && want_wino1(d, b, l); }
@@ -1284,6 +1285,11 @@ int i2v_gblock_forward(i2v_gblock* g, const float* x, const float* z, const floa
     if (g->ctx.cfg.mma == 1)
         I2V_HIP_CHECK(hipMemcpyAsync(g->ctx.status_host, g->ctx.status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     return I2V_OK;
+}
+
+int i2v_gblock_status(i2v_gblock* g, int32_t* flags, int32_t reset, void* stream) {
+    I2V_REQUIRE(g && flags, I2V_E_INVALID, "i2v_gblock_status: null argument");
+    return i2v_dec_status(&g->ctx, flags, reset, stream);
 }
 
 int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* cond, int32_t img_h, int32_t img_w, float* out,

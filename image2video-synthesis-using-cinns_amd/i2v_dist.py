@@ -76,7 +76,10 @@ class OverlappedCollator:
         k = self.i
         self.i ^= 1
         if self.bufs[k] is None or self.bufs[k].shape[1:] != local.shape[1:] or self.bufs[k].dtype != local.dtype:
-            self.bufs[k] = torch.empty((self.total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            if self.events[k] is not None:
+                self.events[k].synchronize()             # a gather into the old buffer may still be in flight
+            with torch.cuda.stream(self.stream):         # owned by the side stream (the only writer); readers sync via events
+                self.bufs[k] = torch.empty((self.total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = local.contiguous()
         ready = torch.cuda.Event()
         ready.record()                                   # the rank's block is complete at this point of the compute stream
@@ -95,7 +98,9 @@ class OverlappedCollator:
         kind, v = self.last
         if kind == "sync":
             return v
-        torch.cuda.current_stream().wait_event(self.events[v])
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.events[v])
+        self.bufs[v].record_stream(cur)                  # read on the caller's stream, allocated on the side stream
         return self.bufs[v]
 
 

@@ -73,6 +73,7 @@ SYMBOLS = {
     "i2v_gblock_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32, c_int32, c_int32]),
     "i2v_gblock_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
                                      c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "i2v_gblock_status": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_void_p]),
     "i2v_gblock_norm": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_int32,
                                   c_int32, c_int32, c_int32, c_void_p]),
     "i2v_embedder_create": (c_int32, [c_int32, c_int32, POINTER(c_void_p)]),
@@ -521,6 +522,13 @@ class NativeGBlock(_Handle):
         _check(lib().i2v_gblock_forward(self._h, x.data_ptr(), z.data_ptr(), img.data_ptr(), img.shape[2], img.shape[3],
                                         out.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, W, _stream()), "i2v_gblock_forward")
         return out
+
+    @_on_device
+    def status(self, reset=False):
+        """Range guard of this block's split-fp16 operand writers (i2v_gblock_status): synchronises, returns the flag word."""
+        flags = c_int32()
+        _check(lib().i2v_gblock_status(self._h, ctypes.byref(flags), int(bool(reset)), _stream()), "i2v_gblock_status")
+        return int(flags.value)
 
     @_on_device
     def norm(self, part, x, cond):

@@ -72,8 +72,8 @@ class ConditionalFlow(NativeBacked):
         for blk in self.sub_layers:
             h, ld = blk(h.reshape(h.shape[0], -1, 1, 1), e4)
             logdet = logdet + ld
-            self.last_outs.append(h)
-            self.last_logdets.append(ld)
+            self.last_outs.append(h)              # [B, C] like the reference (the block's output is 2-D, flow_blocks.py:47-49)
+            self.last_logdets.append(logdet)      # the RUNNING total, as flow_blocks.py:48,50 appends it
         return h[:, :, None, None], logdet
 
     def forward(self, x, embedding, reverse=False):

@@ -193,6 +193,9 @@ size_t i2v_gblock_workspace_bytes(const i2v_gblock* g, int32_t batch, int32_t t,
 int i2v_gblock_forward(i2v_gblock* g, const float* x, const float* z, const float* img, int32_t img_h, int32_t img_w,
                        float* out, void* workspace, size_t workspace_bytes, int32_t batch, int32_t t, int32_t h, int32_t w,
                        void* stream);
+/* The block's own range guard (see i2v_dec_status): synchronises `stream`, returns the sticky flag word of the split-fp16
+ * operand writers of this handle (bit 0 = an operand left the fp16 range) and optionally clears it. */
+int i2v_gblock_status(i2v_gblock* g, int32_t* flags, int32_t reset, void* stream);
 /* part 0: Spade.forward(x, cond = img [B,3,img_h,img_w]); part 1: ADAIN.forward(x [B,n_mid,...], cond = z [B,z_dim]);
  * part 2: Norm3D.forward(x).  Output has the shape of x. */
 int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* cond, int32_t img_h, int32_t img_w, float* out,
