@@ -259,7 +259,8 @@ def main():
             cinn_bytes = flow.native().param_bytes + 4 * nb * (64 + cfg["emb"] + 64)
             measured, msrc = cinn_measured_bytes(default_workload)
             result["roofline_cinn"] = {
-                "kernel": "cINN inverse pass (flow_pre_kernel, then the flow_hidden_kernel / flow_tail_kernel chain)",
+                "kernel": "cINN inverse pass (flow_pre_tile_kernel, then the flow_hid_tile_kernel / flow_tail_tile_kernel chain: "
+                          "v_mfma_f32_16x16x4_f32 tiles)",
                 "bound": "hbm", "bytes_per_pass": cinn_bytes,
                 "achieved": cinn_bytes / (cinn["inv_us"] * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": cinn_bytes / (cinn["inv_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS,
@@ -383,7 +384,7 @@ def cinn_measured_bytes(default_workload):
         with open(path) as f:
             k = json.load(f)["kernels"]
         flow = {n: v for n, v in k.items() if "flow_" in n}
-        passes = next(v["launches"] for n, v in flow.items() if "flow_pre_kernel" in n)
+        passes = next(v["launches"] for n, v in flow.items() if "flow_pre" in n)
         return sum(v["read_bytes"] + v["write_bytes"] for v in flow.values()) / passes, "static: profiles/" + os.path.basename(path)
     except (OSError, KeyError, ValueError, StopIteration, TypeError):
         return None, None

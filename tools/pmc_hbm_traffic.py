@@ -58,8 +58,33 @@ def one_pass(outdir, counter, extra, parse_only):
     return per, " ".join(cmd)
 
 
+def calibrate(outdir):
+    """FETCH_SIZE against known byte counts (tools/fetch_calib.hip): bytes requested / (FETCH_SIZE * 1024) per access pattern."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "tools", "fetch_calib")
+    d = os.path.join(outdir, "fetch_calib")
+    out = subprocess.run(["rocprofv3", "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", exe],
+                         check=True, capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp")).stdout
+    known = {ln.split()[0]: float(ln.split()[1]) for ln in out.splitlines() if ln.startswith("calib_")}
+    res = {}
+    with open(os.path.join(d, "pmc_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            k = r["Kernel_Name"].split("(")[0]
+            if r["Counter_Name"] == "FETCH_SIZE" and k in known:
+                res[k] = {"bytes_requested": known[k], "FETCH_SIZE_KiB": float(r["Counter_Value"]),
+                          "bytes_per_counted_byte": known[k] / (float(r["Counter_Value"]) * 1024.0)}
+    return res
+
+
 def main():
     outdir = sys.argv[1]
+    if "--calibrate" in sys.argv[2:]:
+        os.makedirs(outdir, exist_ok=True)
+        res = calibrate(outdir)
+        with open(os.path.join(outdir, "fetch_calibration.json"), "w") as f:
+            json.dump(res, f, indent=1)
+        print(json.dumps(res))
+        return
     extra = [a for a in sys.argv[2:] if a != "--parse-only"]
     parse_only = "--parse-only" in sys.argv[2:]  # re-derive the JSON from the CSVs of an earlier run
     os.makedirs(outdir, exist_ok=True)

@@ -3,7 +3,7 @@
 out=$1; shift
 export TMPDIR=/tmp
 mkdir -p $out
-rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $out/p1 -o pmc -- "$@" > $out/p1.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $out/p1 -o pmc -- "$@" > $out/p1.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/p2 -o pmc -- "$@" > $out/p2.log 2>&1
 python3 - $out <<'PY'
 import csv, sys, collections, glob
@@ -22,7 +22,9 @@ for k, cs in agg.items():
     if "SQ_WAVE_CYCLES" in v:
         wc = v["SQ_WAVE_CYCLES"]
         print(f"   -> wave time: waitcnt/barrier {v['SQ_WAIT_ANY']/wc:.2f}  issue-stall {v['SQ_WAIT_INST_ANY']/wc:.2f}  issuing {v['SQ_ACTIVE_INST_ANY']/wc:.2f}")
-        if "SQ_BUSY_CYCLES" in v: print(f"   -> MFMA pipe busy {v['SQ_VALU_MFMA_BUSY_CYCLES']/ (v['SQ_BUSY_CYCLES']*4*8/ 8):.3f} (of SQ_BUSY_CYCLES x 4 SIMDs)")
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs of the XCD the counters are read from (32 CUs x 4 SIMDs),
+        # GRBM_GUI_ACTIVE is the kernel's active clock count: busy fraction of ONE matrix pipe = sum / (clocks x 32 x 4)
+        if "GRBM_GUI_ACTIVE" in v: print(f"   -> MFMA pipe busy {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (v['GRBM_GUI_ACTIVE'] * 32 * 4):.3f} (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs))")
     if "SQ_LDS_IDX_ACTIVE" in v and "GRBM_GUI_ACTIVE" in v:
         print(f"   -> LDS bank-conflict cycles / LDS active: {v['SQ_LDS_BANK_CONFLICT']/max(v['SQ_LDS_IDX_ACTIVE'],1):.3f}; LDS latency {v['SQ_INST_LEVEL_LDS']/max(v['SQ_ACTIVE_INST_LDS'],1):.1f}; wait_inst_lds {v['SQ_WAIT_INST_LDS']:.3g}")
 PY
