@@ -355,12 +355,7 @@ def dry_run(args):
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                           "vs_baseline": None, "dtype": "none", "data": "synthetic", "dry": True,
                           "config": {"workload": "dry run", "global_batch": total, "per_gpu_batch": hi - lo},
-                          "pipeline": {"cinn_of_next_step_under_decoder": bool(args.pipeline),
-                         "single_call_ms": single_ms,
-                         "note": "value counts `steps` cINN passes + `steps` decoder runs inside the timed region; with pipelining "
-                                 "the pass of step k+1 overlaps the decoder of step k (first pass exposed); single_call_ms = one "
-                                 "serial call (median of 3)"},
-            "ranks_seen": dist.get_world_size() if world > 1 else 1, "collation_ok": ok}), flush=True)
+                          "ranks_seen": dist.get_world_size() if world > 1 else 1, "collation_ok": ok}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

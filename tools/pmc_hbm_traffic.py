@@ -69,7 +69,7 @@ def calibrate(outdir):
     res = {}
     with open(os.path.join(d, "pmc_counter_collection.csv")) as f:
         for r in csv.DictReader(f):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("void ", "").split("(")[0]
             if r["Counter_Name"] == "FETCH_SIZE" and k in known:
                 res[k] = {"bytes_requested": known[k], "FETCH_SIZE_KiB": float(r["Counter_Value"]),
                           "bytes_per_counted_byte": known[k] / (float(r["Counter_Value"]) * 1024.0)}
