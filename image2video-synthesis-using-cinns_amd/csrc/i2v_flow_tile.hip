@@ -18,9 +18,9 @@
 // The summation order of every output element is fixed by the layer geometry alone, so results do not depend on the
 // batch size, the sample-tile grouping NS or the position of a sample in the batch (shards == full batch, bit for bit).
 //
-// L2 warming: the first 64 workgroups of every chain launch (8 per XCD; workgroup b runs on XCD b % 8 -- speed only,
-// nothing depends on it) do nothing but touch the weight tiles that the workgroups of the SAME XCD will read in the NEXT
-// launch (weights do not depend on the chain), so the dependent launch finds them in its L2 instead of in HBM.
+// Measured and not kept (profiles/r03_a_*, tools/experiments/README.md): 64 extra workgroups per launch that touch the next
+// launch's weight tiles of their XCD ("L2 warming") made the pass 43 us SLOWER at B = 64; with every layer reading the same
+// (L2-resident) weights the pass is only 23 us faster, i.e. the weight fetch is not what a launch waits for.
 #include "i2v_flow_tile.h"
 
 #include <cstdlib>
@@ -32,19 +32,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int NPF = 64;  // prefetch workgroups per launch: 8 per XCD
-
-struct PfSeg {
-    const char* base;     // null: unused
-    unsigned tile_bytes;  // multiple of 16
-    int count;            // tiles; mode 0: XCD x owns tiles x, x + 8, ...   mode 1: every XCD < xlimit wants all of them
-    int mode, xlimit;
-};
-struct PfDesc {
-    PfSeg seg[2];
-    float* sink;
-};
-
 __device__ __forceinline__ v4f ld4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
 __device__ __forceinline__ void st4(float* p, v4f v) { *reinterpret_cast<v4f*>(p) = v; }
 __device__ __forceinline__ v4f lrelu4(v4f v, float slope) {
@@ -52,35 +39,6 @@ __device__ __forceinline__ v4f lrelu4(v4f v, float slope) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = v[r] >= 0.f ? v[r] : v[r] * slope;
     return o;
-}
-
-// Touch the next launch's weight tiles of this XCD.  Plain loads whose sum feeds a store that (practically) never
-// happens: all requests of a thread are in flight together and the wave retires when they have landed.
-__device__ __forceinline__ void prefetch_wg(const PfDesc& d) {
-    const int x = blockIdx.x & 7, p = blockIdx.x >> 3;
-    constexpr int MAXL = 8;  // 8 x 16 B x 512 threads x 8 workgroups = 512 KB per XCD and segment
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const PfSeg g = d.seg[s];
-        if (!g.base) continue;
-        const int nt = g.mode ? (x < g.xlimit ? g.count : 0) : (x < g.count ? (g.count - x + 7) >> 3 : 0);
-        const unsigned total = (unsigned)nt * g.tile_bytes;
-        v4f v[MAXL];
-#pragma unroll
-        for (int i = 0; i < MAXL; ++i) {
-            const unsigned off = ((unsigned)(i * 8 + p) * 512u + threadIdx.x) * 16u;
-            const bool ok = off < total;
-            const unsigned o = ok ? off : 0u;
-            const unsigned t = o / g.tile_bytes, w = o - t * g.tile_bytes;
-            const char* a = g.base + (size_t)(g.mode ? t : (unsigned)x + 8u * t) * g.tile_bytes + w;
-            v[i] = (ok && total) ? *reinterpret_cast<const v4f*>(a) : acc;
-        }
-#pragma unroll
-        for (int i = 0; i < MAXL; ++i) acc += v[i];
-    }
-    const float sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    if (__float_as_uint(sum) == 0x7fc5a5a5u) d.sink[0] = sum;  // keeps the loads alive
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -145,19 +103,20 @@ struct HidTileArgs {
     float* out;         // [NST][NRT][256] or null (last hidden layer)
     const float* W3P;   // [NRT][2][256] or null
     float* P;           // [NST][NRT][2][256] partial products of the final Linear
-    int NRT, NST, npf;
-    PfDesc pf;
+    int NRT, NST;
 };
 
 template <int KPW, int NS>
 __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
     __shared__ v4f red[8][NS][64];
-    if ((int)blockIdx.x < a.npf) { prefetch_wg(a.pf); return; }
     constexpr int HB = 8 * KPW;
-    const int id = blockIdx.x - a.npf;
-    const int sg = id / a.NRT, rt = id - sg * a.NRT, st0 = sg * NS;
+    // Workgroup b runs on XCD b % 8 (speed only).  XCDs 0-3 take the s-net's row tiles, 4-7 the t-net's: an XCD's L2 then
+    // fetches the activations of ONE net (its workgroups read nothing else) and every weight tile exactly once.
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int net = xcd >> 2;
+    const int sg = slot / (HB / 4), rt = net * HB + (xcd & 3) + 4 * (slot - sg * (HB / 4)), st0 = sg * NS;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int net = rt / HB;
     // operand requests: this wave's K slice (k16 blocks w*KPW ...) of the weight tile row and of NS activation tiles
     v4f A[KPW], Bv[NS][KPW];
     const float* wp = a.WT + ((size_t)rt * HB + w * KPW) * 256 + lane * 4;
@@ -228,8 +187,6 @@ struct TailTileArgs {
     const float* W0T;   // [NRT][2][256]
     const float* pre;   // [NST][NRT][256]
     float* h0;          // [NST][NRT][256]
-    int npf;
-    PfDesc pf;
 };
 
 __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
@@ -239,8 +196,7 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
     __shared__ float ld[2][16];
     __shared__ float anl[64], ans[64];
     __shared__ int sidx[64];
-    if ((int)blockIdx.x < a.npf) { prefetch_wg(a.pf); return; }
-    const int id = blockIdx.x - a.npf;
+    const int id = blockIdx.x;
     // all row groups of a sample tile on one XCD (they sum the same 2 x 32 partial tiles)
     const int st = (id >> 6) * 8 + (id & 7), rq = (id >> 3) & 7;
     if (st >= a.NST) return;
@@ -361,7 +317,7 @@ __global__ void flow_set_io_kernel(FlowIo* dst, FlowIo v) { *dst = v; }
 
 template <int KPW>
 void launch_hid(const HidTileArgs& a, int ns, int groups, hipStream_t st) {
-    const dim3 grid(a.npf + a.NRT * groups), block(512);
+    const dim3 grid(a.NRT * groups), block(512);
     if (ns == 1) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 1>), grid, block, 0, st, a);
     else if (ns == 2) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 4>), grid, block, 0, st, a);
@@ -436,7 +392,6 @@ FlowTileWs flow_tile_ws(const FlowTilePack& p, int B) {
     L.hA = take(NST * p.NRT * 1024);
     L.hB = take(NST * p.NRT * 1024);
     L.P = take(NST * p.NRT * 2 * 1024);
-    L.sink = take(256);
     L.total = o;
     return L;
 }
@@ -460,13 +415,10 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     float* hA = reinterpret_cast<float*>(ws + L.hA);
     float* hB = reinterpret_cast<float*>(ws + L.hB);
     float* P = reinterpret_cast<float*>(ws + L.P);
-    float* sink = reinterpret_cast<float*>(ws + L.sink);
     const FlowIo* io = p.io.as<FlowIo>();
-    const int npf = env_int("I2V_FLOW_PF", 0) ? NPF : 0;
     int ns = NST <= 4 ? 1 : NST <= 8 ? 2 : 4;   // sample tiles per hidden-layer workgroup: keep ~256 workgroups
     if (const int e = env_int("I2V_FLOW_NS", 0)) ns = e >= 4 ? 4 : e >= 2 ? 2 : 1;
     const int groups = (NST + ns - 1) / ns;
-    const bool samew = env_int("I2V_FLOW_SAMEW", 0) != 0;  // TIMING EXPERIMENT ONLY (wrong results): every layer reads step 0's weights
 
     {   // embedding part of every first layer of the pass
         PreTileArgs a{};
@@ -475,23 +427,6 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
         hipLaunchKernelGGL(flow_pre_tile_kernel, dim3(a.nblk * ((NST + PRE_SC - 1) / PRE_SC)), dim3(512), 0, st, a);
         I2V_HIP_CHECK(hipGetLastError());
     }
-    // what a launch reads that does not depend on the chain -> prefetch descriptor for the launch in front of it
-    auto pf_for_hidden = [&](int step, int d) {
-        PfDesc f{};
-        f.sink = sink;
-        f.seg[0] = PfSeg{reinterpret_cast<const char*>(p.WT.as<float>() + ((size_t)step * D + d) * NRT * HB * 256), (unsigned)HB * 1024u, NRT, 0, 0};
-        if (d == D - 1) f.seg[1] = PfSeg{reinterpret_cast<const char*>(p.W3P.as<float>() + (size_t)step * NRT * 512), 2048u, NRT, 0, 0};
-        return f;
-    };
-    auto pf_for_tail = [&](int next_step) {   // the tail launch that evaluates the first layer of `next_step`
-        PfDesc f{};
-        f.sink = sink;
-        if (next_step < 0) return f;
-        if (!c.step_cond[next_step])
-            f.seg[0] = PfSeg{reinterpret_cast<const char*>(p.W0T.as<float>() + (size_t)next_step * NRT * 512), (unsigned)NRT * 2048u, 1, 1, NST < 8 ? NST : 8};
-        f.seg[1] = PfSeg{reinterpret_cast<const char*>(pre + (size_t)next_step * NST * NRT * 256), (unsigned)NRT * 1024u, NST, 0, 0};
-        return f;
-    };
     auto step_of = [&](int it) {  // forward visits (fl, i) = (0,0),(0,1),(1,0)...; reverse visits (nf-1,1),(nf-1,0),(nf-2,1)...
         const int fl = reverse ? nf - 1 - it / 2 : it / 2;
         const int i = reverse ? 1 - it % 2 : it % 2;
@@ -515,12 +450,8 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
             t.W0T = p.W0T.as<float>() + (size_t)next_step * NRT * 512;
             t.pre = pre + (size_t)next_step * NST * NRT * 256;
             t.h0 = hA;
-            t.pf = pf_for_hidden(next_step, 0);
-        } else {
-            t.pf.sink = sink;
         }
-        t.npf = (npf && next_step >= 0) ? npf : 0;
-        hipLaunchKernelGGL(flow_tail_tile_kernel, dim3(t.npf + (NST + 7) / 8 * 64), dim3(512), 0, st, t);
+        hipLaunchKernelGGL(flow_tail_tile_kernel, dim3((NST + 7) / 8 * 64), dim3(512), 0, st, t);
         I2V_HIP_CHECK(hipGetLastError());
         return I2V_OK;
     };
@@ -538,14 +469,13 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
         float* nxt = hB;
         for (int d = 0; d < D; ++d) {
             HidTileArgs m{};
-            m.WT = p.WT.as<float>() + (samew ? 0 : ((size_t)step * D + d) * NRT * HB * 256);
+            m.WT = p.WT.as<float>() + ((size_t)step * D + d) * NRT * HB * 256;
             m.bias = c.bmid + ((size_t)step * D + d) * N2;
             m.in = cur;
             m.out = d == D - 1 ? nullptr : nxt;
             m.W3P = d == D - 1 ? p.W3P.as<float>() + (size_t)step * NRT * 512 : nullptr;
             m.P = P;
-            m.NRT = NRT; m.NST = NST; m.npf = npf;
-            m.pf = d == D - 1 ? pf_for_tail(next_step) : pf_for_hidden(step, d + 1);
+            m.NRT = NRT; m.NST = NST;
             switch (HB / 8) {
                 case 1: launch_hid<1>(m, ns, groups, st); break;
                 case 2: launch_hid<2>(m, ns, groups, st); break;

@@ -29,7 +29,7 @@ def one_pass(outdir, counter, extra, parse_only):
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
-            k = r["Kernel_Name"].replace("void ", "").split("(")[0]
+            k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             if "conv_mfma_f16x3_kernel" in k:
                 conv16.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                 continue
