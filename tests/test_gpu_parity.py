@@ -582,7 +582,7 @@ def _range_sweep(exps):
     kernel) whose conv_1 OPERANDS are scaled by s = 2**k exactly: ADAIN's Linear (weight and bias -> gamma, beta) is
     multiplied by s, so lrelu(gamma * norm + beta) -- the tensor that is split into fp16 hi / lo parts and Winograd-
     transformed -- and with it the conv output scale by s; the input x of the identity shortcut is scaled by s too, so the
-    whole block output is s times the unscaled one and rel-L2 stays meaningful.  (SPADE's (1 + gamma) pins conv_0's
+    whole block output is s times the unscaled one (conv_1's bias is set to zero) and rel-L2 stays meaningful.  (SPADE's (1 + gamma) pins conv_0's
     operands at O(1); conv_0 and conv_1 run the same kernel.)  Returns [(k, rel-L2 vs the oracle, range flag)]."""
     from oracle import decoder_ref
     from stage1_VAE.modules import decoder as dec
@@ -597,6 +597,7 @@ def _range_sweep(exps):
         sd = dict(base)
         for key in ("g_0.norm_1.linear.weight", "g_0.norm_1.linear.bias"):
             sd[key] = base[key] * s
+        sd["g_0.conv_1.bias"] = torch.zeros_like(base["g_0.conv_1.bias"])   # (an unscaled bias would swamp the conv term at small s)
         blk = dec.GeneratorBlock(128, 128, True, 64)
         blk.load_state_dict(sub(sd, "g_0."))
         blk = blk.cuda().eval()
