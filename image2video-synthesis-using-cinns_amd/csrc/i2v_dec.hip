@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
     // so that every store instruction of a wave writes 16 whole rows = 1 KB contiguous.
     const int per = H * J * C8 * 2;  // threads per sample (a multiple of 64: whole waves stay active for the shuffles)
     const int Hl = H / us, Wl = W / us, Tl = T / ut;
-    const float2* cp0 = coef + (long)b * C;
+    const float2* cp0 = coef ? coef + (long)b * C : nullptr;   // null: identity (the kernel then only formats the operand)
     const float* xb = x + (long)b * Tl * Hl * Wl * C;
     const float* gbb = gb ? gb + (long)b * H * W * 2 * C : nullptr;
     const int nchunk = C >> 4;
@@ -242,13 +242,16 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
         const int c8 = chunk * 2 + (p >> 1);
         const bool is_lo = p & 1;
         float ca[8], cb[8];
-        {
+        if (cp0) {
             const float4* cp = reinterpret_cast<const float4*>(cp0 + 8 * c8);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float4 ab = cp[k];
                 ca[2 * k] = ab.x; cb[2 * k] = ab.y; ca[2 * k + 1] = ab.z; cb[2 * k + 1] = ab.w;
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
         }
         // own positions w = 2j, 2j + 1; the outer neighbours 2j - 1 / 2j + 2 come from lane -+ 4 unless this pair opens /
         // closes the wave's segment (then they are evaluated here) or the row (then they are 0: the conv's zero padding)
@@ -410,6 +413,7 @@ struct Block {
     Conv16Weights sp_conv16;  // SPADE's Conv2d(3, 128, 3) with the 3 input channels zero-padded to 8 (split-fp16 mode)
     Conv16Weights conv0_16, conv1_16, sp_gb16;  // split-fp16 variants (cfg.mma == 1)
     Conv16Weights convs16;      // the learned shortcut's 1x1x1 conv on split-fp16 operands (pointwise16_forward)
+    Wino16Weights sp_gb_w;      // SPADE's fused gamma|beta Conv2d(128, 2C, 3) on the Winograd kernel (1x3x3 variant)
     Wino16Weights conv0_w, conv1_w;             // Winograd F(2,3) variants of conv_0 / conv_1 (packed where the shape allows)
     bool tdup0 = false;                          // conv_0 runs on the half-rate tensor (x2 temporal up-sampling in front)
     DevBuf gn_w, gn_b;
@@ -433,6 +437,7 @@ struct i2v_dec {
     int Nz = 0;
     int wino = 1;  // 1: 3x3x3 convs whose shape allows it use the Winograd kernel (env I2V_DEC_WINO=0 disables)
     int img16 = 1;  // 1: split-fp16 mode runs conv_img as 1x1x1 GEMM + gather (env I2V_DEC_IMG16=0: vector-ALU kernel)
+    int spw = 1;   // 1: SPADE's gamma|beta conv uses the Winograd kernel where the shape allows (env I2V_DEC_SPW=0: direct kernel)
     int pw16 = 1;  // 1: split-fp16 mode runs the shortcut convs on split-fp16 operands too (env I2V_DEC_PW16=0: exact-fp32 MFMA)
     int device = 0;             // the device the packed weights live on
     int* status_dev = nullptr;  // sticky range flag of the hl16 producers (device) ...
@@ -459,7 +464,7 @@ struct i2v_dec {
 namespace {
 
 struct DecWs {
-    size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, splitk, splitk_floats, total;
+    size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, splitk, splitk_floats, y1v, total;
 };
 
 bool want_wino0(const i2v_dec* d, const Block& b, const Level& l);
@@ -490,6 +495,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
     L.a = take(B * mx_a); L.dx = take(B * mx_dx);
     L.xs_in = take(B * mx_xsin); L.xs_low = take(B * mx_xslow);
     L.y0 = take(B * mx_y * 16); L.y1 = take(B * mx_y * 128); L.gb = take(B * mx_gb);
+    L.y1v = take(B * mx_y * 256);   // Winograd operand V of SPADE's 128-channel activation (8 bytes per activation)
     L.zl = take((size_t)B * d->Nz);
     L.sums1 = take((size_t)B * cmax * 4); L.sums2 = take((size_t)B * cmax * 4);  // doubles: 2 per channel
     L.coef = take((size_t)B * cmax * 2);
@@ -642,6 +648,7 @@ struct BlockBufs {
     double *sums1, *sums2;
     float* splitk = nullptr;      // split-K scratch of conv16_forward (optional)
     size_t splitk_floats = 0;
+    float* y1v = nullptr;         // Winograd operand of SPADE's 128-channel activation (2 x the size of y1; optional)
 };
 
 // One GeneratorBlock (decoder.py:33-52) on channels-last tensors: x [B][T/ut][H/us][W/us][n_in] -> xn [B][T][H][W][n_out].
@@ -669,7 +676,13 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
                            B, img_h, img_w, l.H, l.W, d->cfg.mma == 1 ? 1 : 0, d->status_dev);
         I2V_HIP_CHECK(hipGetLastError());
     }
-    if (d->cfg.mma == 1) {
+    if (d->cfg.mma == 1 && b.sp_gb_w.w.p && w.y1v) {
+        // gamma | beta conv on the Winograd kernel: the 128-channel activation goes through fp32 once more (the operand
+        // writer needs the w-neighbours of every position, which the producing conv's epilogue does not hold)
+        if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
+        if ((rc = run_modulate_wino(y1, nullptr, nullptr, w.y1v, B, 1, l.H, l.W, 128, 1, 1, 0, st, d->status_dev))) return rc;
+        if ((rc = wino16_forward(b.sp_gb_w, w.y1v, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st, nullptr))) return rc;
+    } else if (d->cfg.mma == 1) {
         if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st, nullptr, d->status_dev)))
             return rc;
         if ((rc = conv16_forward(b.sp_gb16, y1, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
@@ -834,6 +847,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     if (const char* e = std::getenv("I2V_DEC_WINO")) d->wino = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_PW16")) d->pw16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
     if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
     const char* names[6] = {"head_0", "g_0", "g_1", "g_2", "g_3", "g_4"};
@@ -935,6 +949,9 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         if (d->cfg.mma == 1) rc = b.sp_gb16.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
         else rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
         if (rc) return rc;
+        if (d->cfg.mma == 1 && d->wino && d->spw && wino16_supported(2 * b.n_in, 128, 1, d->lvl[k].H, d->lvl[k].W, 1) &&
+            (rc = b.sp_gb_w.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 1.0)))
+            return rc;
         // ADAIN linear rows into the shared z-GEMM
         const float* lw = sd.f32(p + "norm_1.linear.weight", (int64_t)2 * b.n_mid * zd);
         const float* lb = sd.f32(p + "norm_1.linear.bias", (int64_t)2 * b.n_mid);
@@ -1072,7 +1089,7 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     float* x = xA;
     float* xn = xB;
     bool x_stats_ready = false;
-    BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, sums1, sums2, F(L.splitk), L.splitk_floats};
+    BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, sums1, sums2, F(L.splitk), L.splitk_floats, F(L.y1v)};
     for (int k = 0; k < 6; ++k) {
         if ((rc = block_forward(d, k, d->blk[k], d->lvl[k], x, xn, img, img_h, img_w, zl, d->Nz, B, bufs, x_stats_ready, k == 5, st)))
             return rc;
