@@ -112,6 +112,24 @@ bool wino16_supported(int cout, int cin, int T, int H, int W, int KT = 3);
 int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T,
                    int H, int W, int epi, hipStream_t st, double* stats = nullptr);
 
+// ---- split-fp16 Winograd F(4,3) along W (i2v_conv16w4.hip): 6 GEMMs per 4 output positions (0.75x the MFMAs of F(2,3)).
+// Input: V = B^T d in hl16 format, [B][T][Cin/16][6][H][W/4][16 channels = 64 B] (modulate_wino4_kernel).
+struct Wino4Weights {
+    DevBuf w;      // U = G g: [parity][tap (kt,kh)][chunk16][6][CoutPad/32][hi | lo][64 lanes][16 B]
+    DevBuf bias;
+    int Cin = 0, Cout = 0, CoutPad = 0, nchunk = 0;
+    int KT = 3;    // temporal taps: 3, or 2 for the temporal-duplication pair
+    int wexp = 0;
+    bool tdup = false;
+    long set_bytes = 0;
+    int pack(const float* w_src, const float* bias_src, int cout, int cin, double scale);       // w_src [Cout][Cin][3][3][3]
+    int pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale);  // from a 3x3x3 kernel
+};
+// T = frames of the tensor V was built from (half the output frames for pack_tdup weights); false = use another kernel
+bool wino4_supported(int cout, int cin, int T, int H, int W, int KT);
+int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T,
+                  int H, int W, int epi, hipStream_t st, double* stats = nullptr);
+
 // ---- helpers implemented in i2v_dec.hip, shared with the embedder (i2v_embed.hip)
 // per-(b,c) sum / sum of squares (fp64) of a channels-last tensor [B][P][C]
 int stats_forward(const float* x, double* sums, int B, long P, int C, hipStream_t st);

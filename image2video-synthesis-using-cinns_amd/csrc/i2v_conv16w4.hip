@@ -1,0 +1,588 @@
+// 3x3x3 Conv3d with a Winograd F(4,3) transform along W on the gfx950 fp16 matrix cores (split-fp16 operands).
+//
+// F(2,3) (i2v_conv16w.hip) multiplies 4 transformed planes per 2 outputs; F(4,3) multiplies 6 per 4: 0.75x the MFMAs and a
+// V operand of 12 instead of 16 bytes per activation.  Per tile of four output positions (w = 4j .. 4j+3) and (kt, kh) tap
+//     d_k = a[t+kt-1][h+kh-1][4j-1+k], k = 0..5 (zero padded)
+//     V0 = 4 d0 - 5 d2 + d4        V1 = -4 d1 - 4 d2 + d3 + d4     V2 = 4 d1 - 4 d2 - d3 + d4
+//     V3 = -2 d1 - d2 + 2 d3 + d4  V4 = 2 d1 - d2 - 2 d3 + d4      V5 = 4 d1 - 5 d3 + d5
+//     U0 = g0/4   U1 = -(g0+g1+g2)/6   U2 = -(g0-g1+g2)/6   U3 = g0/24 + g1/12 + g2/6   U4 = g0/24 - g1/12 + g2/6   U5 = g2
+//     M_x = sum over (kt, kh, c) of V_x U_x
+//     y0 = M0+M1+M2+M3+M4   y1 = M1-M2+2M3-2M4   y2 = M1+M2+4M3+4M4   y3 = M1-M2+8M3-8M4+M5
+// V = B^T d is written once by the producer (modulate_wino4_kernel, fp32 then split into fp16 hi / lo) as
+// [B][T][C/16][6][H][W/4][16 channels = 64 B]; U = G g is computed in fp64 at load time.
+//
+// What shapes the kernel: 160 KB of LDS and the weight (B-operand) traffic.  A wave must multiply ONE weight fragment with
+// 128 tiles (4 MFMA row blocks) -- at 64 tiles the weight stream from L2 doubles per MFMA, which is what holds the
+// 32-channel variant of the F(2,3) kernel at 60 % of the 64-channel one -- and the double-buffered halo brick of SIX planes
+// of 128 tiles would need 184 KB.  So the six planes are multiplied in TWO passes over the K loop with the accumulators of
+// both passes kept in registers:
+//   pass A  planes 0..3: exactly the loop of the F(2,3) kernel (wave = (plane, 32-channel half), 4 row blocks, 64
+//           accumulator registers, nine-slot weight ring, V brick of 4 planes double-buffered by LDS-DMA);
+//   pass B  planes 4, 5: wave = (plane, 32-channel half, tile half), 2 row blocks, 32 more accumulator registers, V brick of
+//           2 planes (this third of the MFMAs sees the doubled weight stream);
+//   epilogue: per 32-channel half the six partial GEMMs of a tile meet in LDS (98 KB), y = A^T M in fp32, then bias,
+//           residual, optional lrelu, fused per-(b,c) statistics, stores of four positions per tile.
+// Workgroup = 512 threads, 128 tiles = 512 output positions (TT x TH x 16 brick) x 64 output channels.
+// Loads are asm statements with hand-counted waits exactly as in i2v_conv16w.hip (tools/check_asm_waits.py replays both
+// compiled loops of every instantiation).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "i2v_conv.h"
+
+namespace i2v {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
+constexpr int W4_KC = 16;       // input channels per K chunk
+constexpr int W4_ROWS_A = 1024; // staged V rows per buffer, pass A (4 planes); pass B stages 512 (2 planes)
+
+struct W4Args {
+    const char* in;     // V: hl16 [B][T][Cin/16][6][H][J][64 B], J = W / 4
+    const char* zeros;  // >= 64 zero bytes
+    const char* wp;     // U: [parity][tap][chunk][6][CoutPad/32][hi | lo][64 lanes][16 B]
+    const float* bias;
+    const float* res;
+    float* out;         // fp32 channels-last [B][To][H][W][Cout]
+    double* stats;
+    int B, T, H, W, J, Cin, Cout, CoutPad, nchunk;   // T = frames of the INPUT tensor
+    int tdup;
+    long wset_stride;
+    int TT, TH, TJ, nbT, nbH, nbJ;
+    int rt, rs, epi;
+    float oscale;
+    int tofs;           // LDS byte offset of the index tables
+};
+
+constexpr int w4_count(int t, int R, int NT, int h) {
+    int n = 0;
+    for (int k = 0; k < R; ++k) n += ((t - k - h) % NT + NT) % NT == 0;
+    return n;
+}
+
+// One pass of the K loop over NPL = VH planes... (VH = 16-byte V pieces per thread and half-request: 4 -> 1024 staged rows =
+// four planes, 2 -> 512 rows = two planes).  WM = MFMA row blocks of this wave.  arow[wm]: LDS row of the lane's tile (tap
+// (0,0)) inside the pass's brick; gpos: global V row (chunk 0) of every staged row, -1 = zero padding; wlane: this wave's
+// weight fragments (tap 0, chunk 0).
+template <int NT, int WM, int VH>
+__device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* gpos, f32x16 (&acc)[WM], int (&arow)[WM],
+                                        const char* wlane, int HH, int tid, int lane, int wave) {
+    constexpr int VROWS = VH * 2 * 128;
+    const int kg = lane >> 5;
+    char* v_lds = smem;
+    const long cstride = (long)a.CoutPad * 384;          // bytes per (tap, chunk): 6 planes x CoutPad x 64
+    const long wtap_stride = (long)a.nchunk * cstride;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+    const int* gq = gpos + (tid >> 2);
+    const long vpiece = (long)((tid & 3) ^ ((tid >> 4) & 3)) * 16;
+    const long vchunk = (long)6 * a.H * a.J * 64;        // bytes between the K chunks of one frame
+#define W4_GLDS(src_, dst_)                                                                                          \
+    {                                                                                                                \
+        unsigned keep_;                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                              \
+    }
+#define W4_REQUEST_V(ch_, VB, HF)                                                                                    \
+    {                                                                                                                \
+        int gp_[VH];                                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < VH; ++u) gp_[u] = gq[128 * (VH * (HF) + u)];                           \
+        const char* vb_ = a.in + (long)(ch_) * vchunk + vpiece;                                                      \
+        _Pragma("unroll") for (int u = 0; u < VH; ++u) {                                                             \
+            const char* s_ = gp_[u] >= 0 ? vb_ + (long)gp_[u] * 64 : a.zeros;                                        \
+            W4_GLDS(s_, vdst + (unsigned)((VB) * (VROWS * 64) + (VH * (HF) + u) * 8192))                             \
+        }                                                                                                            \
+    }
+    struct AOps { half8 ah[WM], al[WM]; };
+    struct BOps { half8 bh, bl; };
+    AOps a0, a1;
+    constexpr int R = NT == 9 ? 9 : 6;
+    BOps bq0, bq1, bq2, bq3, bq4, bq5, bq6, bq7, bq8;
+#define W4_LOAD_A(o, TAP, VB)                                                                                        \
+    {                                                                                                                \
+        const int d_ = (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * VROWS;                                       \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+            const int r_ = arow[wm] + d_;                                                                            \
+            const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                        \
+            (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                               \
+            (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                        \
+        }                                                                                                            \
+    }
+#define W4_REQUEST_B(q, TAP, CH)                                                                                     \
+    {                                                                                                                \
+        const int c_ = (CH) < a.nchunk ? (CH) : a.nchunk - 1;                                                        \
+        const char* p_ = wlane + (long)(TAP) * wtap_stride + (long)c_ * cstride;                                     \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"((q).bh) : "v"(p_));                                   \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=&v"((q).bl) : "v"(p_));                       \
+    }
+#define W4_WAIT_B(q, N) asm volatile("s_waitcnt vmcnt(%2)" : "+v"((q).bh), "+v"((q).bl) : "n"(N));
+#define W4_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#define W4_MFMA(o, q)                                                                                                \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+    }
+
+    __syncthreads();  // tables written / the previous pass has left LDS
+    W4_REQUEST_V(0, 0, 0)
+    W4_REQUEST_V(0, 0, 1)
+    W4_REQUEST_B(bq0, 0 % NT, 0 / NT)
+    W4_REQUEST_B(bq1, 1 % NT, 1 / NT)
+    W4_REQUEST_B(bq2, 2 % NT, 2 / NT)
+    W4_REQUEST_B(bq3, 3 % NT, 3 / NT)
+    W4_REQUEST_B(bq4, 4 % NT, 4 / NT)
+    if constexpr (R == 9) {
+        W4_REQUEST_B(bq5, 5 % NT, 5 / NT)
+        W4_REQUEST_B(bq6, 6 % NT, 6 / NT)
+        W4_REQUEST_B(bq7, 7 % NT, 7 / NT)
+    }
+    W4_WAIT_VM(2 * (R - 1))   // the V brick of chunk 0 (the B loads behind it stay in flight)
+    __syncthreads();
+    W4_LOAD_A(a0, 0, 0)
+
+    // Tap U of a chunk pair: see i2v_conv16w.hip.  Younger than B(U): the B requests of taps U-R+2 .. U (2 (R-1) loads) and
+    // the V half-requests (VH loads each) of every chunk's taps 0 and 1 among taps U-(R-1) .. U.
+#define W4_TAP(U, ACUR, ANXT, BCUR, BREQ)                                                                            \
+    {                                                                                                                \
+        constexpr int cp_ = (U) / NT, t_ = (U) % NT;                                                                 \
+        constexpr int un_ = (U) + R - 1, cn_ = un_ / NT, tn_ = un_ % NT;                                             \
+        constexpr int ng_ = w4_count(t_, R, NT, 0) + w4_count(t_, R, NT, 1 % NT);                                    \
+        constexpr int nb_ = 2 * (R - 1) + VH * ng_;                                                                  \
+        asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[WM - 2]), "+v"(arow[WM - 1]));                     \
+        W4_REQUEST_B(BREQ, tn_, ch + cn_)                                                                            \
+        if constexpr (t_ < 2)                                                                                        \
+            W4_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_, 1 - cp_, t_)                             \
+        if constexpr (t_ < NT - 1) {                                                                                 \
+            W4_LOAD_A(ANXT, t_ + 1, cp_)                                                                             \
+        } else {                                                                                                     \
+            W4_WAIT_VM(2 * (NT - 2))                                                                                 \
+            __syncthreads();                                                                                         \
+            W4_LOAD_A(ANXT, 0, 1 - cp_)                                                                              \
+        }                                                                                                            \
+        W4_WAIT_B(BCUR, nb_)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        W4_MFMA(ACUR, BCUR)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+#define W4_TAP6(U0)                                                                                                  \
+    {                                                                                                                \
+        W4_TAP((U0) + 0, a0, a1, bq0, bq5)                                                                           \
+        W4_TAP((U0) + 1, a1, a0, bq1, bq0)                                                                           \
+        W4_TAP((U0) + 2, a0, a1, bq2, bq1)                                                                           \
+        W4_TAP((U0) + 3, a1, a0, bq3, bq2)                                                                           \
+        W4_TAP((U0) + 4, a0, a1, bq4, bq3)                                                                           \
+        W4_TAP((U0) + 5, a1, a0, bq5, bq4)                                                                           \
+    }
+#define W4_TAP18R9()                                                                                                 \
+    {                                                                                                                \
+        W4_TAP(0, a0, a1, bq0, bq8)                                                                                  \
+        W4_TAP(1, a1, a0, bq1, bq0)                                                                                  \
+        W4_TAP(2, a0, a1, bq2, bq1)                                                                                  \
+        W4_TAP(3, a1, a0, bq3, bq2)                                                                                  \
+        W4_TAP(4, a0, a1, bq4, bq3)                                                                                  \
+        W4_TAP(5, a1, a0, bq5, bq4)                                                                                  \
+        W4_TAP(6, a0, a1, bq6, bq5)                                                                                  \
+        W4_TAP(7, a1, a0, bq7, bq6)                                                                                  \
+        W4_TAP(8, a0, a1, bq8, bq7)                                                                                  \
+        W4_TAP(9, a1, a0, bq0, bq8)                                                                                  \
+        W4_TAP(10, a0, a1, bq1, bq0)                                                                                 \
+        W4_TAP(11, a1, a0, bq2, bq1)                                                                                 \
+        W4_TAP(12, a0, a1, bq3, bq2)                                                                                 \
+        W4_TAP(13, a1, a0, bq4, bq3)                                                                                 \
+        W4_TAP(14, a0, a1, bq5, bq4)                                                                                 \
+        W4_TAP(15, a1, a0, bq6, bq5)                                                                                 \
+        W4_TAP(16, a0, a1, bq7, bq6)                                                                                 \
+        W4_TAP(17, a1, a0, bq8, bq7)                                                                                 \
+    }
+    for (int ch = 0; ch < a.nchunk; ch += 2) {
+        if constexpr (R == 9) {
+            W4_TAP18R9()
+        } else {
+            W4_TAP6(0)
+            if constexpr (NT >= 6) W4_TAP6(6)
+        }
+    }
+    // the stream's harmless last requests (LDS-DMA included) must land before LDS and the ring's registers are reused
+    if constexpr (R == 9) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
+                       "+v"(bq3.bl), "+v"(bq4.bh), "+v"(bq4.bl), "+v"(bq5.bh), "+v"(bq5.bl), "+v"(bq6.bh), "+v"(bq6.bl),
+                       "+v"(bq7.bh), "+v"(bq7.bl), "+v"(bq8.bh), "+v"(bq8.bl)
+                     :
+                     : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
+                       "+v"(bq3.bl), "+v"(bq4.bh), "+v"(bq4.bl), "+v"(bq5.bh), "+v"(bq5.bl)
+                     :
+                     : "memory");
+    }
+#undef W4_GLDS
+#undef W4_REQUEST_V
+#undef W4_LOAD_A
+#undef W4_REQUEST_B
+#undef W4_WAIT_B
+#undef W4_WAIT_VM
+#undef W4_MFMA
+#undef W4_TAP
+#undef W4_TAP6
+#undef W4_TAP18R9
+}
+
+// NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3)
+template <int NT>
+__global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
+    constexpr int KT = NT / 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = lane >> 5, l31 = lane & 31;
+
+    // tile order and the XCDs: as in i2v_conv16w.hip (all workgroups reading the same V brick on one XCD, consecutively)
+    const int nNt = a.CoutPad / 64;
+    const int npar = a.tdup ? 2 : 1;
+    const int per_brick = nNt * npar;
+    const int nbrick = (int)(gridDim.x / per_brick);
+    int par, tile_id;
+    if ((nbrick & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int sub = slot % per_brick, brick_ = (slot / per_brick) * 8 + xcd;
+        par = a.tdup ? sub & 1 : 0;
+        tile_id = brick_ * nNt + (a.tdup ? sub >> 1 : sub);
+    } else {
+        par = a.tdup ? (int)(blockIdx.x >= (gridDim.x >> 1)) : 0;
+        tile_id = a.tdup ? (int)(blockIdx.x % (gridDim.x >> 1)) : (int)blockIdx.x;
+    }
+    const int pt = a.tdup ? 1 - par : KT / 2;
+    const int HT = a.TT + KT - 1, HH = a.TH + 2;
+    const int plane = HT * HH * a.TJ;
+
+    int* gposA = reinterpret_cast<int*>(smem + a.tofs);   // [1024] planes 0..3
+    int* gposB = gposA + W4_ROWS_A;                       // [512]  planes 4, 5
+    int* tpos = gposB + W4_ROWS_A / 2;                    // [128] output position of a tile's first column
+    int* tres = tpos + W4_TILES;                          // [128][4] residual rows of the tile's four columns
+
+    const int ntile = tile_id % nNt;
+    int brick = tile_id / nNt;
+    const int bj = brick % a.nbJ; brick /= a.nbJ;
+    const int bh = brick % a.nbH; brick /= a.nbH;
+    const int bt = brick % a.nbT; brick /= a.nbT;
+    const int b0 = brick, t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * a.TJ;
+    const int n0 = ntile * 64;
+
+    if (tid < W4_TILES) {
+        int m = tid;
+        const int ij = m % a.TJ; m /= a.TJ;
+        const int ih = m % a.TH; m /= a.TH;
+        const int t = t0 + m, h = h0 + ih, w = 4 * (j0 + ij);
+        const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + par : t;
+        tpos[tid] = ((b0 * To + to) * a.H + h) * a.W + w;
+        const int rbase = ((b0 * (To / a.rt) + to / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tres[4 * tid + c] = rbase + (w + c) / a.rs;
+    }
+    for (int r = tid; r < W4_ROWS_A + W4_ROWS_A / 2; r += 512) {
+        const bool pb = r >= W4_ROWS_A;                 // row of pass B's brick
+        const int rr = pb ? r - W4_ROWS_A : r;
+        const int x = rr / plane;
+        int q = rr - x * plane;
+        const int ij = q % a.TJ; q /= a.TJ;
+        const int ih = q % HH; q /= HH;
+        const int t = t0 + q - pt, h = h0 + ih - 1, j = j0 + ij;
+        const bool ok = x < (pb ? 2 : 4) && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H;
+        const int xg = pb ? 4 + x : x;
+        (pb ? gposB : gposA)[rr] = ok ? ((((b0 * a.T + t) * a.nchunk * 6 + xg) * a.H + h) * a.J + j) : -1;  // chunk 0; 64-byte rows
+    }
+    const char* wbase = a.wp + (long)par * a.wset_stride + lane * 16;
+    const int nblk = a.CoutPad >> 5;
+
+    // ---- pass A: planes 0..3, wave = (plane, 32-channel half), all 128 tiles
+    const int xa = wave & 3, nha = wave >> 2;
+    f32x16 accA[4];
+    {
+        int arow[4];
+#pragma unroll
+        for (int wm = 0; wm < 4; ++wm) {
+            int m = wm * 32 + l31;
+            const int ij = m % a.TJ; m /= a.TJ;
+            const int ih = m % a.TH; m /= a.TH;
+            arow[wm] = xa * plane + (m * HH + ih) * a.TJ + ij;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
+        }
+        w4_pass<NT, 4, 4>(a, smem, gposA, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid, lane, wave);
+    }
+    // ---- pass B: planes 4, 5, wave = (plane, 32-channel half, tile half)
+    const int xb = wave & 1, nhb = (wave >> 1) & 1, mhb = wave >> 2;
+    f32x16 accB[2];
+    {
+        int arow[2];
+#pragma unroll
+        for (int wm = 0; wm < 2; ++wm) {
+            int m = mhb * 64 + wm * 32 + l31;
+            const int ij = m % a.TJ; m /= a.TJ;
+            const int ih = m % a.TH; m /= a.TH;
+            arow[wm] = xb * plane + (m * HH + ih) * a.TJ + ij;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[wm][r] = 0.f;
+        }
+        w4_pass<NT, 2, 2>(a, smem, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid, lane, wave);
+    }
+
+    // ---- epilogue, one 32-channel half at a time: E = [6 planes][128 tiles][32 channels] fp32 (98 KB)
+    constexpr int NQ = 8, TPI = 64, NIT = 2;
+    float* E = reinterpret_cast<float*>(smem);
+    double* S = reinterpret_cast<double*>(smem + 6 * W4_TILES * 32 * 4);   // [8 waves][32 channels][2] behind E
+    const int n4 = tid % NQ;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int n = n0 + half * 32 + 4 * n4;
+        const bool ncol = n < a.Cout;
+        // residual rows first, all of them, so that their latency hides behind the LDS exchange
+        f32x4 rres[NIT][4];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                rres[it][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.res && ncol)
+                    rres[it][c] = *reinterpret_cast<const f32x4*>(a.res + (long)tres[4 * (tid / NQ + TPI * it) + c] * a.Cout + n);
+            }
+        __syncthreads();   // the V bricks / the previous half's E are no longer read
+        if (nha == half) {
+#pragma unroll
+            for (int wm = 0; wm < 4; ++wm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    E[(xa * W4_TILES + m) * 32 + l31] = accA[wm][r];
+                }
+        }
+        if (nhb == half) {
+#pragma unroll
+            for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mhb * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    E[((4 + xb) * W4_TILES + m) * 32 + l31] = accB[wm][r];
+                }
+        }
+        __syncthreads();
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias && ncol) bias = *reinterpret_cast<const float4*>(a.bias + n);
+        const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
+        double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int tile = tid / NQ + TPI * it;
+            float mx[6][4];
+#pragma unroll
+            for (int x = 0; x < 6; ++x) {
+                const float4 v = *reinterpret_cast<const float4*>(E + (x * W4_TILES + tile) * 32 + 4 * n4);
+                mx[x][0] = v.x; mx[x][1] = v.y; mx[x][2] = v.z; mx[x][3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s12 = mx[1][j] + mx[2][j], d12 = mx[1][j] - mx[2][j];
+                const float s34 = mx[3][j] + mx[4][j], d34 = mx[3][j] - mx[4][j];
+                const float y[4] = {mx[0][j] + s12 + s34, fmaf(2.f, d34, d12), fmaf(4.f, s34, s12), fmaf(8.f, d34, d12) + mx[5][j]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = fmaf(y[c], a.oscale, bv[j]) + rres[it][c][j];
+                    if (ncol) {
+                        ssum[j] += (double)v;
+                        ssq[j] = fma((double)v, (double)v, ssq[j]);
+                    }
+                    if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
+                    rres[it][c][j] = v;
+                }
+            }
+        }
+        if (ncol) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const long p = tpos[tid / NQ + TPI * it];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.out + (p + c) * a.Cout + n) = rres[it][c];
+            }
+        }
+        if (a.stats) {
+            // lanes of a wave that share (lane % NQ) hold the same four channels -> wavefront shuffles; the eight waves'
+            // partials meet in LDS (behind E) and one wave issues the 2 x 32 fp64 atomics of this channel half
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int off = NQ; off < 64; off <<= 1) {
+                    ssum[j] += __shfl_xor(ssum[j], off);
+                    ssq[j] += __shfl_xor(ssq[j], off);
+                }
+            }
+            if (lane < NQ) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    S[(wave * 32 + 4 * lane + j) * 2] = ssum[j];
+                    S[(wave * 32 + 4 * lane + j) * 2 + 1] = ssq[j];
+                }
+            }
+            __syncthreads();
+            if (wave == 0 && lane < 32 && n0 + half * 32 + lane < a.Cout) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    s0 += S[(w * 32 + lane) * 2];
+                    s1 += S[(w * 32 + lane) * 2 + 1];
+                }
+                double* dst = a.stats + ((long)b0 * a.Cout + n0 + half * 32 + lane) * 2;
+                atomicAdd(dst, s0);
+                atomicAdd(dst + 1, s1);
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+
+// w3: [nset][Cout][Cin][NT][3] (fp64, already scaled); packs U = G g per (kt, kh)
+static int wino4_pack_sets(Wino4Weights& o, const std::vector<double>& w3, int nset, int cout, int cin, int kt) {
+    o.Cin = cin; o.Cout = cout; o.KT = kt;
+    o.CoutPad = (cout + 63) / 64 * 64;
+    o.nchunk = cin / W4_KC;
+    const int NT = kt * 3;
+    std::vector<double> u((size_t)nset * cout * cin * NT * 6);
+    double wmax = 0.0;
+    for (size_t i = 0; i < (size_t)nset * cout * cin * NT; ++i) {
+        const double g0 = w3[i * 3], g1 = w3[i * 3 + 1], g2 = w3[i * 3 + 2];
+        double* d = &u[i * 6];
+        d[0] = g0 / 4.0;
+        d[1] = -(g0 + g1 + g2) / 6.0;
+        d[2] = -(g0 - g1 + g2) / 6.0;
+        d[3] = g0 / 24.0 + g1 / 12.0 + g2 / 6.0;
+        d[4] = g0 / 24.0 - g1 / 12.0 + g2 / 6.0;
+        d[5] = g2;
+        for (int x = 0; x < 6; ++x) wmax = std::max(wmax, std::fabs(d[x]));
+    }
+    o.wexp = 0;
+    if (wmax > 0.0 && std::isfinite(wmax)) o.wexp = std::max(-40, std::min(40, (int)std::floor(std::log2(16384.0 / wmax))));
+    const double pre = std::ldexp(1.0, o.wexp);
+    const size_t set_halfs = (size_t)NT * o.nchunk * 6 * o.CoutPad * 32;
+    std::vector<_Float16> p((size_t)nset * set_halfs, (_Float16)0.f);
+    for (int s = 0; s < nset; ++s)
+        for (int n = 0; n < cout; ++n)
+            for (int c = 0; c < cin; ++c)
+                for (int tap = 0; tap < NT; ++tap)
+                    for (int x = 0; x < 6; ++x) {
+                        const float v = (float)(u[((((size_t)s * cout + n) * cin + c) * NT + tap) * 6 + x] * pre);
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        // fragment-major: [tap][chunk][x][32-channel block][hi | lo][lane = kg * 32 + n % 32][8 halfs]
+                        const int chunk = c / W4_KC, kgq = (c % W4_KC) / 8, j = c % 8;
+                        _Float16* blk = &p[s * set_halfs + ((((size_t)tap * o.nchunk + chunk) * 6 + x) * (o.CoutPad / 32) + n / 32) * 1024];
+                        blk[(kgq * 32 + n % 32) * 8 + j] = hi;
+                        blk[512 + (kgq * 32 + n % 32) * 8 + j] = lo;
+                    }
+    o.set_bytes = (long)set_halfs * 2;
+    return o.w.upload(p.data(), p.size() * 2);
+}
+
+// brick of 128 tiles = TT frames x TH rows x 4 tiles (16 output positions)
+static bool wino4_tiling(int T, int H, int W, int KT, int* TT_, int* TH_) {
+    if (T < 2 || W % 16 || H < 8) return false;
+    int TT = 1;
+    while (TT < 4 && T % (TT * 2) == 0) TT *= 2;
+    const int TH = W4_TILES / (TT * 4);
+    if (TH > H || H % TH || TH * 4 % 32) return false;
+    if (4 * (TT + KT - 1) * (TH + 2) * 4 > W4_ROWS_A) return false;   // pass A's halo brick (pass B: half of it)
+    *TT_ = TT; *TH_ = TH;
+    return true;
+}
+
+bool wino4_supported(int cout, int cin, int T, int H, int W, int KT) {
+    if (cout % 64 || cin % (2 * W4_KC) || (KT != 3 && KT != 2)) return false;
+    int TT, TH;
+    return wino4_tiling(T, H, W, KT, &TT, &TH);
+}
+
+int Wino4Weights::pack(const float* w_src, const float* bias_src, int cout, int cin, double scale) {
+    tdup = false;
+    std::vector<double> w3((size_t)cout * cin * 27);
+    for (size_t i = 0; i < w3.size(); ++i) w3[i] = (double)w_src[i] * scale;
+    int rc = wino4_pack_sets(*this, w3, 1, cout, cin, 3);
+    if (rc) return rc;
+    if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
+    bias.release();
+    return I2V_OK;
+}
+
+int Wino4Weights::pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale) {
+    // parity 0 = (W[0], W[1]+W[2]), parity 1 = (W[0]+W[1], W[2]) along time (see Conv16Weights::pack_tdup)
+    std::vector<double> w3((size_t)2 * cout * cin * 18);
+    for (int par = 0; par < 2; ++par)
+        for (size_t nc = 0; nc < (size_t)cout * cin; ++nc)
+            for (int hw = 0; hw < 9; ++hw) {
+                const double w0 = w_src[nc * 27 + hw], w1 = w_src[nc * 27 + 9 + hw], w2 = w_src[nc * 27 + 18 + hw];
+                double* dst = &w3[((size_t)par * cout * cin + nc) * 18];
+                dst[hw] = (par == 0 ? w0 : w0 + w1) * scale;
+                dst[9 + hw] = (par == 0 ? w1 + w2 : w2) * scale;
+            }
+    tdup = true;
+    int rc = wino4_pack_sets(*this, w3, 2, cout, cin, 2);
+    if (rc) return rc;
+    if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
+    bias.release();
+    return I2V_OK;
+}
+
+template <int NT>
+static int launch_wino4(const W4Args& a, unsigned nblk, size_t lds, hipStream_t st) {
+    auto kern = conv_wino4_f16x3_kernel<NT>;
+    static bool attr_set[I2V_MAX_DEV] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
+    hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(512), lds, st, a);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T, int H,
+                  int W, int epi, hipStream_t st, double* stats) {
+    I2V_REQUIRE(wts.w.p, I2V_E_STATE, "wino4: weights not packed");
+    I2V_REQUIRE((epi & ~EPI_LRELU) == 0, I2V_E_INVALID, "wino4: unsupported epilogue %d", epi);
+    W4Args a{};
+    if (int rc0 = zero_page(&a.zeros)) return rc0;
+    a.in = static_cast<const char*>(v_hl16); a.wp = wts.w.as<char>(); a.bias = wts.bias.as<float>(); a.res = res; a.out = out;
+    a.stats = stats;
+    a.B = B; a.H = H; a.W = W; a.J = W / 4; a.Cin = wts.Cin; a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
+    a.tdup = wts.tdup ? 1 : 0;
+    a.wset_stride = wts.set_bytes;
+    if (wts.tdup) {  // T is the OUTPUT frame count; the half-rate input has T / 2 frames
+        I2V_REQUIRE(T % 2 == 0 && !res, I2V_E_INVALID, "wino4: temporal-duplication mode needs an even frame count and no residual");
+        T /= 2;
+    }
+    a.T = T;
+    I2V_REQUIRE(wino4_supported(wts.Cout, wts.Cin, T, H, W, wts.KT), I2V_E_INVALID, "wino4: unsupported shape [%d,%d,%d] %d -> %d (kt = %d)",
+                T, H, W, wts.Cin, wts.Cout, wts.KT);
+    a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
+    a.oscale = (float)std::ldexp(1.0, -wts.wexp);
+    int TT = 1, TH = 1;
+    (void)wino4_tiling(T, H, W, wts.KT, &TT, &TH);
+    a.TT = TT; a.TH = TH; a.TJ = 4; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = a.J / 4;
+    const int body = 2 * W4_ROWS_A * 64;   // two V bricks of pass A (pass B and the epilogue's exchange buffer reuse them)
+    a.tofs = body;
+    const size_t lds = (size_t)body + (size_t)(W4_ROWS_A + W4_ROWS_A / 2) * 4 + W4_TILES * 4 + W4_TILES * 16;
+    I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino4: LDS %zu bytes", lds);
+    I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
+    const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / 64);
+    I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
+    if (wts.KT == 3) return launch_wino4<9>(a, (unsigned)nblk, lds, st);
+    return launch_wino4<6>(a, (unsigned)nblk, lds, st);
+}
+
+}  // namespace i2v

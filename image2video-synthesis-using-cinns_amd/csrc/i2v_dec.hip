@@ -299,6 +299,96 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
     if (bad && range_flag) atomicOr(range_flag, 1);
 }
 
+// The operand of the F(4,3) kernel (i2v_conv16w4.hip): V[b][t][c/16][x][h][j][c%16], x = 0..5, j = tile of four output
+// positions (w = 4j .. 4j+3), d_k = act(...)[t][h][4j-1+k]:
+//   V0 = 4 d0 - 5 d2 + d4   V1 = -4 d1 - 4 d2 + d3 + d4   V2 = 4 d1 - 4 d2 - d3 + d4
+//   V3 = -2 d1 - d2 + 2 d3 + d4   V4 = 2 d1 - d2 - 2 d3 + d4   V5 = 4 d1 - 5 d3 + d5
+// Same thread mapping as modulate_wino_kernel: one thread = one 16-byte piece of the V rows of one (h, tile) column; it
+// evaluates its OWN four positions (d1..d4), gets d0 / d5 from the neighbouring tiles by lane shuffle and loops over the frames.
+__global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
+                                                             const float* __restrict__ gb, char* __restrict__ out, int T, int H,
+                                                             int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag) {
+    bool bad = false;
+    const int C8 = C >> 3, J = W >> 2;
+    const int b = blockIdx.y;
+    const int per = H * J * C8 * 2;
+    const int Hl = H / us, Wl = W / us, Tl = T / ut;
+    const float2* cp0 = coef ? coef + (long)b * C : nullptr;
+    const float* xb = x + (long)b * Tl * Hl * Wl * C;
+    const float* gbb = gb ? gb + (long)b * H * W * 2 * C : nullptr;
+    const int nchunk = C >> 4;
+    const long xstride = (long)Hl * Wl * C;
+    const int lane = threadIdx.x & 63, jj = lane >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+        const int p = i & 3;
+        int q = i >> 2;
+        const int j = q % J; q /= J;
+        const int chunk = q % nchunk;
+        const int h = q / nchunk;
+        const int c8 = chunk * 2 + (p >> 1);
+        const bool is_lo = p & 1;
+        float ca[8], cb[8];
+        if (cp0) {
+            const float4* cp = reinterpret_cast<const float4*>(cp0 + 8 * c8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 ab = cp[k];
+                ca[2 * k] = ab.x; cb[2 * k] = ab.y; ca[2 * k + 1] = ab.z; cb[2 * k + 1] = ab.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
+        }
+        ModPos m1, m2, m3, m4, me;
+        mod_pos_init(m1, ca, cb, xb, gbb, h, 4 * j, W, C, c8, us, Wl);
+        mod_pos_init(m2, ca, cb, xb, gbb, h, 4 * j + 1, W, C, c8, us, Wl);
+        mod_pos_init(m3, ca, cb, xb, gbb, h, 4 * j + 2, W, C, c8, us, Wl);
+        mod_pos_init(m4, ca, cb, xb, gbb, h, 4 * j + 3, W, C, c8, us, Wl);
+        const bool left_row = j == 0, right_row = j == J - 1;
+        const bool left_own = !left_row && jj == 0, right_own = !right_row && jj == 15;
+        if (left_own || right_own) mod_pos_init(me, ca, cb, xb, gbb, h, left_own ? 4 * j - 1 : 4 * j + 4, W, C, c8, us, Wl);
+        float d0[8], d1[8], d2[8], d3[8], d4[8], d5[8], de[8];
+        char* ob = out + ((((long)b * T * nchunk + chunk) * 6 * H + h) * J + j) * 64 + p * 16;
+        const long ostride_x = (long)H * J * 64, ostride_t = (long)nchunk * 6 * ostride_x;
+        for (int t = 0; t < T; ++t) {
+            if (t % ut == 0) {
+                const long toff = (long)(t / ut) * xstride;
+                mod_pos_eval(m1, toff, lrelu, d1);
+                mod_pos_eval(m2, toff, lrelu, d2);
+                mod_pos_eval(m3, toff, lrelu, d3);
+                mod_pos_eval(m4, toff, lrelu, d4);
+                if (left_own || right_own) mod_pos_eval(me, toff, lrelu, de);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float up = __shfl_up(d4[c], 4), dn = __shfl_down(d1[c], 4);
+                    d0[c] = left_row ? 0.f : (left_own ? de[c] : up);
+                    d5[c] = right_row ? 0.f : (right_own ? de[c] : dn);
+                }
+            }
+            char* o = ob + (long)t * ostride_t;
+#pragma unroll
+            for (int xq = 0; xq < 6; ++xq) {
+                half8_t piece;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float v;
+                    if (xq == 0) v = fmaf(4.f, d0[c], fmaf(-5.f, d2[c], d4[c]));
+                    else if (xq == 1) v = fmaf(-4.f, d1[c] + d2[c], d3[c] + d4[c]);
+                    else if (xq == 2) v = fmaf(4.f, d1[c] - d2[c], d4[c] - d3[c]);
+                    else if (xq == 3) v = fmaf(2.f, d3[c] - d1[c], d4[c] - d2[c]);
+                    else if (xq == 4) v = fmaf(2.f, d1[c] - d3[c], d4[c] - d2[c]);
+                    else v = fmaf(4.f, d1[c], fmaf(-5.f, d3[c], d5[c]));
+                    const _Float16 hh = (_Float16)v;
+                    bad |= !(fabsf(v) <= 65504.f);
+                    piece[c] = is_lo ? (_Float16)(v - (float)hh) : hh;
+                }
+                *reinterpret_cast<half8_t*>(o + xq * ostride_x) = piece;
+            }
+        }
+    }
+    if (bad && range_flag) atomicOr(range_flag, 1);
+}
+
 // conv_img (decoder.py:117: Conv3d(nf, 3, 3, padding 1) + tanh) in split-fp16 mode.  With three output channels a tiled
 // implicit GEMM wastes the matrix cores (N padded to 32) and the vector-ALU kernel is LDS-bound; instead the conv is split
 // into a 1x1x1 GEMM Y[tap * 3 + n][pos] = sum_c x[pos][c] w[n][c][tap] (81 planes, written transposed by
@@ -415,6 +505,7 @@ struct Block {
     Conv16Weights convs16;      // the learned shortcut's 1x1x1 conv on split-fp16 operands (pointwise16_forward)
     Wino16Weights sp_gb_w;      // SPADE's fused gamma|beta Conv2d(128, 2C, 3) on the Winograd kernel (1x3x3 variant)
     Wino16Weights conv0_w, conv1_w;             // Winograd F(2,3) variants of conv_0 / conv_1 (packed where the shape allows)
+    Wino4Weights conv0_w4, conv1_w4;            // Winograd F(4,3) variants (i2v_conv16w4.hip); packed INSTEAD of the F(2,3) ones
     bool tdup0 = false;                          // conv_0 runs on the half-rate tensor (x2 temporal up-sampling in front)
     DevBuf gn_w, gn_b;
     int zoff = 0;  // offset of this block's ADAIN (gamma|beta) in the z-GEMM output
@@ -437,6 +528,7 @@ struct i2v_dec {
     int Nz = 0;
     int wino = 1;  // 1: 3x3x3 convs whose shape allows it use the Winograd kernel (env I2V_DEC_WINO=0 disables)
     int img16 = 1;  // 1: split-fp16 mode runs conv_img as 1x1x1 GEMM + gather (env I2V_DEC_IMG16=0: vector-ALU kernel)
+    int wino4 = 1; // 1: F(4,3) Winograd kernel where the shape allows and the launch fills the chip (env I2V_DEC_WINO4=0: F(2,3))
     int spw = 1;   // 1: SPADE's gamma|beta conv uses the Winograd kernel where the shape allows (env I2V_DEC_SPW=0: direct kernel)
     int pw16 = 1;  // 1: split-fp16 mode runs the shortcut convs on split-fp16 operands too (env I2V_DEC_PW16=0: exact-fp32 MFMA)
     int device = 0;             // the device the packed weights live on
@@ -469,6 +561,8 @@ struct DecWs {
 
 bool want_wino0(const i2v_dec* d, const Block& b, const Level& l);
 bool want_wino1(const i2v_dec* d, const Block& b, const Level& l);
+bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l);
+bool want_w4_1(const i2v_dec* d, const Block& b, const Level& l);
 
 DecWs dec_ws(const i2v_dec* d, int B) {
     size_t mx_x = (size_t)16 * d->blk[0].n_in, mx_a = 0, mx_dx = 0, mx_xsin = 0, mx_xslow = 0, mx_y = 0, mx_gb = 0;
@@ -479,8 +573,8 @@ DecWs dec_ws(const i2v_dec* d, int B) {
         const size_t P = (size_t)l.T * l.H * l.W, Pl = P / ((size_t)l.ut * l.us * l.us);
         mx_x = std::max(mx_x, P * b.n_out);
         // conv operands: hl16 (4 B per element), or the Winograd operand V (4 values per output pair: 8 B per element)
-        mx_a = std::max(mx_a, P * b.n_in * (want_wino0(d, b, l) ? 2 : 1));
-        mx_a = std::max(mx_a, P * b.n_mid * (want_wino1(d, b, l) ? 2 : 1));
+        mx_a = std::max(mx_a, P * b.n_in * (want_wino0(d, b, l) || want_w4_0(d, b, l) ? 2 : 1));
+        mx_a = std::max(mx_a, P * b.n_mid * (want_wino1(d, b, l) || want_w4_1(d, b, l) ? 2 : 1));
         mx_dx = std::max(mx_dx, P * b.n_mid);
         if (b.learned) { mx_xsin = std::max(mx_xsin, Pl * b.n_in); mx_xslow = std::max(mx_xslow, Pl * b.n_out); }
         mx_y = std::max(mx_y, (size_t)l.H * l.W);
@@ -551,6 +645,19 @@ int run_modulate(const float* x, const float* coef, const float* gb, float* out,
     return I2V_OK;
 }
 
+int run_modulate_wino4(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
+                       int us, int lrelu, hipStream_t st, int* range_flag) {
+    I2V_REQUIRE(C % 32 == 0 && W % 4 == 0, I2V_E_INVALID, "modulate (F(4,3) operand): channels %d / width %d", C, W);
+    const long per = (long)H * (W / 4) * (C / 8) * 2;
+    I2V_REQUIRE(per % 64 == 0, I2V_E_INVALID, "modulate (F(4,3) operand): %ld threads per sample (need whole wavefronts)", per);
+    I2V_REQUIRE(per * T * 6 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
+    const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
+    hipLaunchKernelGGL(modulate_wino4_kernel, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
+                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag);
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
 int run_modulate_wino(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
                       int us, int lrelu, hipStream_t st, int* range_flag) {
     I2V_REQUIRE(C % 32 == 0 && W % 2 == 0, I2V_E_INVALID, "modulate (Winograd operand): channels %d / width %d", C, W);
@@ -612,6 +719,15 @@ int conv3_w(i2v_dec* d, const Wino16Weights& w, const float* v_hl16, float* out,
     return wino16_forward(w, v_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats);
 }
 
+int conv3_w4(i2v_dec* d, const Wino4Weights& w, const float* v_hl16, float* out, const float* res, int rt, int rs, int B,
+             const Level& l, int epi, hipStream_t st, double* stats = nullptr) {
+    if (stats) I2V_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * w.Cout * 16, st));
+    // matrix-core FLOPs issued: 6 Winograd products per 4 outputs x 3 kw taps (x 1/2), 3 fp16 MFMAs each
+    const double fl = 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0;
+    ProfScope ps(d, st, fl, 3.0 * fl * 0.5 * (w.tdup ? 18.0 / 27.0 : 1.0));
+    return wino4_forward(w, v_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats);
+}
+
 // which kernel conv_0 / conv_1 of a block use at this geometry (want_*: by shape; use_*: and the weights are packed for it)
 bool want_wino0(const i2v_dec* d, const Block& b, const Level& l) {
     const bool tdup = l.ut == 2;   // conv_0 behind a x2 temporal up-sampling: pair kernels on the half-rate tensor (Block::tdup0)
@@ -620,6 +736,19 @@ bool want_wino0(const i2v_dec* d, const Block& b, const Level& l) {
 bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
     return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
 }
+// F(4,3): its bricks hold 512 output positions x 64 channels -- only where one SAMPLE already gives >= 32 workgroups (the
+// per-GPU batch of the 8-GPU jobs is 8), i.e. from the 32x32 level on; 16x16 maps stay on the F(2,3) kernel
+bool w4_fills(const Level& l, int cout) { return (long)l.T * l.H * l.W / 512 * (cout / 64) >= 32; }
+bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l) {
+    const bool tdup = l.ut == 2;
+    return d->cfg.mma == 1 && d->wino && d->wino4 && w4_fills(l, b.n_mid) &&
+           wino4_supported(b.n_mid, b.n_in, tdup ? l.T / 2 : l.T, l.H, l.W, tdup ? 2 : 3);
+}
+bool want_w4_1(const i2v_dec* d, const Block& b, const Level& l) {
+    return d->cfg.mma == 1 && d->wino && d->wino4 && w4_fills(l, b.n_out) && wino4_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
+}
+bool use_w4_0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_w4.w.p && want_w4_0(d, b, l); }
+bool use_w4_1(const i2v_dec* d, const Block& b, const Level& l) { return b.conv1_w4.w.p && want_w4_1(d, b, l); }
 bool use_wino0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_w.w.p && want_wino0(d, b, l); }
 bool use_wino1(const i2v_dec* d, const Block& b, const Level& l) { return b.conv1_w.w.p && want_wino1(d, b, l); }
 
@@ -693,17 +822,20 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
     const bool f16 = d->cfg.mma == 1;
     const bool tdup = f16 && b.tdup0;  // a0 is kept at the half temporal rate (its frames 2i and 2i+1 coincide)
-    const bool w0 = use_wino0(d, b, l), w1 = use_wino1(d, b, l);
+    const bool q0 = use_w4_0(d, b, l), q1 = use_w4_1(d, b, l);          // F(4,3)
+    const bool w0 = !q0 && use_wino0(d, b, l), w1 = !q1 && use_wino1(d, b, l);   // F(2,3)
     int* flag = d->status_dev;
-    if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag);
+    if (q0) rc = run_modulate_wino4(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag);
+    else if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag);
     else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true, flag);
     else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16, flag);
     if (rc) return rc;
     if ((rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
     const bool fuse = f16 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
     d->prof_cur_layer = 2 * k;
-    d->prof_cur_kernel = w0 ? 2 : (f16 ? 1 : 0);
-    if (w0) rc = conv3_w(d, b.conv0_w, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
+    d->prof_cur_kernel = q0 ? 3 : w0 ? 2 : (f16 ? 1 : 0);
+    if (q0) rc = conv3_w4(d, b.conv0_w4, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
+    else if (w0) rc = conv3_w(d, b.conv0_w, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr, w.splitk, w.splitk_floats);
     else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
     if (rc) return rc;
@@ -711,7 +843,8 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // ADAIN (normalization_layer.py:47-51) + leaky_relu
     if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
     if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, zstride, b.zoff, nullptr, nullptr, st))) return rc;
-    if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag);
+    if (q1) rc = run_modulate_wino4(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag);
+    else if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag);
     else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16, flag);
     if (rc) return rc;
     if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
@@ -733,8 +866,9 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // statistics of the block OUTPUT = the next block's input)
     const bool fuse_out = f16 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
     d->prof_cur_layer = 2 * k + 1;
-    d->prof_cur_kernel = w1 ? 2 : (f16 ? 1 : 0);
-    if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
+    d->prof_cur_kernel = q1 ? 3 : w1 ? 2 : (f16 ? 1 : 0);
+    if (q1) rc = conv3_w4(d, b.conv1_w4, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
+    else if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
     else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr,
                                 w.splitk, w.splitk_floats);
     else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
@@ -823,6 +957,16 @@ int sn_pack_wino(const StateDict& sd, const std::string& name, bool spectral, in
     return tdup ? out.pack_tdup(w, bias, cout, cin, scale) : out.pack(w, bias, cout, cin, 3, scale);
 }
 
+int sn_pack_wino4(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, bool tdup, Wino4Weights& out) {
+    const float* bias = sd.f32(name + ".bias", cout);
+    if (!bias) return I2V_E_MISSING;
+    const float* w = nullptr;
+    double scale = 1.0;
+    int rc = sn_scale(sd, name, spectral, cout, (int64_t)cin * 27, &w, &scale);
+    if (rc) return rc;
+    return tdup ? out.pack_tdup(w, bias, cout, cin, scale) : out.pack(w, bias, cout, cin, scale);
+}
+
 }  // namespace
 
 extern "C" {
@@ -845,6 +989,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     auto d = std::make_unique<i2v_dec>();
     d->cfg = *cfg;
     if (const char* e = std::getenv("I2V_DEC_WINO")) d->wino = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_WINO4")) d->wino4 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_PW16")) d->pw16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
@@ -906,11 +1051,13 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
             // on t): conv_0 runs on the half-rate tensor with two pre-summed 2-tap temporal kernels (-1/3 of its MACs)
             b.tdup0 = d->lvl[k].ut == 2;
             // layers whose shape allows it run on the Winograd kernel (1.5x fewer MFMAs), the rest on the direct one
-            if (want_wino0(d, b, d->lvl[k])) rc = sn_pack_wino(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.tdup0, b.conv0_w);
+            if (want_w4_0(d, b, d->lvl[k])) rc = sn_pack_wino4(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.tdup0, b.conv0_w4);
+            else if (want_wino0(d, b, d->lvl[k])) rc = sn_pack_wino(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.tdup0, b.conv0_w);
             else if (b.tdup0) rc = sn_pack_tdup(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.conv0_16);
             else rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0_16);
             if (rc) return rc;
-            if (want_wino1(d, b, d->lvl[k])) rc = sn_pack_wino(sd, p + "conv_1", sn, b.n_out, b.n_mid, false, b.conv1_w);
+            if (want_w4_1(d, b, d->lvl[k])) rc = sn_pack_wino4(sd, p + "conv_1", sn, b.n_out, b.n_mid, false, b.conv1_w4);
+            else if (want_wino1(d, b, d->lvl[k])) rc = sn_pack_wino(sd, p + "conv_1", sn, b.n_out, b.n_mid, false, b.conv1_w);
             else rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1_16);
             if (rc) return rc;
         } else {

@@ -1,8 +1,9 @@
 // Stand-alone check + benchmark of the Winograd split-fp16 conv kernel (csrc/i2v_conv16w.hip) against the direct
 // split-fp16 kernel (csrc/i2v_conv16.hip) on one layer shape.
 //   conv16w_check B T H W Cin Cout tdup res      (T = output frames; tdup: conv_0 behind a x2 temporal up-sampling)
-// Build: hipcc -O3 --offload-arch=gfx950 -I<csrc> tools/conv16w_check.hip <csrc>/i2v_conv16w.hip <csrc>/i2v_conv16.hip
-//        <csrc>/i2v_common.hip -o tools/conv16w_check
+// and, where the shape allows it, of the F(4,3) kernel (csrc/i2v_conv16w4.hip) next to them.
+// Build: hipcc -O3 --offload-arch=gfx950 -I<csrc> tools/conv16w_check.hip <csrc>/i2v_conv16w.hip <csrc>/i2v_conv16w4.hip
+//        <csrc>/i2v_conv16.hip <csrc>/i2v_common.hip -o tools/conv16w_check
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -42,7 +43,13 @@ int main(int argc, char** argv) {
         rc = tdup ? ww.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : ww.pack(w.data(), bias.data(), Cout, Cin, 3, 0.7);
     }
     if (rc) { printf("packw: %s\n", i2v_last_error()); return 1; }
-    if (!wino16_supported(Cout, Cin, Ti, H, W)) { printf("shape not supported by the Winograd kernel\n"); return 1; }
+    if (!wino16_supported(Cout, Cin, Ti, H, W, T == 1 && !tdup ? 1 : tdup ? 2 : 3)) { printf("shape not supported by the Winograd kernel\n"); return 1; }
+    const bool do4 = wino4_supported(Cout, Cin, Ti, H, W, tdup ? 2 : 3) && !(T == 1 && !tdup);
+    Wino4Weights w4;
+    if (do4) {
+        rc = tdup ? w4.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : w4.pack(w.data(), bias.data(), Cout, Cin, 0.7);
+        if (rc) { printf("pack4: %s\n", i2v_last_error()); return 1; }
+    }
 
     const size_t npi = (size_t)B * Ti * H * W, npo = (size_t)B * T * H * W;
     std::vector<float> a(npi * Cin);
@@ -81,14 +88,39 @@ int main(int argc, char** argv) {
                     dst[((c & 15) >> 3) * 16 + 8 + (c & 7)] = lo;
                 }
             }
+    // F(4,3) operand: [B][T][Cin/16][6][H][W/4][32 halfs]
+    std::vector<_Float16> V4;
+    if (do4) {
+        const int J4 = W / 4;
+        V4.resize((size_t)B * Ti * H * J4 * 6 * Cin * 2);
+        for (size_t row = 0; row < (size_t)B * Ti * H; ++row)
+            for (int j = 0; j < J4; ++j)
+                for (int c = 0; c < Cin; ++c) {
+                    float d[6];
+                    for (int k = 0; k < 6; ++k) {
+                        const int wq = 4 * j - 1 + k;
+                        d[k] = (wq >= 0 && wq < W) ? a[(row * W + wq) * Cin + c] : 0.f;
+                    }
+                    const float v[6] = {4 * d[0] - 5 * d[2] + d[4], -4 * (d[1] + d[2]) + d[3] + d[4], 4 * (d[1] - d[2]) - d[3] + d[4],
+                                        2 * (d[3] - d[1]) + d[4] - d[2], 2 * (d[1] - d[3]) + d[4] - d[2], 4 * d[1] - 5 * d[3] + d[5]};
+                    for (int x = 0; x < 6; ++x) {
+                        _Float16 hi, lo;
+                        split(v[x], hi, lo);
+                        const size_t bt = row / H, h = row % H;
+                        _Float16* dst = &V4[((((bt * (Cin / 16) + c / 16) * 6 + x) * H + h) * J4 + j) * 32];
+                        dst[((c & 15) >> 3) * 16 + (c & 7)] = hi;
+                        dst[((c & 15) >> 3) * 16 + 8 + (c & 7)] = lo;
+                    }
+                }
+    }
     std::vector<float> res;
     if (use_res) {
         res.resize(npo * Cout);
         for (auto& v : res) v = rand() / (float)RAND_MAX - 0.5f;
     }
-    void *dhl, *dV;
-    float *o0, *o1, *dres = nullptr;
-    double *s0, *s1;
+    void *dhl, *dV, *dV4 = nullptr;
+    float *o0, *o1, *o2 = nullptr, *dres = nullptr;
+    double *s0, *s1, *s2 = nullptr;
     hipMalloc(&dhl, hl.size() * 2);
     hipMalloc(&dV, V.size() * 2);
     hipMalloc(&o0, npo * Cout * 4);
@@ -101,12 +133,21 @@ int main(int argc, char** argv) {
         hipMalloc(&dres, res.size() * 4);
         hipMemcpy(dres, res.data(), res.size() * 4, hipMemcpyHostToDevice);
     }
+    if (do4) {
+        hipMalloc(&dV4, V4.size() * 2);
+        hipMemcpy(dV4, V4.data(), V4.size() * 2, hipMemcpyHostToDevice);
+        hipMalloc(&o2, npo * Cout * 4);
+        hipMemset(o2, 0xff, npo * Cout * 4);
+        hipMalloc(&s2, (size_t)B * Cout * 16);
+        hipMemset(s2, 0, (size_t)B * Cout * 16);
+    }
     hipMemset(o1, 0xff, npo * Cout * 4);
     hipMemset(s0, 0, (size_t)B * Cout * 16);
     hipMemset(s1, 0, (size_t)B * Cout * 16);
     const bool fuse = !nostats && conv16_can_fuse_stats(Ti, H, W);
     if (conv16_forward(cw, dhl, o0, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, fuse ? s0 : nullptr)) { printf("conv16: %s\n", i2v_last_error()); return 1; }
     if (wino16_forward(ww, dV, o1, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s1)) { printf("wino16: %s\n", i2v_last_error()); return 1; }
+    if (do4 && wino4_forward(w4, dV4, o2, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s2)) { printf("wino4: %s\n", i2v_last_error()); return 1; }
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
     std::vector<float> h0(npo * Cout), h1(npo * Cout);
     std::vector<double> hs0((size_t)B * Cout * 2), hs1((size_t)B * Cout * 2);
@@ -126,7 +167,23 @@ int main(int argc, char** argv) {
     if (fuse)
         for (size_t i = 0; i < hs0.size(); ++i) smx = std::max(smx, std::fabs(hs1[i] - hs0[i]) / (std::fabs(hs0[i]) + 1.0));
     // exact fp64 reference on a sample of outputs
-    double rnum = 0, rden = 0;
+    std::vector<float> h2;
+    std::vector<double> hs2;
+    double num4 = 0, mx4 = 0, smx4 = 0;
+    size_t bad4 = 0;
+    if (do4) {
+        h2.resize(npo * Cout); hs2.resize((size_t)B * Cout * 2);
+        hipMemcpy(h2.data(), o2, h2.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(hs2.data(), s2, hs2.size() * 8, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < h0.size(); ++i) {
+            const double d = (double)h2[i] - h0[i];
+            if (!(std::fabs(d) < 1e30)) { ++bad4; continue; }
+            num4 += d * d; mx4 = std::max(mx4, std::fabs(d));
+        }
+        if (fuse)
+            for (size_t i = 0; i < hs0.size(); ++i) smx4 = std::max(smx4, std::fabs(hs2[i] - hs0[i]) / (std::fabs(hs0[i]) + 1.0));
+    }
+    double rnum = 0, rden = 0, rnum4 = 0;
     for (int s = 0; s < 400; ++s) {
         const size_t p = ((size_t)rand() * 7919u + s) % npo;
         const int n = rand() % Cout;
@@ -148,30 +205,33 @@ int main(int argc, char** argv) {
         if (use_res) ref += res[p * Cout + n];
         const double d = h1[p * Cout + n] - ref;
         rnum += d * d; rden += ref * ref;
+        if (do4) { const double d4 = h2[p * Cout + n] - ref; rnum4 += d4 * d4; }
     }
     printf("[B=%d,T=%d,%dx%d] %d -> %d tdup=%d res=%d: wino vs direct rel-L2 %.3e max|d| %.3e nonfinite %zu  stats rel %.2e | wino vs fp64 (400 samples) rel-L2 %.3e\n",
            B, T, H, W, Cin, Cout, tdup, use_res, std::sqrt(num / (den + 1e-30)), mx, bad, smx, std::sqrt(rnum / (rden + 1e-30)));
 
+    if (do4)
+        printf("   F(4,3) vs direct rel-L2 %.3e max|d| %.3e nonfinite %zu  stats rel %.2e | F(4,3) vs fp64 (400 samples) rel-L2 %.3e\n",
+               std::sqrt(num4 / (den + 1e-30)), mx4, bad4, smx4, std::sqrt(rnum4 / (rden + 1e-30)));
     const double flops = 2.0 * npo * Cin * Cout * 27.0;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int n = 5;
-    for (int which = 0; which < 2; ++which) {
-        for (int it = 0; it < 2; ++it) {
-            if (which) wino16_forward(ww, dV, o1, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s1);
+    for (int which = 0; which < (do4 ? 3 : 2); ++which) {
+        auto go = [&]() {
+            if (which == 2) wino4_forward(w4, dV4, o2, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s2);
+            else if (which) wino16_forward(ww, dV, o1, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s1);
             else conv16_forward(cw, dhl, o0, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, fuse ? s0 : nullptr);
-        }
+        };
+        for (int it = 0; it < 2; ++it) go();
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
-        for (int it = 0; it < n; ++it) {
-            if (which) wino16_forward(ww, dV, o1, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s1);
-            else conv16_forward(cw, dhl, o0, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, fuse ? s0 : nullptr);
-        }
+        for (int it = 0; it < n; ++it) go();
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         ms /= n;
-        printf("   %-8s %8.3f ms  %7.1f TFLOP/s algorithmic\n", which ? "winograd" : "direct", ms, flops / ms / 1e9);
+        printf("   %-8s %8.3f ms  %7.1f TFLOP/s algorithmic\n", which == 2 ? "F(4,3)" : which ? "F(2,3)" : "direct", ms, flops / ms / 1e9);
     }
     return 0;
 }
