@@ -265,10 +265,10 @@ def test_both_matrix_core_modes_agree():
         assert rel_l2(gen.cuda().eval()(cu(g["img"]), cu(g["z"])).cpu(), g["out"]) < TOL
 
 
-@pytest.mark.parametrize("env", ["I2V_DEC_WINO", "I2V_DEC_PW16", "I2V_DEC_IMG16", "I2V_DEC_SPW"])
+@pytest.mark.parametrize("env", ["I2V_DEC_WINO", "I2V_DEC_WINO4", "I2V_DEC_PW16", "I2V_DEC_IMG16", "I2V_DEC_SPW"])
 def test_decoder_alternative_kernel_paths(env, monkeypatch):
     """The kernels the split-fp16 mode picks by default each have a tested fallback behind an env switch read when the
-    handle is created (direct instead of Winograd 3x3x3 convs; exact-fp32 MFMA shortcut GEMM; vector-ALU conv_img; SPADE's gamma | beta
+    handle is created (direct instead of Winograd 3x3x3 convs; Winograd F(2,3) instead of F(4,3); exact-fp32 MFMA shortcut GEMM; vector-ALU conv_img; SPADE's gamma | beta
     conv on the direct instead of the 1x3x3 Winograd kernel): the
     full-width BAIR decoder must reproduce the golden frames either way."""
     g, meta = load_golden("dec_nf64_bair")
