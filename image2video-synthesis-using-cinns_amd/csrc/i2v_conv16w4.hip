@@ -156,7 +156,8 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         constexpr int un_ = (U) + R - 1, cn_ = un_ / NT, tn_ = un_ % NT;                                             \
         constexpr int ng_ = w4_count(t_, R, NT, 0) + w4_count(t_, R, NT, 1 % NT);                                    \
         constexpr int nb_ = 2 * (R - 1) + VH * ng_;                                                                  \
-        asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[WM - 2]), "+v"(arow[WM - 1]));                     \
+        if constexpr (WM >= 2) asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[WM - 2]), "+v"(arow[WM - 1])); \
+        else asm volatile("" : "+v"(arow[0]));                                                                       \
         W4_REQUEST_B(BREQ, tn_, ch + cn_)                                                                            \
         if constexpr (t_ < 2)                                                                                        \
             W4_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_, 1 - cp_, t_)                             \
@@ -237,9 +238,12 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
 #undef W4_TAP18R9
 }
 
-// NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3)
-template <int NT>
+// NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3).
+// BN: output channels per workgroup.  64: as described above.  32 (layers with 32 output channels): pass A wave = (plane,
+// tile half) with 2 row blocks, pass B wave = (plane, tile quarter) with 1 row block, one epilogue pass.
+template <int NT, int BN>
 __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
+    constexpr int WMA = BN == 64 ? 4 : 2, WMB = BN == 64 ? 2 : 1;
     constexpr int KT = NT / 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     const int kg = lane >> 5, l31 = lane & 31;
 
     // tile order and the XCDs: as in i2v_conv16w.hip (all workgroups reading the same V brick on one XCD, consecutively)
-    const int nNt = a.CoutPad / 64;
+    const int nNt = a.CoutPad / BN;
     const int npar = a.tdup ? 2 : 1;
     const int per_brick = nNt * npar;
     const int nbrick = (int)(gridDim.x / per_brick);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     const int bh = brick % a.nbH; brick /= a.nbH;
     const int bt = brick % a.nbT; brick /= a.nbT;
     const int b0 = brick, t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * a.TJ;
-    const int n0 = ntile * 64;
+    const int n0 = ntile * BN;
 
     if (tid < W4_TILES) {
         int m = tid;
@@ -305,37 +309,37 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     const char* wbase = a.wp + (long)par * a.wset_stride + lane * 16;
     const int nblk = a.CoutPad >> 5;
 
-    // ---- pass A: planes 0..3, wave = (plane, 32-channel half), all 128 tiles
-    const int xa = wave & 3, nha = wave >> 2;
-    f32x16 accA[4];
+    // ---- pass A: planes 0..3, wave = (plane, 32-channel half), all 128 tiles   [BN = 32: (plane, tile half)]
+    const int xa = wave & 3, nha = BN == 64 ? wave >> 2 : 0, mha = BN == 64 ? 0 : (wave >> 2) * 64;
+    f32x16 accA[WMA];
     {
-        int arow[4];
+        int arow[WMA];
 #pragma unroll
-        for (int wm = 0; wm < 4; ++wm) {
-            int m = wm * 32 + l31;
+        for (int wm = 0; wm < WMA; ++wm) {
+            int m = mha + wm * 32 + l31;
             const int ij = m % a.TJ; m /= a.TJ;
             const int ih = m % a.TH; m /= a.TH;
             arow[wm] = xa * plane + (m * HH + ih) * a.TJ + ij;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
         }
-        w4_pass<NT, 4, 4>(a, smem, gposA, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid, lane, wave);
+        w4_pass<NT, WMA, 4>(a, smem, gposA, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid, lane, wave);
     }
-    // ---- pass B: planes 4, 5, wave = (plane, 32-channel half, tile half)
-    const int xb = wave & 1, nhb = (wave >> 1) & 1, mhb = wave >> 2;
-    f32x16 accB[2];
+    // ---- pass B: planes 4, 5, wave = (plane, 32-channel half, tile half)   [BN = 32: (plane, tile quarter)]
+    const int xb = wave & 1, nhb = BN == 64 ? (wave >> 1) & 1 : 0, mhb = BN == 64 ? (wave >> 2) * 64 : (wave >> 1) * 32;
+    f32x16 accB[WMB];
     {
-        int arow[2];
+        int arow[WMB];
 #pragma unroll
-        for (int wm = 0; wm < 2; ++wm) {
-            int m = mhb * 64 + wm * 32 + l31;
+        for (int wm = 0; wm < WMB; ++wm) {
+            int m = mhb + wm * 32 + l31;
             const int ij = m % a.TJ; m /= a.TJ;
             const int ih = m % a.TH; m /= a.TH;
             arow[wm] = xb * plane + (m * HH + ih) * a.TJ + ij;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accB[wm][r] = 0.f;
         }
-        w4_pass<NT, 2, 2>(a, smem, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid, lane, wave);
+        w4_pass<NT, WMB, 2>(a, smem, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid, lane, wave);
     }
 
     // ---- epilogue, one 32-channel half at a time: E = [6 planes][128 tiles][32 channels] fp32 (98 KB)
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     double* S = reinterpret_cast<double*>(smem + 6 * W4_TILES * 32 * 4);   // [8 waves][32 channels][2] behind E
     const int n4 = tid % NQ;
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < BN / 32; ++half) {
         const int n = n0 + half * 32 + 4 * n4;
         const bool ncol = n < a.Cout;
         // residual rows first, all of them, so that their latency hides behind the LDS exchange
@@ -360,19 +364,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         __syncthreads();   // the V bricks / the previous half's E are no longer read
         if (nha == half) {
 #pragma unroll
-            for (int wm = 0; wm < 4; ++wm)
+            for (int wm = 0; wm < WMA; ++wm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    const int m = mha + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                     E[(xa * W4_TILES + m) * 32 + l31] = accA[wm][r];
                 }
         }
         if (nhb == half) {
 #pragma unroll
-            for (int wm = 0; wm < 2; ++wm)
+            for (int wm = 0; wm < WMB; ++wm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mhb * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    const int m = mhb + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                     E[((4 + xb) * W4_TILES + m) * 32 + l31] = accB[wm][r];
                 }
         }
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
 // w3: [nset][Cout][Cin][NT][3] (fp64, already scaled); packs U = G g per (kt, kh)
 static int wino4_pack_sets(Wino4Weights& o, const std::vector<double>& w3, int nset, int cout, int cin, int kt) {
     o.Cin = cin; o.Cout = cout; o.KT = kt;
-    o.CoutPad = (cout + 63) / 64 * 64;
+    o.CoutPad = (cout + 31) / 32 * 32;
     o.nchunk = cin / W4_KC;
     const int NT = kt * 3;
     std::vector<double> u((size_t)nset * cout * cin * NT * 6);
@@ -506,7 +510,7 @@ static bool wino4_tiling(int T, int H, int W, int KT, int* TT_, int* TH_) {
 }
 
 bool wino4_supported(int cout, int cin, int T, int H, int W, int KT) {
-    if (cout % 64 || cin % (2 * W4_KC) || (KT != 3 && KT != 2)) return false;
+    if (cout % 32 || cin % (2 * W4_KC) || (KT != 3 && KT != 2)) return false;
     int TT, TH;
     return wino4_tiling(T, H, W, KT, &TT, &TH);
 }
@@ -541,9 +545,9 @@ int Wino4Weights::pack_tdup(const float* w_src, const float* bias_src, int cout,
     return I2V_OK;
 }
 
-template <int NT>
+template <int NT, int BN>
 static int launch_wino4(const W4Args& a, unsigned nblk, size_t lds, hipStream_t st) {
-    auto kern = conv_wino4_f16x3_kernel<NT>;
+    auto kern = conv_wino4_f16x3_kernel<NT, BN>;
     static bool attr_set[I2V_MAX_DEV] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(512), lds, st, a);
@@ -579,10 +583,15 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     const size_t lds = (size_t)body + (size_t)(W4_ROWS_A + W4_ROWS_A / 2) * 4 + W4_TILES * 4 + W4_TILES * 16;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino4: LDS %zu bytes", lds);
     I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
-    const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / 64);
+    const int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
+    const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
-    if (wts.KT == 3) return launch_wino4<9>(a, (unsigned)nblk, lds, st);
-    return launch_wino4<6>(a, (unsigned)nblk, lds, st);
+    if (BN == 64) {
+        if (wts.KT == 3) return launch_wino4<9, 64>(a, (unsigned)nblk, lds, st);
+        return launch_wino4<6, 64>(a, (unsigned)nblk, lds, st);
+    }
+    if (wts.KT == 3) return launch_wino4<9, 32>(a, (unsigned)nblk, lds, st);
+    return launch_wino4<6, 32>(a, (unsigned)nblk, lds, st);
 }
 
 }  // namespace i2v

@@ -738,7 +738,7 @@ bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
 }
 // F(4,3): its bricks hold 512 output positions x 64 channels -- only where one SAMPLE already gives >= 32 workgroups (the
 // per-GPU batch of the 8-GPU jobs is 8), i.e. from the 32x32 level on; 16x16 maps stay on the F(2,3) kernel
-bool w4_fills(const Level& l, int cout) { return (long)l.T * l.H * l.W / 512 * (cout / 64) >= 32; }
+bool w4_fills(const Level& l, int cout) { return (long)l.T * l.H * l.W / 512 * std::max(cout / 64, 1) >= 32; }
 bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l) {
     const bool tdup = l.ut == 2;
     return d->cfg.mma == 1 && d->wino && d->wino4 && w4_fills(l, b.n_mid) &&

@@ -261,6 +261,43 @@ def test_winograd_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     assert checked == 6
 
 
+def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
+    """The same static checks for the Winograd F(4,3) kernel (csrc/i2v_conv16w4.hip): every instantiation has TWO tap loops
+    (pass A: planes 0..3, pass B: planes 4, 5), no scratch, exactly the loads the macros issue, and the replay of each
+    compiled loop against the in-order VMEM queue finds no hazard while a wait relaxed by one does."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(PKG, "csrc", "i2v_conv16w4.hip")
+    asm = tmp_path / "w4.s"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", src,
+                    "-o", str(asm)], check=True, capture_output=True, timeout=900)
+    text = asm.read_text()
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_asm_waits as caw
+    kernels = re.findall(r"^(_ZN3i2v23conv_wino4_f16x3_kernelILi(\d)ELi(\d+)EEEvNS_6W4ArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+                         flags=re.S | re.M)
+    assert len(kernels) == 4, [k[0] for k in kernels]
+    for name, nt, bn, whole in kernels:
+        nt = int(nt)
+        assert "scratch_" not in whole and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", whole), name
+        loops = [mm.group(2) for mm in re.finditer(r"^(\.LBB\d+_\d+):[^\n]*\n((?:(?!^\.LBB).)*?)s_cbranch_\w+ \1\n", whole, flags=re.S | re.M)
+                 if "v_mfma" in mm.group(2)]
+        assert len(loops) == 2, (name, len(loops))
+        for loop, wm, vh in zip(loops, (4, 2) if bn == "64" else (2, 1), (4, 2)):
+            taps = 2 * nt
+            assert loop.count("v_mfma_f32_32x32x16_f16") == taps * 3 * wm, name
+            assert loop.count("global_load_lds_dwordx4") == 2 * 2 * vh, name                 # two half-requests per chunk
+            assert len(re.findall(r"global_load_dwordx4", loop)) == taps * 2, name
+            assert loop.count("s_barrier") == 2, name
+            assert caw.check_loop(loop) == [], name
+            b_wait, bar_wait = max(waits_of(loop)), min(waits_of(loop))
+            for w in (b_wait, bar_wait):
+                mutated = re.sub(r"s_waitcnt vmcnt\(%d\)" % w, "s_waitcnt vmcnt(%d)" % (w + 1), loop)
+                assert caw.check_loop(mutated) != [], (name, w)
+
+
 def waits_of(loop):
     return [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)]
 
