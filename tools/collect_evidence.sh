@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 out=${1:-gpurun_out/evidence}
 mkdir -p $out
-timeout 300 python bench.py --per-layer $out/conv16_per_layer_bair64.csv 2>$out/bench_bair64.err | tail -1 > $out/bench_bair64.json
+timeout 400 python bench.py --per-layer $out/conv16_per_layer_bair64.csv 2>$out/bench_bair64.err | tail -1 > $out/bench_bair64.json
 timeout 300 python bench.py --config land128 --steps 10 --warmup 3 --no-cpu-baseline --per-layer $out/conv16_per_layer_land128.csv 2>/dev/null | tail -1 > $out/bench_land128_b32.json
 for b in 4 8 16; do timeout 200 python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_bair64_b$b.json; done
 timeout 300 python bench.py --config dtdb128 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_dtdb128_strong_b256.json
@@ -16,3 +16,11 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_la
 rm -f $out/prof_*/bench_kernel_trace.csv
 timeout 400 python tools/pmc_hbm_traffic.py $out/pmc_traffic > $out/pmc_traffic.log 2>&1
 rm -rf $out/pmc_traffic/fetch_size $out/pmc_traffic/write_size
+# round 3 additions: cINN latencies / per-kernel stats, FETCH_SIZE calibration, SQ counters of the F(4,3) kernel on the
+# g_3.conv_1 shape (pass A and pass B are one kernel; MFMA-busy normalised by GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs)
+timeout 300 python tools/flowtime.py > $out/flowtime.txt 2>&1
+FLOWTIME_B=64 timeout 300 bash tools/flow_prof.sh evidence_b64 > /dev/null 2>&1; cp gpurun_out/flowprof_evidence_b64.csv $out/kernel_stats_flow_b64.csv 2>/dev/null
+timeout 300 python tools/pmc_hbm_traffic.py $out/pmc_traffic --calibrate > $out/fetch_calibration.log 2>&1
+rm -rf $out/pmc_traffic/fetch_calib
+timeout 400 bash tools/pmc_sq.sh $out/pmc_sq_f43 tools/conv16w_check 8 16 64 64 128 128 0 1 > $out/pmc_sq_f43_g3conv1.txt 2>&1
+rm -rf $out/pmc_sq_f43

@@ -33,28 +33,25 @@ def one_pass(outdir, counter, extra, parse_only):
             if "conv_mfma_f16x3_kernel" in k:
                 conv16.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                 continue
-            if "conv_wino_f16x3_kernel" in k:
-                k = "i2v::conv_wino_f16x3_kernel [3x3x3 Conv3d, Winograd]"
+            if "conv_wino4_f16x3_kernel" in k:
+                k = "i2v::conv_wino4_f16x3_kernel [3x3x3 Conv3d, Winograd F(4,3)]"
+            elif "conv_wino_f16x3_kernel<3," in k:
+                k = "i2v::conv_wino_f16x3_kernel<3, .> [SPADE 3x3 Conv2d, Winograd F(2,3)]"
+            elif "conv_wino_f16x3_kernel" in k:
+                k = "i2v::conv_wino_f16x3_kernel [3x3x3 Conv3d, Winograd F(2,3)]"
             per[k][0] += 1
             per[k][1] += float(r["Counter_Value"])
     # direct split-fp16 launches of one decoder pass, in dispatch order: per block SPADE conv (3 -> 128) and SPADE
     # gamma/beta (3x3 Conv2d), then conv_0 / conv_1 for the blocks the Winograd tiling does not cover (head_0, g_0, and
     # shapes with odd channel counts).  With 6 blocks: 12 SPADE launches; whatever exceeds 2 per block is 3x3x3.
     conv16.sort()
-    n3 = max(len(conv16) - 12, 0)          # 3x3x3 launches on the direct kernel (head_0, g_0: 2 each in the BAIR decoder)
-    per_block = {0: 4, 1: 4}               # blocks whose conv_0 / conv_1 run on the direct kernel -> 4 launches in that block
-    i = 0
-    blk = 0
-    while i < len(conv16):
-        n_here = 4 if (blk in per_block and n3 >= 2 * (len(per_block))) else 2
-        for j in range(n_here):
-            if i + j >= len(conv16):
-                break
-            name = "i2v::conv_mfma_f16x3_kernel [SPADE 3x3 Conv2d]" if j < 2 else "i2v::conv_mfma_f16x3_kernel [3x3x3 Conv3d, direct]"
-            per[name][0] += 1
-            per[name][1] += conv16[i + j][1]
-        i += n_here
-        blk += 1
+    # The first two blocks (head_0, g_0: 4x4 and 8x8 maps) run all four of their convs on the direct kernel (SPADE input conv,
+    # SPADE gamma|beta conv, conv_0, conv_1); every later block only its SPADE input conv (3 -> 128) and, where the 1x3x3
+    # Winograd variant does not apply (maps below 32x32), its gamma|beta conv.  Count from the front: 4 + 4, the rest SPADE.
+    for i, (_, v) in enumerate(conv16):
+        name = "i2v::conv_mfma_f16x3_kernel [3x3x3 Conv3d, direct]" if i < 8 and i % 4 >= 2 else "i2v::conv_mfma_f16x3_kernel [SPADE 3x3 Conv2d]"
+        per[name][0] += 1
+        per[name][1] += v
     return per, " ".join(cmd)
 
 
@@ -102,7 +99,8 @@ def main():
            "units": "read bytes = 2 * FETCH_SIZE[KiB] * 1024 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
                     "write bytes = WRITE_SIZE[KiB] * 1024",
            "kernels": dict(sorted(kernels.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]))),
-           "dominant_kernel": {"name": "the 3x3x3 Conv3d launches: conv_wino_f16x3_kernel (g_1..g_4) + conv_mfma_f16x3_kernel (head_0, g_0)", "launches": n,
+           "dominant_kernel": {"name": "the 3x3x3 Conv3d launches: conv_wino4_f16x3_kernel (F(4,3): g_2..g_4), conv_wino_f16x3_kernel (F(2,3): g_1) "
+                                       "+ conv_mfma_f16x3_kernel (head_0, g_0)", "launches": n,
                                "hbm_bytes_per_launch": tot / max(n, 1)}}
     with open(os.path.join(outdir, "hbm_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
