@@ -68,9 +68,12 @@ constexpr int w4_count(int t, int R, int NT, int h) {
 // four planes, 2 -> 512 rows = two planes).  WM = MFMA row blocks of this wave.  arow[wm]: LDS row of the lane's tile (tap
 // (0,0)) inside the pass's brick; gpos: global V row (chunk 0) of every staged row, -1 = zero padding; wlane: this wave's
 // weight fragments (tap 0, chunk 0).
-template <int NT, int WM, int VH>
-__device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* gpos, f32x16 (&acc)[WM], int (&arow)[WM],
-                                        const char* wlane, int HH, int tid, int lane, int wave) {
+// gposN / PRE: hand-over between the passes.  The request a chunk issues for "the next chunk" is a harmless repeat behind the
+// LAST chunk; pass A instead requests chunk 0 of pass B's brick there (table gposN: its rows in front, -1 behind), into the
+// buffer pass B reads first, so that pass B (PRE = true) starts without a V round trip.
+template <int NT, int WM, int VH, bool PRE>
+__device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* gpos, const int* gposN, f32x16 (&acc)[WM],
+                                        int (&arow)[WM], const char* wlane, int HH, int tid, int lane, int wave) {
     constexpr int VROWS = VH * 2 * 128;
     const int kg = lane >> 5;
     char* v_lds = smem;
@@ -79,6 +82,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
     const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
     const int* gq = gpos + (tid >> 2);
+    const int* gqn = gposN + (tid >> 2);
     const long vpiece = (long)((tid & 3) ^ ((tid >> 4) & 3)) * 16;
     const long vchunk = (long)6 * a.H * a.J * 64;        // bytes between the K chunks of one frame
 #define W4_GLDS(src_, dst_)                                                                                          \
@@ -89,9 +93,11 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     }
 #define W4_REQUEST_V(ch_, VB, HF)                                                                                    \
     {                                                                                                                \
+        const bool nx_ = (ch_) >= a.nchunk;              /* behind the last chunk: the hand-over table, chunk 0 */    \
+        const int* gt_ = nx_ ? gqn : gq;                                                                             \
         int gp_[VH];                                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < VH; ++u) gp_[u] = gq[128 * (VH * (HF) + u)];                           \
-        const char* vb_ = a.in + (long)(ch_) * vchunk + vpiece;                                                      \
+        _Pragma("unroll") for (int u = 0; u < VH; ++u) gp_[u] = gt_[128 * (VH * (HF) + u)];                          \
+        const char* vb_ = a.in + (long)(nx_ ? 0 : (ch_)) * vchunk + vpiece;                                          \
         _Pragma("unroll") for (int u = 0; u < VH; ++u) {                                                             \
             const char* s_ = gp_[u] >= 0 ? vb_ + (long)gp_[u] * 64 : a.zeros;                                        \
             W4_GLDS(s_, vdst + (unsigned)((VB) * (VROWS * 64) + (VH * (HF) + u) * 8192))                             \
@@ -131,9 +137,11 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
             acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
     }
 
-    __syncthreads();  // tables written / the previous pass has left LDS
-    W4_REQUEST_V(0, 0, 0)
-    W4_REQUEST_V(0, 0, 1)
+    if constexpr (!PRE) {
+        __syncthreads();  // tables written
+        W4_REQUEST_V(0, 0, 0)
+        W4_REQUEST_V(0, 0, 1)
+    }
     W4_REQUEST_B(bq0, 0 % NT, 0 / NT)
     W4_REQUEST_B(bq1, 1 % NT, 1 / NT)
     W4_REQUEST_B(bq2, 2 % NT, 2 / NT)
@@ -160,7 +168,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         else asm volatile("" : "+v"(arow[0]));                                                                       \
         W4_REQUEST_B(BREQ, tn_, ch + cn_)                                                                            \
         if constexpr (t_ < 2)                                                                                        \
-            W4_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_, 1 - cp_, t_)                             \
+            W4_REQUEST_V(ch + cp_ + 1, 1 - cp_, t_)                                                                  \
         if constexpr (t_ < NT - 1) {                                                                                 \
             W4_LOAD_A(ANXT, t_ + 1, cp_)                                                                             \
         } else {                                                                                                     \
@@ -271,8 +279,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     const int plane = HT * HH * a.TJ;
 
     int* gposA = reinterpret_cast<int*>(smem + a.tofs);   // [1024] planes 0..3
-    int* gposB = gposA + W4_ROWS_A;                       // [512]  planes 4, 5
-    int* tpos = gposB + W4_ROWS_A / 2;                    // [128] output position of a tile's first column
+    int* gposB = gposA + W4_ROWS_A;                       // [1024] planes 4, 5 in rows 0..511, -1 (zero page) behind
+    int* tpos = gposB + W4_ROWS_A;                        // [128] output position of a tile's first column
     int* tres = tpos + W4_TILES;                          // [128][4] residual rows of the tile's four columns
 
     const int ntile = tile_id % nNt;
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) tres[4 * tid + c] = rbase + (w + c) / a.rs;
     }
-    for (int r = tid; r < W4_ROWS_A + W4_ROWS_A / 2; r += 512) {
+    for (int r = tid; r < 2 * W4_ROWS_A; r += 512) {
         const bool pb = r >= W4_ROWS_A;                 // row of pass B's brick
         const int rr = pb ? r - W4_ROWS_A : r;
         const int x = rr / plane;
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
         }
-        w4_pass<NT, WMA, 4>(a, smem, gposA, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid, lane, wave);
+        w4_pass<NT, WMA, 4, false>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid, lane, wave);
     }
     // ---- pass B: planes 4, 5, wave = (plane, 32-channel half, tile half)   [BN = 32: (plane, tile quarter)]
     const int xb = wave & 1, nhb = BN == 64 ? (wave >> 1) & 1 : 0, mhb = BN == 64 ? (wave >> 2) * 64 : (wave >> 1) * 32;
@@ -339,7 +347,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) accB[wm][r] = 0.f;
         }
-        w4_pass<NT, WMB, 2>(a, smem, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid, lane, wave);
+        // (chunk 0 of this brick was requested by pass A behind its last chunk and published by its last barrier; pass B's
+        //  own request behind ITS last chunk re-reads its chunk 0 harmlessly)
+        w4_pass<NT, WMB, 2, true>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid, lane, wave);
     }
 
     // ---- epilogue, one 32-channel half at a time: E = [6 planes][128 tiles][32 channels] fp32 (98 KB)
@@ -580,7 +590,7 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     a.TT = TT; a.TH = TH; a.TJ = 4; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = a.J / 4;
     const int body = 2 * W4_ROWS_A * 64;   // two V bricks of pass A (pass B and the epilogue's exchange buffer reuse them)
     a.tofs = body;
-    const size_t lds = (size_t)body + (size_t)(W4_ROWS_A + W4_ROWS_A / 2) * 4 + W4_TILES * 4 + W4_TILES * 16;
+    const size_t lds = (size_t)body + (size_t)(2 * W4_ROWS_A) * 4 + W4_TILES * 4 + W4_TILES * 16;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino4: LDS %zu bytes", lds);
     I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
     const int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
