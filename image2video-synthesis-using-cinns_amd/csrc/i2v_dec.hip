@@ -528,7 +528,7 @@ struct i2v_dec {
     int Nz = 0;
     int wino = 1;  // 1: 3x3x3 convs whose shape allows it use the Winograd kernel (env I2V_DEC_WINO=0 disables)
     int img16 = 1;  // 1: split-fp16 mode runs conv_img as 1x1x1 GEMM + gather (env I2V_DEC_IMG16=0: vector-ALU kernel)
-    int wino4 = 1; // 1: F(4,3) Winograd kernel where the shape allows and the launch fills the chip (env I2V_DEC_WINO4=0: F(2,3))
+    int wino4 = 1; // 1: F(4,3) Winograd kernel where the shape allows and one sample gives >= 32 workgroups (env I2V_DEC_WINO4=0: F(2,3); 2: wherever the shape allows)
     int spw = 1;   // 1: SPADE's gamma|beta conv uses the Winograd kernel where the shape allows (env I2V_DEC_SPW=0: direct kernel)
     int pw16 = 1;  // 1: split-fp16 mode runs the shortcut convs on split-fp16 operands too (env I2V_DEC_PW16=0: exact-fp32 MFMA)
     int device = 0;             // the device the packed weights live on
@@ -741,11 +741,11 @@ bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
 bool w4_fills(const Level& l, int cout) { return (long)l.T * l.H * l.W / 512 * std::max(cout / 64, 1) >= 32; }
 bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l) {
     const bool tdup = l.ut == 2;
-    return d->cfg.mma == 1 && d->wino && d->wino4 && w4_fills(l, b.n_mid) &&
+    return d->cfg.mma == 1 && d->wino && d->wino4 && (d->wino4 == 2 || w4_fills(l, b.n_mid)) &&
            wino4_supported(b.n_mid, b.n_in, tdup ? l.T / 2 : l.T, l.H, l.W, tdup ? 2 : 3);
 }
 bool want_w4_1(const i2v_dec* d, const Block& b, const Level& l) {
-    return d->cfg.mma == 1 && d->wino && d->wino4 && w4_fills(l, b.n_out) && wino4_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
+    return d->cfg.mma == 1 && d->wino && d->wino4 && (d->wino4 == 2 || w4_fills(l, b.n_out)) && wino4_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
 }
 bool use_w4_0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_w4.w.p && want_w4_0(d, b, l); }
 bool use_w4_1(const i2v_dec* d, const Block& b, const Level& l) { return b.conv1_w4.w.p && want_w4_1(d, b, l); }
@@ -989,7 +989,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     auto d = std::make_unique<i2v_dec>();
     d->cfg = *cfg;
     if (const char* e = std::getenv("I2V_DEC_WINO")) d->wino = std::atoi(e) != 0;
-    if (const char* e = std::getenv("I2V_DEC_WINO4")) d->wino4 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_WINO4")) d->wino4 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_PW16")) d->pw16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
@@ -1331,6 +1331,7 @@ int i2v_gblock_create(int32_t n_in, int32_t n_out, int32_t z_dim, int32_t spectr
     g->ctx.cfg.z_dim = z_dim;
     if (const char* e = std::getenv("I2V_DEC_WINO")) g->ctx.wino = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_PW16")) g->ctx.pw16 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_WINO4")) g->ctx.wino4 = std::atoi(e);
     if (int rc = init_status(&g->ctx)) return rc;
     g->z_dim = z_dim;
     Block& b = g->b;
@@ -1364,6 +1365,11 @@ int i2v_gblock_load(i2v_gblock* g, const i2v_tensor* tensors, int32_t n_tensors)
                 (rc = sn_pack_wino(sd, "conv_0", sn, b.n_mid, b.n_in, false, b.conv0_w))) return rc;
             if (g->ctx.wino && wino16_supported(b.n_out, b.n_mid, 16, 64, 64) &&
                 (rc = sn_pack_wino(sd, "conv_1", sn, b.n_out, b.n_mid, false, b.conv1_w))) return rc;
+            // ... and the F(4,3) variants (used where the call's geometry gives a sample >= 32 workgroups; I2V_DEC_WINO4=2: always)
+            if (g->ctx.wino && g->ctx.wino4 && wino4_supported(b.n_mid, b.n_in, 16, 64, 64, 3) &&
+                (rc = sn_pack_wino4(sd, "conv_0", sn, b.n_mid, b.n_in, false, b.conv0_w4))) return rc;
+            if (g->ctx.wino && g->ctx.wino4 && wino4_supported(b.n_out, b.n_mid, 16, 64, 64, 3) &&
+                (rc = sn_pack_wino4(sd, "conv_1", sn, b.n_out, b.n_mid, false, b.conv1_w4))) return rc;
         } else {
             if ((rc = sn_pack(sd, "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
             if ((rc = sn_pack(sd, "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;

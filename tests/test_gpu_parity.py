@@ -230,13 +230,16 @@ def test_decoder_submodules_vs_golden():
         assert out.shape == (2, n_out, 2, 8, 8) and rel_l2(out.cpu(), g[key]) < TOL
 
 
-def test_generator_block_shape_sweep_winograd_and_fallback():
+@pytest.mark.parametrize("wino4", [None, "2"])
+def test_generator_block_shape_sweep_winograd_and_fallback(wino4, monkeypatch):
     """Stand-alone GeneratorBlock over geometries on both sides of the Winograd kernel's tiling rule (csrc/i2v_conv16w.hip:
     bricks of TT x TH x 4 output pairs, halo brick <= 1024 staged rows): single frames and T = 2 (halo too large -> direct
     kernel; these raised I2V_E_INVALID before round 3), narrow / wide / tall maps, T = 4 and 8 (TT = 4, TH = 8 bricks), both
     the identity-shortcut (128 -> 128) and the learned-shortcut (128 -> 64) block, against the oracle."""
     from oracle import decoder_ref
     from stage1_VAE.modules import decoder as dec
+    if wino4:   # I2V_DEC_WINO4=2: the F(4,3) kernel wherever its tiling allows (default: only where a sample fills 32 workgroups,
+        monkeypatch.setenv("I2V_DEC_WINO4", wino4)   # which none of these small maps does) -- [.,4,16,16], [.,4,8,32], [.,8,32,16] here
     sd = T(synth.decoder_state_dict(seed=5, channel_factor=8))
     g = torch.Generator().manual_seed(31)
     for name, n_out in (("g_0", 128), ("g_1", 64)):
@@ -252,6 +255,15 @@ def test_generator_block_shape_sweep_winograd_and_fallback():
             out = blk(x.cuda(), z.cuda(), img.cuda())
             assert out.shape == ref.shape and rel_l2(out.cpu(), ref) < TOL, (name, B, Tn, H, W, rel_l2(out.cpu(), ref))
         assert blk.native().status() == 0
+    if wino4:   # the forced mode really ran another kernel on an eligible shape
+        x = torch.randn(1, 128, 4, 16, 16, generator=g).cuda()
+        img, z = (2 * torch.rand(1, 3, 16, 16, generator=g) - 1).cuda(), torch.randn(1, 64, generator=g).cuda()
+        a = blk(x, z, img)
+        monkeypatch.setenv("I2V_DEC_WINO4", "0")
+        blk0 = dec.GeneratorBlock(128, 64, True, 64)
+        blk0.load_state_dict(sub(sd, "g_1."))
+        b = blk0.cuda().eval()(x, z, img)
+        assert not torch.equal(a, b) and rel_l2(a.cpu(), b.cpu()) < 1e-5
 
 
 def test_both_matrix_core_modes_agree():
