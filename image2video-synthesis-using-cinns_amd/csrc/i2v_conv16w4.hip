@@ -37,6 +37,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef W4_INTERLEAVE
+#define W4_INTERLEAVE 1   // measurement builds: 0 = A-operand reads in one burst in front of the MFMA block (round 2's schedule)
+#endif
 constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
 constexpr int W4_KC = 16;       // input channels per K chunk
 constexpr int W4_ROWS_A = 1024; // staged V rows per buffer, pass A (4 planes); pass B stages 512 (2 planes)
@@ -118,6 +121,14 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
             (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                        \
         }                                                                                                            \
     }
+    /* one row block of the A operands (address arithmetic + two ds_read_b128) */                                   \
+#define W4_LOAD_A1(o, TAP, VB, wm)                                                                                   \
+    {                                                                                                                \
+        const int r_ = arow[wm] + (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * VROWS;                            \
+        const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                            \
+        (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                                   \
+        (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                            \
+    }
 #define W4_REQUEST_B(q, TAP, CH)                                                                                     \
     {                                                                                                                \
         const int c_ = (CH) < a.nchunk ? (CH) : a.nchunk - 1;                                                        \
@@ -127,6 +138,30 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     }
 #define W4_WAIT_B(q, N) asm volatile("s_waitcnt vmcnt(%2)" : "+v"((q).bh), "+v"((q).bl) : "n"(N));
 #define W4_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+// the MFMAs of a tap with the NEXT tap's A-operand reads spread between them: the two waves of a SIMD fall into step (they
+// share the matrix pipe), so whatever a wave issues outside its MFMA block is time the pipe idles for both
+#if W4_INTERLEAVE
+#define W4_MFMA_LD(o, q, onxt, TAPN, VBN)                                                                            \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            W4_LOAD_A1(onxt, TAPN, VBN, wm)                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+    }
+#else
+#define W4_MFMA_LD(o, q, onxt, TAPN, VBN)                                                                            \
+    {                                                                                                                \
+        W4_LOAD_A(onxt, TAPN, VBN)                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        W4_MFMA(o, q)                                                                                                \
+    }
+#endif
 #define W4_MFMA(o, q)                                                                                                \
     {                                                                                                                \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
@@ -169,16 +204,14 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         W4_REQUEST_B(BREQ, tn_, ch + cn_)                                                                            \
         if constexpr (t_ < 2)                                                                                        \
             W4_REQUEST_V(ch + cp_ + 1, 1 - cp_, t_)                                                                  \
-        if constexpr (t_ < NT - 1) {                                                                                 \
-            W4_LOAD_A(ANXT, t_ + 1, cp_)                                                                             \
-        } else {                                                                                                     \
+        if constexpr (t_ == NT - 1) {                                                                                \
             W4_WAIT_VM(2 * (NT - 2))                                                                                 \
             __syncthreads();                                                                                         \
-            W4_LOAD_A(ANXT, 0, 1 - cp_)                                                                              \
         }                                                                                                            \
         W4_WAIT_B(BCUR, nb_)                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        W4_MFMA(ACUR, BCUR)                                                                                          \
+        if constexpr (t_ < NT - 1) W4_MFMA_LD(ACUR, BCUR, ANXT, t_ + 1, cp_)                                         \
+        else W4_MFMA_LD(ACUR, BCUR, ANXT, 0, 1 - cp_)                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
 #define W4_TAP6(U0)                                                                                                  \
@@ -237,6 +270,8 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
 #undef W4_GLDS
 #undef W4_REQUEST_V
 #undef W4_LOAD_A
+#undef W4_LOAD_A1
+#undef W4_MFMA_LD
 #undef W4_REQUEST_B
 #undef W4_WAIT_B
 #undef W4_WAIT_VM
