@@ -47,38 +47,41 @@ __global__ __launch_bounds__(CI_NTHR) void conv_img_kernel(const float* __restri
     const float* my = in_lds + ((it * CI_HH + ih) * CI_HW + iw) * CI_LS;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
     __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        __syncthreads();
+    // Register double buffer: the global loads of chunk ch + 1 are issued right after chunk ch has been parked in LDS and
+    // stay in flight while chunk ch is multiplied (one exposed load latency per WORKGROUP instead of one per chunk).
+    constexpr int NS = (CI_NPOS * CI_Q + CI_NTHR - 1) / CI_NTHR;
+    constexpr int NW4 = CI_WCH / 4, NWS = (NW4 + CI_NTHR - 1) / CI_NTHR;
+    float4 v[NS], wv[NWS];
+    auto request = [&](int ch) {   // all of a thread's pieces back to back (branch-free, clamped)
         const int c0 = ch * CI_KC;
-        {   // all of a thread's pieces are requested back to back (branch-free, clamped): one exposed latency per chunk
-            constexpr int NS = (CI_NPOS * CI_Q + CI_NTHR - 1) / CI_NTHR;
-            float4 v[NS];
 #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                const int idx = tid + u * CI_NTHR;
-                const int q = idx % CI_Q, gp = gpos[idx < CI_NPOS * CI_Q ? (idx / CI_Q) : 0];
-                const bool ok = idx < CI_NPOS * CI_Q && gp >= 0 && c0 + 4 * q < C;
-                const float4 t4 = *reinterpret_cast<const float4*>(in + (ok ? (long)gp * C + c0 + 4 * q : 0));
-                v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            constexpr int NW4 = CI_WCH / 4, NWS = (NW4 + CI_NTHR - 1) / CI_NTHR;
-            float4 wv[NWS];
-#pragma unroll
-            for (int u = 0; u < NWS; ++u) {
-                const int f = tid + u * CI_NTHR;
-                wv[u] = *reinterpret_cast<const float4*>(wp + (long)ch * CI_WCH + (f < NW4 ? f : 0) * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                const int idx = tid + u * CI_NTHR;
-                if (idx < CI_NPOS * CI_Q) *reinterpret_cast<float4*>(in_lds + (idx / CI_Q) * CI_LS + 4 * (idx % CI_Q)) = v[u];
-            }
-#pragma unroll
-            for (int u = 0; u < NWS; ++u) {
-                const int f = tid + u * CI_NTHR;
-                if (f < NW4) *reinterpret_cast<float4*>(w_lds + f * 4) = wv[u];
-            }
+        for (int u = 0; u < NS; ++u) {
+            const int idx = tid + u * CI_NTHR;
+            const int q = idx % CI_Q, gp = gpos[idx < CI_NPOS * CI_Q ? (idx / CI_Q) : 0];
+            const bool ok = idx < CI_NPOS * CI_Q && gp >= 0 && c0 + 4 * q < C;
+            const float4 t4 = *reinterpret_cast<const float4*>(in + (ok ? (long)gp * C + c0 + 4 * q : 0));
+            v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int u = 0; u < NWS; ++u) {
+            const int f = tid + u * CI_NTHR;
+            wv[u] = *reinterpret_cast<const float4*>(wp + (long)ch * CI_WCH + (f < NW4 ? f : 0) * 4);
+        }
+    };
+    request(0);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();   // the previous chunk's LDS image is no longer read
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int idx = tid + u * CI_NTHR;
+            if (idx < CI_NPOS * CI_Q) *reinterpret_cast<float4*>(in_lds + (idx / CI_Q) * CI_LS + 4 * (idx % CI_Q)) = v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NWS; ++u) {
+            const int f = tid + u * CI_NTHR;
+            if (f < NW4) *reinterpret_cast<float4*>(w_lds + f * 4) = wv[u];
+        }
+        if (ch + 1 < nchunk) request(ch + 1);
         __syncthreads();
 #pragma unroll 1
         for (int dt = 0; dt < 3; ++dt)
