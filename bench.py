@@ -139,8 +139,11 @@ def main():
     import i2v_pipeline
     prefetch = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True), device=dev, enabled=bool(args.pipeline))
 
+    last_z = {}
+
     def decode(z):
         z = z.view(hi - lo, -1)
+        last_z["z"] = z
         seq = gen(x0_d, z)
         while seq.shape[1] < vid_length:
             seq = torch.cat((seq, gen(seq[:, -1].contiguous(), z)), dim=1)
@@ -200,12 +203,19 @@ def main():
     amax = float(out.abs().max())
     if not finite or amax > 1.0:
         raise SystemExit(f"bench.py: invalid output of the timed steps (finite={finite}, max|y|={amax}): tanh frames must lie in [-1, 1]")
+    # the latent the last timed step decoded (computed on the side stream, underneath the previous decoder) must be the one a
+    # serial pass gives, bit for bit
+    z_serial = flow(res_d, emb_d, reverse=True).view(hi - lo, -1)
+    z_ok = bool(torch.equal(z_serial, last_z["z"]))
+    if not z_ok:
+        raise SystemExit("bench.py: the pipelined cINN pass of the last timed step differs from a serial pass on the same inputs")
     flags = gen.native().status()
     if flags:
         raise SystemExit(f"bench.py: the decoder reported status flags {flags} (fp16 range of the split-fp16 operands exceeded)")
     od = out.double()
     output_check = {"finite": finite, "max_abs": amax, "sum": float(od.sum()), "sum_sq": float((od * od).sum()),
-                    "mean_abs": float(od.abs().mean()), "shape": list(out.shape)}
+                    "mean_abs": float(od.abs().mean()), "shape": list(out.shape),
+                    "pipelined_latent_equals_serial": z_ok}
 
     nb = hi - lo
     single_ms = None if args.no_extras else single_call_ms()   # (every rank: the collation inside is a collective)

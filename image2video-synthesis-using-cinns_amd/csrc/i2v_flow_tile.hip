@@ -170,7 +170,9 @@ __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
 struct TailTileArgs {
     const float* P;     // [NST][NRT][2][256] or null (launch in front of the first half-step: no coupling)
     const float* b3;    // [64]: s bias 0..31, t bias 32..63
-    float* x;           // workspace state [NST * 16][64]
+    const float* x;     // workspace state [NST * 16][64] this launch reads ...
+    float* xo;          // ... and the one it writes: NOT the same buffer -- the eight row-group workgroups of a sample tile all
+                        // read the old state, one of them writes the new one, and nothing orders them inside a launch
     float* logdet;      // workspace [NST * 16] or null (reverse pass)
     const FlowIo* io;
     int io_in, io_out;  // read the caller's x instead of the workspace state / also write the caller's outputs
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
         }
         *reinterpret_cast<float2*>(&xs2[nn][e2]) = make_float2(o[0], o[1]);
         if (rq == 0) {
-            *reinterpret_cast<float2*>(a.x + (size_t)b * 64 + e2) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2*>(a.xo + (size_t)b * 64 + e2) = make_float2(o[0], o[1]);
             if (a.io_out && b < a.B) *reinterpret_cast<float2*>(a.io->xout + (size_t)b * 64 + e2) = make_float2(o[0], o[1]);
         }
         if (rq == 0 && a.logdet && tid < 16) {
@@ -387,6 +389,7 @@ FlowTileWs flow_tile_ws(const FlowTilePack& p, int B) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, 256); return r; };
     L.x = take(NST * 16 * 64 * 4);
+    L.x2 = take(NST * 16 * 64 * 4);
     L.logdet = take(NST * 16 * 4);
     L.pre = take((size_t)p.S * NST * p.NRT * 1024);
     L.hA = take(NST * p.NRT * 1024);
@@ -409,7 +412,8 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     const FlowTilePack& p = *c.pack;
     const FlowTileWs L = flow_tile_ws(p, B);
     const int NST = (B + 15) / 16, NRT = p.NRT, HB = p.HB, S = p.S, D = p.depth, N2 = 2 * p.H, nf = c.n_flows;
-    float* x = reinterpret_cast<float*>(ws + L.x);
+    float* xbuf[2] = {reinterpret_cast<float*>(ws + L.x), reinterpret_cast<float*>(ws + L.x2)};   // state, ping-pong per tail launch
+    int xcur = 0;
     float* logdet = reinterpret_cast<float*>(ws + L.logdet);
     float* pre = reinterpret_cast<float*>(ws + L.pre);
     float* hA = reinterpret_cast<float*>(ws + L.hA);
@@ -436,7 +440,8 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
         TailTileArgs t{};
         t.P = coupling ? P : nullptr;
         t.b3 = c.b3 + (size_t)step * 64;
-        t.x = x;
+        t.x = xbuf[xcur]; t.xo = xbuf[xcur ^ 1];
+        xcur ^= 1;
         t.logdet = reverse ? nullptr : logdet;
         t.io = io; t.io_in = first ? 1 : 0; t.io_out = last ? 1 : 0; t.ld_init = first ? 1 : 0;
         t.B = B; t.NST = NST; t.NRT = NRT; t.HB2 = HB / 2; t.reverse = reverse ? 1 : 0;

@@ -748,6 +748,39 @@ def test_generic_flow_chain_and_other_geometries(monkeypatch):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_pipelined_sampling_equals_serial():
+    """i2v_pipeline.LatentPrefetcher: the cINN pass of batch k+1 on a high-priority side stream underneath the decoder of
+    batch k.  The chain's workgroups are then dispatched irregularly between the decoder's -- the situation in which a
+    missing inter-workgroup ordering inside a launch shows (round 3 found one: the row-group workgroups of a tail launch read
+    the state a sibling was already overwriting).  Every latent and every frame must equal the serial loop bit for bit."""
+    import i2v_pipeline
+    from stage1_VAE.modules.decoder import Generator
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    flow = ConditionalFlow(64, 64, 512, 2, 20, conditioning_option="None")
+    flow.load_state_dict(T(synth.flow_state_dict(seed=7, embedding_dim=64)))
+    # full-width decoder: its conv workgroups fill every CU (136 KB LDS each), so the chain's workgroups trickle in one by one
+    gen = Generator({"channel_factor": 64, "z_dim": 64, "upsample_s": [2, 1], "upsample_t": [2, 1], "spectral_norm": True})
+    gen.load_state_dict(T(synth.decoder_state_dict(seed=7, channel_factor=64)))
+    flow, gen = flow.cuda().eval(), gen.cuda().eval()
+    nb, B = 8, 8
+    x0, residual, embed = synth.bench_inputs(nb * B, 64, 64)
+    x0, residual, embed = x0.cuda(), residual.cuda(), embed.cuda()
+    sl = lambda k: slice(k * B, (k + 1) * B)
+    zs = [flow(residual[sl(k)].contiguous(), embed[sl(k)].contiguous(), reverse=True).view(B, -1).clone() for k in range(nb)]
+    seqs = [gen(x0[sl(k)].contiguous(), zs[k]).clone() for k in range(nb)]
+    torch.cuda.synchronize()
+    for trial in range(3):
+        pf = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True))
+        ticket = pf.submit(residual[sl(0)].contiguous(), embed[sl(0)].contiguous())
+        for k in range(nb):
+            z = pf.get(ticket).view(B, -1)
+            if k + 1 < nb:
+                ticket = pf.submit(residual[sl(k + 1)].contiguous(), embed[sl(k + 1)].contiguous())
+            seq = gen(x0[sl(k)].contiguous(), z)
+            assert torch.equal(z, zs[k]), (trial, k, float((z - zs[k]).abs().max()))
+            assert torch.equal(seq, seqs[k]), (trial, k)
+
+
 def test_hl16_range_guard():
     """A checkpoint whose SPADE (1 + gamma) drives activations past the fp16 range: the split-fp16 path must say so
     (sticky flag -> I2VError at the next call), the exact-fp32 mode must keep working."""
