@@ -220,6 +220,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
             (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                        \
         }                                                                                                            \
     }
+    // one row block of them (address arithmetic + two ds_read_b128)
+#define W16_LOAD_A1(o, TAP, VB, wm)                                                                                  \
+    {                                                                                                                \
+        const int r_ = arow[wm] + (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * W16_VROWS;                        \
+        const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                            \
+        (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                                   \
+        (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                            \
+    }
     // B operands of tap TAP of chunk CH (clamped to the last chunk: past the end the stream re-requests harmlessly)
 #define W16_REQUEST_B(q, TAP, CH)                                                                                    \
     {                                                                                                                \
@@ -242,6 +250,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     } else {                                                                                                         \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
             acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+    }
+
+    // the MFMAs of a tap with the NEXT tap's A-operand reads spread between them (round 3): the two waves of a SIMD fall into
+    // step because they share the matrix pipe, so a burst of reads in front of the MFMA block idles the pipe for both
+#define W16_MFMA_LD(o, q, onxt, TAPN, VBN)                                                                           \
+    if (W16_ABLATE & 1) {                                                                                            \
+        W16_LOAD_A(onxt, TAPN, VBN)                                                                                  \
+        W16_MFMA(o, q)                                                                                               \
+    } else {                                                                                                         \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            W16_LOAD_A1(onxt, TAPN, VBN, wm)                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
             acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
@@ -286,16 +313,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
         if (!(W16_ABLATE & 2)) W16_REQUEST_B(BREQ, tn_, ch + cn_)                                                    \
         if constexpr (t_ < 2 && !(W16_ABLATE & 4))                                                                   \
             W16_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_, 1 - cp_, t_)                            \
-        if constexpr (t_ < NT - 1) {                                                                                 \
-            W16_LOAD_A(ANXT, t_ + 1, cp_)                                                                            \
-        } else {                                                                                                     \
+        if constexpr (t_ == NT - 1) {                                                                                \
             W16_WAIT_VM((W16_ABLATE & 2) ? 0 : 2 * (NT - 2))                                                         \
             W16_SYNC()                                                                                               \
-            W16_LOAD_A(ANXT, 0, 1 - cp_)                                                                             \
         }                                                                                                            \
         if (!(W16_ABLATE & 2)) W16_WAIT_B(BCUR, nb_)                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        W16_MFMA(ACUR, BCUR)                                                                                         \
+        if constexpr (t_ < NT - 1) W16_MFMA_LD(ACUR, BCUR, ANXT, t_ + 1, cp_)                                        \
+        else W16_MFMA_LD(ACUR, BCUR, ANXT, 0, 1 - cp_)                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
 #define W16_TAP6(U0)                                                                                                 \
