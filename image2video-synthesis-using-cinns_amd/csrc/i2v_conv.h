@@ -151,6 +151,15 @@ struct ConvImgWeights {
     int pack(const float* w_src, const float* bias_src, int cin);
 };
 bool conv_img_supported(int T, int H, int W, int C);
+// ---- conv_img as a fused matrix-core kernel (per temporal tap a 32 x Cin split-fp16 GEMM over the halo positions of an 8 x 32
+// brick into LDS, then a per-position gather): Cin in {16, 32, 48, 64}, H % 8 == 0, W % 32 == 0
+struct ConvImgMfmaWeights {
+    DevBuf w, bias;  // [dt][Cin/16][hi | lo][64 lanes][8 halfs], bias[3]
+    int Cin = 0;
+    int pack(const float* w_src, const float* bias_src, int cin);
+};
+bool conv_img_mfma_supported(int T, int H, int W, int C);
+int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st);
 // in: fp32 channels-last [B][T][H][W][Cin]; out: frames [B][T][3][H][W] with tanh applied
 int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st);
 

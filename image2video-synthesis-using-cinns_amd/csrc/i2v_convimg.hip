@@ -138,4 +138,154 @@ int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int
     return I2V_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_img on the matrix cores, fused (round 3).  N = 3 cannot fill a 32-wide MFMA tile as an implicit GEMM over positions,
+// but the 27 (dh, dw, n) combinations of ONE temporal tap can: per dt
+//     Y_dt[(dh, dw, n)][p] = sum_c w[n][c][dt][dh][dw] * x[frame t + dt - 1][p][c]        (32 x Cin) x (Cin x positions)
+// is a small split-fp16 GEMM over the halo positions p of an 8 x 32 output brick (A = the padded 32 x Cin weight slab of the
+// tap, B = the activations straight from global memory, converted to fp16 hi / lo in registers), Y_dt is parked in LDS
+// (45 KB) and every thread gathers its own output position:  out[n][h][w] += sum_{dh,dw} Y_dt[(dh,dw,n)][h+dh][w+dw].
+// Three such passes (dt = 0, 1, 2), then bias + tanh and the [B][T][3][H][W] store.  No 81-plane round trip through HBM
+// (the nf >= 64 path of round 2) and no vector-ALU inner loop (nf = 32).
+typedef _Float16 ci_half8 __attribute__((ext_vector_type(8)));
+typedef float ci_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ci_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CM_TH = 8, CM_TW = 32;                 // output brick (one frame)
+constexpr int CM_HH = CM_TH + 2, CM_HW = CM_TW + 2;  // halo 10 x 34 = 340 positions
+constexpr int CM_NP = CM_HH * CM_HW;
+constexpr int CM_NB = (CM_NP + 31) / 32;             // 11 column blocks
+constexpr int CM_LD = CM_NB * 32;                    // 352 columns per plane row
+
+template <int KS>   // KS = Cin / 16 k-steps
+__global__ __launch_bounds__(256) void conv_img_mfma_kernel(const float* __restrict__ in, const ci_half8* __restrict__ wp,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int B, int T,
+                                                            int H, int W) {
+    __shared__ float Y[32 * CM_LD];
+    constexpr int C = 16 * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    int brick = blockIdx.x;
+    const int nbW = W / CM_TW, nbH = H / CM_TH;
+    const int bw = brick % nbW; brick /= nbW;
+    const int bh = brick % nbH; brick /= nbH;
+    const int t = brick % T, b = brick / T;
+    const int h0 = bh * CM_TH, w0 = bw * CM_TW;
+    // the halo positions of this lane's column blocks (blocks wave, wave + 4, wave + 8): offset inside a frame, or -1
+    int gp[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int p = (wave + 4 * u) * 32 + l31;
+        const int ih = p / CM_HW, iw = p - ih * CM_HW;
+        const int h = h0 + ih - 1, w = w0 + iw - 1;
+        const bool ok = wave + 4 * u < CM_NB && p < CM_NP && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        gp[u] = ok ? h * W + w : -1;
+    }
+    const int oh = tid >> 5, ow = tid & 31;              // this thread's output position inside the brick
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    for (int dt = 0; dt < 3; ++dt) {
+        const int tt = t + dt - 1;
+        if ((unsigned)tt >= (unsigned)T) continue;       // (uniform) zero padding in time
+        // A: the tap's weight slab, fragment-major [dt][ks][hi | lo][64 lanes]
+        ci_half8 ah[KS], al[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ah[ks] = wp[((dt * KS + ks) * 2 + 0) * 64 + lane];
+            al[ks] = wp[((dt * KS + ks) * 2 + 1) * 64 + lane];
+        }
+        const float* fr = in + ((size_t)b * T + tt) * H * W * C + 8 * kg;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (wave + 4 * u >= CM_NB) continue;         // (uniform: wave 3 owns two blocks)
+            ci_f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            ci_f32x4 xv[KS][2];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    xv[ks][q] = gp[u] >= 0 ? *reinterpret_cast<const ci_f32x4*>(fr + (size_t)gp[u] * C + 16 * ks + 4 * q)
+                                           : ci_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                ci_half8 bh_, bl_;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = xv[ks][j >> 2][j & 3];
+                    const _Float16 hi = (_Float16)v;
+                    bh_[j] = hi;
+                    bl_[j] = (_Float16)(v - (float)hi);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh_, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl_, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh_, acc, 0, 0, 0);
+            }
+            const int col = (wave + 4 * u) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                Y[row * CM_LD + col] = acc[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const float* y = Y + ((dh * 3 + dw) * 3) * CM_LD + (oh + dh) * CM_HW + ow + dw;
+                o0 += y[0]; o1 += y[CM_LD]; o2 += y[2 * CM_LD];
+            }
+        __syncthreads();   // Y is overwritten by the next temporal tap
+    }
+    const size_t HWo = (size_t)H * W;
+    float* o = out + (((size_t)b * T + t) * 3) * HWo + (size_t)(h0 + oh) * W + w0 + ow;
+    o[0] = tanhf(o0 + bias[0]); o[HWo] = tanhf(o1 + bias[1]); o[2 * HWo] = tanhf(o2 + bias[2]);
+}
+
+int ConvImgMfmaWeights::pack(const float* w_src, const float* bias_src, int cin) {
+    Cin = cin;
+    const int KS = cin / 16;
+    std::vector<_Float16> p((size_t)3 * KS * 2 * 64 * 8, (_Float16)0.f);
+    for (int dt = 0; dt < 3; ++dt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = lane & 31, kgq = lane >> 5;
+                if (row >= 27) continue;
+                const int n = row % 3, dw = (row / 3) % 3, dh = row / 9;
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * ks + 8 * kgq + j;
+                    const float v = w_src[((size_t)n * cin + c) * 27 + dt * 9 + dh * 3 + dw];
+                    const _Float16 hi = (_Float16)v;
+                    p[((((size_t)dt * KS + ks) * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                    p[((((size_t)dt * KS + ks) * 2 + 1) * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
+                }
+            }
+    int rc = w.upload(p.data(), p.size() * 2);
+    if (rc) return rc;
+    return bias.upload(bias_src, 12);
+}
+
+bool conv_img_mfma_supported(int T, int H, int W, int C) {
+    return T >= 1 && H % CM_TH == 0 && W % CM_TW == 0 && (C == 16 || C == 32 || C == 48 || C == 64);
+}
+
+int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st) {
+    I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv_img (MFMA): weights not packed");
+    I2V_REQUIRE(conv_img_mfma_supported(T, H, W, wts.Cin), I2V_E_INVALID, "conv_img (MFMA): unsupported geometry");
+    const long nblk = (long)B * T * (H / CM_TH) * (W / CM_TW);
+    I2V_REQUIRE(nblk < (1L << 31), I2V_E_INVALID, "conv_img (MFMA): %ld workgroups", nblk);
+    const dim3 grid((unsigned)nblk), block(256);
+    const ci_half8* wp = wts.w.as<ci_half8>();
+    switch (wts.Cin / 16) {
+        case 1: hipLaunchKernelGGL(conv_img_mfma_kernel<1>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W); break;
+        case 2: hipLaunchKernelGGL(conv_img_mfma_kernel<2>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W); break;
+        case 3: hipLaunchKernelGGL(conv_img_mfma_kernel<3>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W); break;
+        default: hipLaunchKernelGGL(conv_img_mfma_kernel<4>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W); break;
+    }
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
 }  // namespace i2v

@@ -523,11 +523,12 @@ struct i2v_dec {
     Level lvl[6];
     ConvWeights fc, zlin, conv_img;
     ConvImgWeights conv_img_v;  // vector-ALU variant (used when the output geometry tiles into 4x8x8 bricks)
+    ConvImgMfmaWeights conv_img_m;  // fused matrix-core variant (split-fp16 mode, img16 == 2)
     Conv16Weights conv_img16;   // split-fp16 mode: the 81-column 1x1x1 GEMM of conv_img_gather_kernel
     DevBuf conv_img_bias;
     int Nz = 0;
     int wino = 1;  // 1: 3x3x3 convs whose shape allows it use the Winograd kernel (env I2V_DEC_WINO=0 disables)
-    int img16 = 1;  // 1: split-fp16 mode runs conv_img as 1x1x1 GEMM + gather (env I2V_DEC_IMG16=0: vector-ALU kernel)
+    int img16 = 2;  // split-fp16 mode: 2 fused matrix-core kernel (i2v_convimg.hip), 1 round 2's 81-plane GEMM + gather at nf >= 64, 0 vector-ALU kernel (env I2V_DEC_IMG16)
     int wino4 = 1; // 1: F(4,3) Winograd kernel where the shape allows and one sample gives >= 32 workgroups (env I2V_DEC_WINO4=0: F(2,3); 2: wherever the shape allows)
     int spw = 1;   // 1: SPADE's gamma|beta conv uses the Winograd kernel where the shape allows (env I2V_DEC_SPW=0: direct kernel)
     int pw16 = 1;  // 1: split-fp16 mode runs the shortcut convs on split-fp16 operands too (env I2V_DEC_PW16=0: exact-fp32 MFMA)
@@ -581,7 +582,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
         mx_gb = std::max(mx_gb, (size_t)l.H * l.W * 2 * b.n_in);
         cmax = std::max(cmax, std::max(b.n_in, b.n_mid));
     }
-    if (d->cfg.mma == 1 && d->img16 && d->nf >= 64) mx_a = std::max(mx_a, (size_t)d->lvl[5].T * d->lvl[5].H * d->lvl[5].W * 81);  // conv_img's Y
+    if (d->cfg.mma == 1 && d->img16 == 1 && d->nf >= 64) mx_a = std::max(mx_a, (size_t)d->lvl[5].T * d->lvl[5].H * d->lvl[5].W * 81);  // conv_img's Y
     DecWs L;
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o = align_up(o + floats * 4, 256); return r; };
@@ -991,7 +992,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     if (const char* e = std::getenv("I2V_DEC_WINO")) d->wino = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_WINO4")) d->wino4 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_PW16")) d->pw16 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
     if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
@@ -1115,7 +1116,9 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         if ((rc = d->conv_img_v.pack(w, b, nf))) return rc;
         // (measured: 1.3 vs 1.7 ms per B = 64 BAIR pass at nf = 64, but 0.8 ms SLOWER than the vector-ALU kernel per B = 32
         //  128x128 pass at nf = 32, where the 81 planes outweigh the 32-channel input)
-        if (d->cfg.mma == 1 && d->img16 && nf >= 64 && nf % 4 == 0) {
+        if (d->cfg.mma == 1 && d->img16 == 2 && conv_img_mfma_supported(d->lvl[5].T, d->lvl[5].H, d->lvl[5].W, nf) &&
+            (rc = d->conv_img_m.pack(w, b, nf))) return rc;
+        if (d->cfg.mma == 1 && d->img16 == 1 && nf >= 64 && nf % 4 == 0) {
             std::vector<float> w81((size_t)81 * nf);   // row tap * 3 + n = w[n][:][tap]
             for (int n = 0; n < 3; ++n)
                 for (int c = 0; c < nf; ++c)
@@ -1244,7 +1247,8 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     }
     {
         const Level& l = d->lvl[5];
-        if (d->conv_img16.w.p) {
+        if (d->conv_img_m.w.p) rc = conv_img_mfma_forward(d->conv_img_m, x, out, B, l.T, l.H, l.W, st);
+        else if (d->conv_img16.w.p) {
             const long P = (long)l.T * l.H * l.W, tot = (long)B * P;
             I2V_REQUIRE((tot + 255) / 256 < (1L << 31), I2V_E_INVALID, "conv_img: %ld positions", tot);
             if ((rc = pointwise16_forward(d->conv_img16, x, a, nullptr, tot, P, EPI_NONE, st, nullptr, d->status_dev, true))) return rc;
