@@ -122,7 +122,7 @@ struct Wino4Weights {
     int wexp = 0;
     bool tdup = false;
     long set_bytes = 0;
-    int pack(const float* w_src, const float* bias_src, int cout, int cin, double scale);       // w_src [Cout][Cin][3][3][3]
+    int pack(const float* w_src, const float* bias_src, int cout, int cin, double scale, int kt = 3);   // w_src [Cout][Cin][kt][3][3], kt = 3 or 1
     int pack_tdup(const float* w_src, const float* bias_src, int cout, int cin, double scale);  // from a 3x3x3 kernel
 };
 // T = frames of the tensor V was built from (half the output frames for pack_tdup weights); false = use another kernel

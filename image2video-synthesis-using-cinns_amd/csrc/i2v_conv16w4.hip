@@ -281,7 +281,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
 #undef W4_TAP18R9
 }
 
-// NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3).
+// NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time slice (1x3x3: Conv2d).
 // BN: output channels per workgroup.  64: as described above.  32 (layers with 32 output channels): pass A wave = (plane,
 // tile half) with 2 row blocks, pass B wave = (plane, tile quarter) with 1 row block, one epilogue pass.
 template <int NT, int BN>
@@ -544,7 +544,7 @@ static int wino4_pack_sets(Wino4Weights& o, const std::vector<double>& w3, int n
 
 // brick of 128 tiles = TT frames x TH rows x 4 tiles (16 output positions)
 static bool wino4_tiling(int T, int H, int W, int KT, int* TT_, int* TH_) {
-    if (T < 2 || W % 16 || H < 8) return false;
+    if (T < 1 || (T < 2 && KT != 1) || W % 16 || H < 8) return false;
     int TT = 1;
     while (TT < 4 && T % (TT * 2) == 0) TT *= 2;
     const int TH = W4_TILES / (TT * 4);
@@ -555,16 +555,17 @@ static bool wino4_tiling(int T, int H, int W, int KT, int* TT_, int* TH_) {
 }
 
 bool wino4_supported(int cout, int cin, int T, int H, int W, int KT) {
-    if (cout % 32 || cin % (2 * W4_KC) || (KT != 3 && KT != 2)) return false;
+    if (cout % 32 || cin % (2 * W4_KC) || (KT != 3 && KT != 2 && KT != 1)) return false;
     int TT, TH;
     return wino4_tiling(T, H, W, KT, &TT, &TH);
 }
 
-int Wino4Weights::pack(const float* w_src, const float* bias_src, int cout, int cin, double scale) {
+int Wino4Weights::pack(const float* w_src, const float* bias_src, int cout, int cin, double scale, int kt) {
+    I2V_REQUIRE(kt == 3 || kt == 1, I2V_E_INVALID, "wino4: temporal kernel size %d", kt);
     tdup = false;
-    std::vector<double> w3((size_t)cout * cin * 27);
+    std::vector<double> w3((size_t)cout * cin * kt * 9);
     for (size_t i = 0; i < w3.size(); ++i) w3[i] = (double)w_src[i] * scale;
-    int rc = wino4_pack_sets(*this, w3, 1, cout, cin, 3);
+    int rc = wino4_pack_sets(*this, w3, 1, cout, cin, kt);
     if (rc) return rc;
     if (bias_src) return bias.upload(bias_src, (size_t)cout * 4);
     bias.release();
@@ -633,8 +634,10 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
     if (BN == 64) {
         if (wts.KT == 3) return launch_wino4<9, 64>(a, (unsigned)nblk, lds, st);
-        return launch_wino4<6, 64>(a, (unsigned)nblk, lds, st);
+        if (wts.KT == 2) return launch_wino4<6, 64>(a, (unsigned)nblk, lds, st);
+        return launch_wino4<3, 64>(a, (unsigned)nblk, lds, st);   // one time slice: SPADE's 2-D convs
     }
+    I2V_REQUIRE(wts.KT != 1, I2V_E_INVALID, "wino4: the 1x3x3 variant exists for 64-channel tiles only");
     if (wts.KT == 3) return launch_wino4<9, 32>(a, (unsigned)nblk, lds, st);
     return launch_wino4<6, 32>(a, (unsigned)nblk, lds, st);
 }

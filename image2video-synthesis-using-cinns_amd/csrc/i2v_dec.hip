@@ -504,6 +504,7 @@ struct Block {
     Conv16Weights conv0_16, conv1_16, sp_gb16;  // split-fp16 variants (cfg.mma == 1)
     Conv16Weights convs16;      // the learned shortcut's 1x1x1 conv on split-fp16 operands (pointwise16_forward)
     Wino16Weights sp_gb_w;      // SPADE's fused gamma|beta Conv2d(128, 2C, 3) on the Winograd kernel (1x3x3 variant)
+    Wino4Weights sp_gb_w4;      // ... on the F(4,3) kernel (packed INSTEAD where the shape allows: W % 16 == 0, H % 32 == 0)
     Wino16Weights conv0_w, conv1_w;             // Winograd F(2,3) variants of conv_0 / conv_1 (packed where the shape allows)
     Wino4Weights conv0_w4, conv1_w4;            // Winograd F(4,3) variants (i2v_conv16w4.hip); packed INSTEAD of the F(2,3) ones
     bool tdup0 = false;                          // conv_0 runs on the half-rate tensor (x2 temporal up-sampling in front)
@@ -806,7 +807,11 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
                            B, img_h, img_w, l.H, l.W, d->cfg.mma == 1 ? 1 : 0, d->status_dev);
         I2V_HIP_CHECK(hipGetLastError());
     }
-    if (d->cfg.mma == 1 && b.sp_gb_w.w.p && w.y1v) {
+    if (d->cfg.mma == 1 && b.sp_gb_w4.w.p && w.y1v) {
+        if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
+        if ((rc = run_modulate_wino4(y1, nullptr, nullptr, w.y1v, B, 1, l.H, l.W, 128, 1, 1, 0, st, d->status_dev))) return rc;
+        if ((rc = wino4_forward(b.sp_gb_w4, w.y1v, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st, nullptr))) return rc;
+    } else if (d->cfg.mma == 1 && b.sp_gb_w.w.p && w.y1v) {
         // gamma | beta conv on the Winograd kernel: the 128-channel activation goes through fp32 once more (the operand
         // writer needs the w-neighbours of every position, which the producing conv's epilogue does not hold)
         if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
@@ -1097,7 +1102,10 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         if (d->cfg.mma == 1) rc = b.sp_gb16.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
         else rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
         if (rc) return rc;
-        if (d->cfg.mma == 1 && d->wino && d->spw && wino16_supported(2 * b.n_in, 128, 1, d->lvl[k].H, d->lvl[k].W, 1) &&
+        if (d->cfg.mma == 1 && d->wino && d->spw && d->wino4 && (2 * b.n_in) % 64 == 0 &&
+            wino4_supported(2 * b.n_in, 128, 1, d->lvl[k].H, d->lvl[k].W, 1)) {
+            if ((rc = b.sp_gb_w4.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1.0, 1))) return rc;
+        } else if (d->cfg.mma == 1 && d->wino && d->spw && wino16_supported(2 * b.n_in, 128, 1, d->lvl[k].H, d->lvl[k].W, 1) &&
             (rc = b.sp_gb_w.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 1.0)))
             return rc;
         // ADAIN linear rows into the shared z-GEMM

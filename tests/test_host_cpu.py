@@ -278,7 +278,7 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     import check_asm_waits as caw
     kernels = re.findall(r"^(_ZN3i2v23conv_wino4_f16x3_kernelILi(\d)ELi(\d+)EEEvNS_6W4ArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
                          flags=re.S | re.M)
-    assert len(kernels) == 4, [k[0] for k in kernels]
+    assert len(kernels) == 5, [k[0] for k in kernels]     # <9,64> <6,64> <3,64> (SPADE's 2-D convs) <9,32> <6,32>
     for name, nt, bn, whole in kernels:
         nt = int(nt)
         assert "scratch_" not in whole and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", whole), name
@@ -293,7 +293,8 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
             assert loop.count("s_barrier") == 2, name
             assert caw.check_loop(loop) == [], name
             b_wait, bar_wait = max(waits_of(loop)), min(waits_of(loop))
-            for w in (b_wait, bar_wait):
+            # (3-tap kernels: the chunk barrier's wait, every third tap, already covers the weight ring -- only it is tight)
+            for w in ((b_wait, bar_wait) if nt != 3 else (bar_wait,)):
                 mutated = re.sub(r"s_waitcnt vmcnt\(%d\)" % w, "s_waitcnt vmcnt(%d)" % (w + 1), loop)
                 assert caw.check_loop(mutated) != [], (name, w)
 
