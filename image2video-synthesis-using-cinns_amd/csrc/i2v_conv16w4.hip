@@ -23,6 +23,9 @@
 //   epilogue: per 32-channel half the six partial GEMMs of a tile meet in LDS (98 KB), y = A^T M in fp32, then bias,
 //           residual, optional lrelu, fused per-(b,c) statistics, stores of four positions per tile.
 // Workgroup = 512 threads, 128 tiles = 512 output positions (TT x TH x 16 brick) x 64 output channels.
+// Schedule details measured in round 3: the next tap's A-operand reads are spread between the MFMAs of the current tap (the
+// two waves of a SIMD fall into step because they share the matrix pipe; a burst in front of the MFMA block idles it for
+// both: +4.5..10 %), and pass A requests pass B's first brick behind its own last chunk (no V round trip between the passes).
 // Loads are asm statements with hand-counted waits exactly as in i2v_conv16w.hip (tools/check_asm_waits.py replays both
 // compiled loops of every instantiation).
 #include <algorithm>
