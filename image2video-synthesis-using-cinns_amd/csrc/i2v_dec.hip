@@ -72,14 +72,25 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
 __global__ void coef_kernel(const double* __restrict__ sums, float2* __restrict__ coef, int C, int groups, double count,
                             const float* __restrict__ zl, int zstride, int zoff, const float* __restrict__ gw,
                             const float* __restrict__ gb) {
+    // (the sample's C (sum, sumsq) pairs are staged in LDS first: one memory round trip instead of a chain of C / groups
+    //  dependent ones per thread -- 12-24 us per launch before, 16 launches per decoder pass)
+    __shared__ double ss[1024], qq[1024];
     const int b = blockIdx.x;
     const int cpg = C / groups;
+    const bool staged = C <= 1024;
+    if (staged) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const double2 v = *reinterpret_cast<const double2*>(sums + ((long)b * C + c) * 2);
+            ss[c] = v.x; qq[c] = v.y;
+        }
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int g0 = (c / cpg) * cpg;
         double s = 0, q = 0;
-        for (int j = 0; j < cpg; ++j) {
-            s += sums[((long)b * C + g0 + j) * 2];
-            q += sums[((long)b * C + g0 + j) * 2 + 1];
+        for (int j = 0; j < cpg; ++j) {   // same summation order either way
+            s += staged ? ss[g0 + j] : sums[((long)b * C + g0 + j) * 2];
+            q += staged ? qq[g0 + j] : sums[((long)b * C + g0 + j) * 2 + 1];
         }
         const double n = count * cpg;
         const double mean = s / n;
