@@ -72,9 +72,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
 __global__ void coef_kernel(const double* __restrict__ sums, float2* __restrict__ coef, int C, int groups, double count,
                             const float* __restrict__ zl, int zstride, int zoff, const float* __restrict__ gw,
                             const float* __restrict__ gb) {
-    // (the sample's C (sum, sumsq) pairs are staged in LDS first: one memory round trip instead of a chain of C / groups
-    //  dependent ones per thread -- 12-24 us per launch before, 16 launches per decoder pass)
-    __shared__ double ss[1024], qq[1024];
+    // The sample's C (sum, sumsq) pairs are staged in LDS (one memory round trip instead of a chain of dependent ones), the
+    // per-GROUP totals are formed once per group (not once per channel of the group), in the same summation order.
+    __shared__ double ss[1024], qq[1024], gsum[512], gsq[512];
     const int b = blockIdx.x;
     const int cpg = C / groups;
     const bool staged = C <= 1024;
@@ -84,13 +84,26 @@ __global__ void coef_kernel(const double* __restrict__ sums, float2* __restrict_
             ss[c] = v.x; qq[c] = v.y;
         }
         __syncthreads();
+        if (cpg > 1) {   // (then groups <= 512)
+            for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+                double s = 0, q = 0;
+                for (int j = 0; j < cpg; ++j) { s += ss[g * cpg + j]; q += qq[g * cpg + j]; }
+                gsum[g] = s; gsq[g] = q;
+            }
+            __syncthreads();
+        }
     }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g0 = (c / cpg) * cpg;
         double s = 0, q = 0;
-        for (int j = 0; j < cpg; ++j) {   // same summation order either way
-            s += staged ? ss[g0 + j] : sums[((long)b * C + g0 + j) * 2];
-            q += staged ? qq[g0 + j] : sums[((long)b * C + g0 + j) * 2 + 1];
+        if (staged) {
+            s = cpg > 1 ? gsum[c / cpg] : ss[c];
+            q = cpg > 1 ? gsq[c / cpg] : qq[c];
+        } else {
+            const int g0 = (c / cpg) * cpg;
+            for (int j = 0; j < cpg; ++j) {
+                s += sums[((long)b * C + g0 + j) * 2];
+                q += sums[((long)b * C + g0 + j) * 2 + 1];
+            }
         }
         const double n = count * cpg;
         const double mean = s / n;
