@@ -31,6 +31,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #include "i2v_conv.h"
 
@@ -40,8 +42,32 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef W4_INTERLEAVE
-#define W4_INTERLEAVE 1   // measurement builds: 0 = A-operand reads in one burst in front of the MFMA block (round 2's schedule)
+#ifdef W4_TIMELINE   // measurement builds (tools/conv16w_check): per-workgroup phase stamps, 100 MHz wall clock
+__device__ unsigned long long w4_tl[8192 * 8];
+#define W4_STAMP(i) { if (tid == 0 && blockIdx.x < 8192) w4_tl[blockIdx.x * 8 + (i)] = wall_clock64(); }
+#else
+#define W4_STAMP(i)
+#endif
+#ifdef W4_ABLATE_AL   // measurement builds only (wrong results): the lo halves of the A operands are not read from LDS
+#define W4_ABL_AL(x, y) y
+#else
+#define W4_ABL_AL(x, y) x
+#endif
+#ifdef W4_ABLATE_BL   // measurement builds only (wrong results): the lo weight fragment is loaded from the hi fragment's lines
+#define W4_ABL_BL(x, y) y
+#else
+#define W4_ABL_BL(x, y) x
+#endif
+#ifdef W4_TAPTIME   // measurement builds: time between the starts of consecutive taps, per wave and tap slot (s_memtime, 100 MHz)
+__device__ unsigned long long w4_tt[2 * 8 * 18 * 2];   // [pass][wave][tap slot]{ticks, count}
+#define W4_TT(U)                                                                                                     \
+    {                                                                                                                \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                                \
+        if (lane == 0) { tt_lds[(U)] += (unsigned)(now_ - tt_prev); tt_cnt[(U)] += 1; }                              \
+        tt_prev = now_;                                                                                              \
+    }
+#else
+#define W4_TT(U)
 #endif
 constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
 constexpr int W4_KC = 16;       // input channels per K chunk
@@ -64,6 +90,16 @@ struct W4Args {
     int tofs;           // LDS byte offset of the index tables
 };
 
+// Wave priority inside a chunk.  The two waves of a SIMD share the matrix pipe, arbitrated by priority, then age: at equal
+// priority the older wave (0..3) runs its taps at full speed, the younger one gets the leftover slots, falls ~4 taps behind per
+// chunk, finishes the chunk alone at half the pipe rate while the older one waits ~2000 cycles at the chunk barrier
+// (per-tap timing, -DW4_TAPTIME).  A priority that FALLS with the tap index hands the pipe to whichever wave is behind.
+#ifndef W4_PRIO
+#define W4_PRIO 1
+#endif
+constexpr int w4_prio(int t, int NT) {
+    return NT == 3 ? 3 - t : (t < 6 ? 3 - t / 2 : 0);   // 9 taps: 3 3 2 2 1 1 0 0 0
+}
 constexpr int w4_count(int t, int R, int NT, int h) {
     int n = 0;
     for (int k = 0; k < R; ++k) n += ((t - k - h) % NT + NT) % NT == 0;
@@ -79,7 +115,7 @@ constexpr int w4_count(int t, int R, int NT, int h) {
 // buffer pass B reads first, so that pass B (PRE = true) starts without a V round trip.
 template <int NT, int WM, int VH, bool PRE>
 __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* gpos, const int* gposN, f32x16 (&acc)[WM],
-                                        int (&arow)[WM], const char* wlane, int HH, int tid, int lane, int wave) {
+                                        int (&arow)[WM], const char* wfrag, int HH, int tid, int lane, int wave) {
     constexpr int VROWS = VH * 2 * 128;
     const int kg = lane >> 5;
     char* v_lds = smem;
@@ -91,6 +127,13 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     const int* gqn = gposN + (tid >> 2);
     const long vpiece = (long)((tid & 3) ^ ((tid >> 4) & 3)) * 16;
     const long vchunk = (long)6 * a.H * a.J * 64;        // bytes between the K chunks of one frame
+    const unsigned wofs = lane * 16;                     // the lane's piece of a weight fragment (the rest of the address is scalar)
+    {   // the fragment base goes into the loads' scalar address operand: make its uniformity explicit
+        const unsigned long w_ = (unsigned long)wfrag;
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w_);          // (the builtin returns int:
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w_ >> 32));  //  no sign extension)
+        wfrag = reinterpret_cast<const char*>((unsigned long)lo_ | ((unsigned long)hi_ << 32));
+    }
 #define W4_GLDS(src_, dst_)                                                                                          \
     {                                                                                                                \
         unsigned keep_;                                                                                              \
@@ -105,81 +148,72 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         _Pragma("unroll") for (int u = 0; u < VH; ++u) gp_[u] = gt_[128 * (VH * (HF) + u)];                          \
         const char* vb_ = a.in + (long)(nx_ ? 0 : (ch_)) * vchunk + vpiece;                                          \
         _Pragma("unroll") for (int u = 0; u < VH; ++u) {                                                             \
-            const char* s_ = gp_[u] >= 0 ? vb_ + (long)gp_[u] * 64 : a.zeros;                                        \
+            const char* s_ = gp_[u] >= 0 ? vb_ + (long)gp_[u] * 64 : a.zeros;                     \
             W4_GLDS(s_, vdst + (unsigned)((VB) * (VROWS * 64) + (VH * (HF) + u) * 8192))                             \
         }                                                                                                            \
     }
     struct AOps { half8 ah[WM], al[WM]; };
     struct BOps { half8 bh, bl; };
     AOps a0, a1;
+    int adn[WM];
     constexpr int R = NT == 9 ? 9 : 6;
     BOps bq0, bq1, bq2, bq3, bq4, bq5, bq6, bq7, bq8;
-#define W4_LOAD_A(o, TAP, VB)                                                                                        \
-    {                                                                                                                \
-        const int d_ = (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * VROWS;                                       \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
-            const int r_ = arow[wm] + d_;                                                                            \
-            const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                        \
-            (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                               \
-            (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                        \
-        }                                                                                                            \
-    }
-    /* one row block of the A operands (address arithmetic + two ds_read_b128) */                                   \
-#define W4_LOAD_A1(o, TAP, VB, wm)                                                                                   \
+    /* LDS address of one row block of the A operands, and its two ds_read_b128 */
+#define W4_ADDR_A(TAP, VB, wm)                                                                                       \
     {                                                                                                                \
         const int r_ = arow[wm] + (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * VROWS;                            \
-        const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                            \
-        (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                                   \
-        (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                            \
+        adn[wm] = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                                  \
     }
+#define W4_READ_A(o, wm)                                                                                             \
+    {                                                                                                                \
+        (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + adn[wm]);                                               \
+        W4_ABL_AL((o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (adn[wm] ^ 16)), (o).al[wm] = (o).ah[wm]);    \
+    }
+#define W4_LOAD_A(o, TAP, VB)                                                                                        \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+            W4_ADDR_A(TAP, VB, wm)                                                                                   \
+            W4_READ_A(o, wm)                                                                                         \
+        }                                                                                                            \
+    }
+    /* weight fragments of one tap: scalar base + the lane's 16 bytes */                                            \
 #define W4_REQUEST_B(q, TAP, CH)                                                                                     \
     {                                                                                                                \
         const int c_ = (CH) < a.nchunk ? (CH) : a.nchunk - 1;                                                        \
-        const char* p_ = wlane + (long)(TAP) * wtap_stride + (long)c_ * cstride;                                     \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"((q).bh) : "v"(p_));                                   \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=&v"((q).bl) : "v"(p_));                       \
+        const char* p_ = wfrag + (long)(TAP) * wtap_stride + (long)c_ * cstride;                                     \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"((q).bh) : "v"(wofs), "s"(p_));                         \
+        W4_ABL_BL(asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"((q).bl) : "v"(wofs), "s"(p_)),   \
+                  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"((q).bl) : "v"(wofs), "s"(p_)));              \
     }
 #define W4_WAIT_B(q, N) asm volatile("s_waitcnt vmcnt(%2)" : "+v"((q).bh), "+v"((q).bl) : "n"(N));
 #define W4_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-// the MFMAs of a tap with the NEXT tap's A-operand reads spread between them: the two waves of a SIMD fall into step (they
-// share the matrix pipe), so whatever a wave issues outside its MFMA block is time the pipe idles for both
-#if W4_INTERLEAVE
-#define W4_MFMA_LD(o, q, onxt, TAPN, VBN)                                                                            \
+    // The 3 WM MFMAs of a tap with everything else this wave has to issue for the NEXT taps in the 32-cycle shadows between
+    // them, one small piece per gap: an in-order wave that issues its MFMAs back to back sits blocked on the pipe, and whatever
+    // it issues outside the MFMA block is time the pipe idles unless the partner wave happens to have an MFMA ready (per-tap
+    // timing: a wave running alone reached 54 % of the pipe, the pair 66-76 %).  Pieces: per row block the LDS address
+    // arithmetic and the two ds_read_b128 of the next tap's A operands, then the weight request of tap U + R - 1.
+#define W4_MFMA_SPREAD(o, q, onxt, TAPN, VBN, QREQ, TAPR, CHR)                                                       \
     {                                                                                                                \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+        _Pragma("unroll") for (int i = 0; i < 3 * WM; ++i) {                                                         \
+            const int wm_ = i % WM, term_ = i / WM;                                                                  \
+            acc[wm_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term_ == 2 ? (o).al[wm_] : (o).ah[wm_],                \
+                                                              term_ == 1 ? (q).bl : (q).bh, acc[wm_], 0, 0, 0);      \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
-            W4_LOAD_A1(onxt, TAPN, VBN, wm)                                                                          \
+            if (WM >= 2) {                                                                                           \
+                if (i < 2 * WM && (i & 1) == 0) W4_ADDR_A(TAPN, VBN, i / 2)                                          \
+                if (i < 2 * WM && (i & 1) == 1) W4_READ_A(onxt, i / 2)                                               \
+                if (i == 2 * WM) W4_REQUEST_B(QREQ, TAPR, CHR)                                 \
+            } else {                                                                                                 \
+                if (i == 0) W4_ADDR_A(TAPN, VBN, 0)                                                                  \
+                if (i == 1) W4_READ_A(onxt, 0)                                                                       \
+                if (i == 2) W4_REQUEST_B(QREQ, TAPR, CHR)                                      \
+            }                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
-    }
-#else
-#define W4_MFMA_LD(o, q, onxt, TAPN, VBN)                                                                            \
-    {                                                                                                                \
-        W4_LOAD_A(onxt, TAPN, VBN)                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        W4_MFMA(o, q)                                                                                                \
-    }
-#endif
-#define W4_MFMA(o, q)                                                                                                \
-    {                                                                                                                \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
     }
 
-    if constexpr (!PRE) {
-        __syncthreads();  // tables written
-        W4_REQUEST_V(0, 0, 0)
-        W4_REQUEST_V(0, 0, 1)
-    }
+    // prologue: the first R-1 weight requests do not need the index tables; everything requested here has landed before the
+    // loop starts (the wait counts inside the loop assume the steady state and would under-wait in the first taps otherwise)
     W4_REQUEST_B(bq0, 0 % NT, 0 / NT)
     W4_REQUEST_B(bq1, 1 % NT, 1 / NT)
     W4_REQUEST_B(bq2, 2 % NT, 2 / NT)
@@ -190,21 +224,52 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         W4_REQUEST_B(bq6, 6 % NT, 6 / NT)
         W4_REQUEST_B(bq7, 7 % NT, 7 / NT)
     }
-    W4_WAIT_VM(2 * (R - 1))   // the V brick of chunk 0 (the B loads behind it stay in flight)
+    if constexpr (!PRE) {
+        __syncthreads();  // tables written
+        W4_REQUEST_V(0, 0, 0)
+        W4_REQUEST_V(0, 0, 1)
+    }
+    if constexpr (R == 9) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
+                       "+v"(bq3.bl), "+v"(bq4.bh), "+v"(bq4.bl), "+v"(bq5.bh), "+v"(bq5.bl), "+v"(bq6.bh), "+v"(bq6.bl),
+                       "+v"(bq7.bh), "+v"(bq7.bl)
+                     :
+                     : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
+                       "+v"(bq3.bl), "+v"(bq4.bh), "+v"(bq4.bl)
+                     :
+                     : "memory");
+    }
     __syncthreads();
+    W4_STAMP(PRE ? 3 : 1)
     W4_LOAD_A(a0, 0, 0)
+#ifdef W4_TAPTIME
+    unsigned* tt_lds = reinterpret_cast<unsigned*>(smem + 150 * 1024) + ((PRE ? 8 : 0) + wave) * 36;
+    unsigned* tt_cnt = tt_lds + 18;
+    if (lane < 36) tt_lds[lane] = 0;
+    unsigned long long tt_prev = __builtin_readcyclecounter();
+#endif
 
-    // Tap U of a chunk pair: see i2v_conv16w.hip.  Younger than B(U): the B requests of taps U-R+2 .. U (2 (R-1) loads) and
-    // the V half-requests (VH loads each) of every chunk's taps 0 and 1 among taps U-(R-1) .. U.
+    // Tap U of a chunk pair.  Program order of a tap: [V half-request of the next chunk (taps 0, 1)] [chunk barrier (last tap)]
+    // [wait for this tap's weights] [MFMAs, between them: next tap's A operands, then the weight request of tap U + R - 1].
+    // Younger than the weight request of tap U (issued in the middle of tap U - R + 1): the weight requests of taps
+    // U-R+2 .. U-1 (2 (R-2) loads) and the V half-requests (VH loads each) of every chunk's taps 0 and 1 among taps
+    // U-R+2 .. U.  At a chunk's last tap the next chunk's brick must have landed: younger than its second half-request (start
+    // of tap 1) are the weight requests of taps 1 .. NT-2.
 #define W4_TAP(U, ACUR, ANXT, BCUR, BREQ)                                                                            \
     {                                                                                                                \
         constexpr int cp_ = (U) / NT, t_ = (U) % NT;                                                                 \
         constexpr int un_ = (U) + R - 1, cn_ = un_ / NT, tn_ = un_ % NT;                                             \
-        constexpr int ng_ = w4_count(t_, R, NT, 0) + w4_count(t_, R, NT, 1 % NT);                                    \
-        constexpr int nb_ = 2 * (R - 1) + VH * ng_;                                                                  \
+        constexpr int ng_ = w4_count(t_, R - 1, NT, 0) + w4_count(t_, R - 1, NT, 1 % NT);                            \
+        constexpr int nb_ = 2 * (R - 2) + VH * ng_;                                                                  \
+        W4_TT(U)                                                                                                     \
+        if constexpr (W4_PRIO && (t_ == 0 || w4_prio(t_, NT) != w4_prio(t_ - 1, NT)))                                \
+            __builtin_amdgcn_s_setprio(w4_prio(t_, NT));                                                             \
         if constexpr (WM >= 2) asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[WM - 2]), "+v"(arow[WM - 1])); \
         else asm volatile("" : "+v"(arow[0]));                                                                       \
-        W4_REQUEST_B(BREQ, tn_, ch + cn_)                                                                            \
         if constexpr (t_ < 2)                                                                                        \
             W4_REQUEST_V(ch + cp_ + 1, 1 - cp_, t_)                                                                  \
         if constexpr (t_ == NT - 1) {                                                                                \
@@ -213,9 +278,8 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         }                                                                                                            \
         W4_WAIT_B(BCUR, nb_)                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if constexpr (t_ < NT - 1) W4_MFMA_LD(ACUR, BCUR, ANXT, t_ + 1, cp_)                                         \
-        else W4_MFMA_LD(ACUR, BCUR, ANXT, 0, 1 - cp_)                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if constexpr (t_ < NT - 1) W4_MFMA_SPREAD(ACUR, BCUR, ANXT, t_ + 1, cp_, BREQ, tn_, ch + cn_)                \
+        else W4_MFMA_SPREAD(ACUR, BCUR, ANXT, 0, 1 - cp_, BREQ, tn_, ch + cn_)                                       \
     }
 #define W4_TAP6(U0)                                                                                                  \
     {                                                                                                                \
@@ -255,6 +319,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
             if constexpr (NT >= 6) W4_TAP6(6)
         }
     }
+    if constexpr (W4_PRIO) __builtin_amdgcn_s_setprio(0);
     // the stream's harmless last requests (LDS-DMA included) must land before LDS and the ring's registers are reused
     if constexpr (R == 9) {
         asm volatile("s_waitcnt vmcnt(0)"
@@ -270,15 +335,21 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
                      :
                      : "memory");
     }
+#ifdef W4_TAPTIME
+    if (lane < 18) {
+        atomicAdd(&w4_tt[(((PRE ? 8 : 0) + wave) * 18 + lane) * 2], (unsigned long long)tt_lds[lane]);
+        atomicAdd(&w4_tt[(((PRE ? 8 : 0) + wave) * 18 + lane) * 2 + 1], (unsigned long long)tt_cnt[lane]);
+    }
+#endif
 #undef W4_GLDS
 #undef W4_REQUEST_V
 #undef W4_LOAD_A
-#undef W4_LOAD_A1
-#undef W4_MFMA_LD
+#undef W4_ADDR_A
+#undef W4_READ_A
+#undef W4_MFMA_SPREAD
 #undef W4_REQUEST_B
 #undef W4_WAIT_B
 #undef W4_WAIT_VM
-#undef W4_MFMA
 #undef W4_TAP
 #undef W4_TAP6
 #undef W4_TAP18R9
@@ -296,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 5, l31 = lane & 31;
+    W4_STAMP(0)
 
     // tile order and the XCDs: as in i2v_conv16w.hip (all workgroups reading the same V brick on one XCD, consecutively)
     const int nNt = a.CoutPad / BN;
@@ -352,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         const int xg = pb ? 4 + x : x;
         (pb ? gposB : gposA)[rr] = ok ? ((((b0 * a.T + t) * a.nchunk * 6 + xg) * a.H + h) * a.J + j) : -1;  // chunk 0; 64-byte rows
     }
-    const char* wbase = a.wp + (long)par * a.wset_stride + lane * 16;
+    const char* wbase = a.wp + (long)par * a.wset_stride;   // wave-uniform; the lane's 16 bytes are added by the load
     const int nblk = a.CoutPad >> 5;
 
     // ---- pass A: planes 0..3, wave = (plane, 32-channel half), all 128 tiles   [BN = 32: (plane, tile half)]
@@ -371,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         }
         w4_pass<NT, WMA, 4, false>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid, lane, wave);
     }
+    W4_STAMP(2)
     // ---- pass B: planes 4, 5, wave = (plane, 32-channel half, tile half)   [BN = 32: (plane, tile quarter)]
     const int xb = wave & 1, nhb = BN == 64 ? (wave >> 1) & 1 : 0, mhb = BN == 64 ? (wave >> 2) * 64 : (wave >> 1) * 32;
     f32x16 accB[WMB];
@@ -389,6 +462,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         //  own request behind ITS last chunk re-reads its chunk 0 harmlessly)
         w4_pass<NT, WMB, 2, true>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid, lane, wave);
     }
+    W4_STAMP(4)
 
     // ---- epilogue, one 32-channel half at a time: E = [6 planes][128 tiles][32 channels] fp32 (98 KB)
     constexpr int NQ = 8, TPI = 64, NIT = 2;
@@ -498,6 +572,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                 atomicAdd(dst + 1, s1);
             }
         }
+        W4_STAMP(5 + half)
     }
 }
 
@@ -629,12 +704,21 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     a.TT = TT; a.TH = TH; a.TJ = 4; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = a.J / 4;
     const int body = 2 * W4_ROWS_A * 64;   // two V bricks of pass A (pass B and the epilogue's exchange buffer reuse them)
     a.tofs = body;
+#ifdef W4_TAPTIME
+    const size_t lds = 160 * 1024;
+#else
     const size_t lds = (size_t)body + (size_t)(2 * W4_ROWS_A) * 4 + W4_TILES * 4 + W4_TILES * 16;
+#endif
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino4: LDS %zu bytes", lds);
     I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
     const int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
+    if (getenv("I2V_W4_TRACE")) {
+        fprintf(stderr, "wino4: B %d T %d H %d W %d Cin %d Cout %d pad %d KT %d tdup %d TT %d TH %d res %p rt %d rs %d stats %p epi %d nblk %ld lds %zu\n", B, T, H, W,
+                a.Cin, a.Cout, a.CoutPad, wts.KT, a.tdup, TT, TH, (const void*)res, a.rt, a.rs, (void*)stats, epi, nblk, lds);
+        (void)hipDeviceSynchronize();
+    }
     if (BN == 64) {
         if (wts.KT == 3) return launch_wino4<9, 64>(a, (unsigned)nblk, lds, st);
         if (wts.KT == 2) return launch_wino4<6, 64>(a, (unsigned)nblk, lds, st);
@@ -644,5 +728,43 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     if (wts.KT == 3) return launch_wino4<9, 32>(a, (unsigned)nblk, lds, st);
     return launch_wino4<6, 32>(a, (unsigned)nblk, lds, st);
 }
+
+#ifdef W4_TAPTIME
+void w4_taptime_report() {
+    std::vector<unsigned long long> h(2 * 8 * 18 * 2);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(w4_tt), h.size() * 8);
+    for (int p = 0; p < 2; ++p) {
+        printf("   pass %c: mean ticks (10 ns) from the start of tap slot U-1 to the start of tap slot U, per wave\n", p ? 'B' : 'A');
+        for (int w = 0; w < 8; ++w) {
+            printf("      wave %d:", w);
+            for (int u = 0; u < 18; ++u) {
+                const unsigned long long t = h[((p * 8 + w) * 18 + u) * 2], c = h[((p * 8 + w) * 18 + u) * 2 + 1];
+                printf(" %5.1f", c ? (double)t / (double)c : 0.0);
+            }
+            printf("\n");
+        }
+    }
+}
+#endif
+
+#ifdef W4_TIMELINE
+void w4_timeline_report(unsigned nwg) {
+    if (nwg > 8192) nwg = 8192;
+    std::vector<unsigned long long> h(8192 * 8);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(w4_tl), h.size() * 8);
+    const char* nm[6] = {"tables + first V brick", "pass A loop", "hand-over to pass B", "pass B loop", "epilogue half 0", "epilogue half 1"};
+    double sum[6] = {}, tot = 0;
+    unsigned long long lo = ~0ull, hi = 0;
+    for (unsigned w = 0; w < nwg; ++w) {
+        const unsigned long long* t = &h[w * 8];
+        for (int i = 0; i < 6; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+        tot += (double)(t[6] - t[0]);
+        lo = std::min(lo, t[0]); hi = std::max(hi, t[6]);
+    }
+    printf("   F(4,3) timeline over %u workgroups (us, 100 MHz clock): total %.2f per workgroup; kernel span %.1f = %.2f per workgroup slot of 256 CUs\n",
+           nwg, tot / nwg / 100.0, (double)(hi - lo) / 100.0, (double)(hi - lo) / 100.0 / (nwg / 256.0));
+    for (int i = 0; i < 6; ++i) printf("      %-24s %7.2f\n", nm[i], sum[i] / nwg / 100.0);
+}
+#endif
 
 }  // namespace i2v

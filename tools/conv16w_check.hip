@@ -12,6 +12,12 @@
 #include "i2v_conv.h"
 
 using namespace i2v;
+#ifdef W4_TAPTIME
+namespace i2v { void w4_taptime_report(); }
+#endif
+#ifdef W4_TIMELINE
+namespace i2v { void w4_timeline_report(unsigned nwg); }
+#endif
 
 static inline void split(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
@@ -44,9 +50,16 @@ int main(int argc, char** argv) {
     }
     if (rc) { printf("packw: %s\n", i2v_last_error()); return 1; }
     if (!wino16_supported(Cout, Cin, Ti, H, W, T == 1 && !tdup ? 1 : tdup ? 2 : 3)) { printf("shape not supported by the Winograd kernel\n"); return 1; }
-    const bool do4 = wino4_supported(Cout, Cin, Ti, H, W, tdup ? 2 : 3) && !(T == 1 && !tdup);
+    const bool one = T == 1 && !tdup;
+    const bool do4 = wino4_supported(Cout, Cin, Ti, H, W, one ? 1 : tdup ? 2 : 3);
     Wino4Weights w4;
     if (do4) {
+        if (one) {
+            std::vector<float> w1((size_t)Cout * Cin * 9);
+            for (size_t nc = 0; nc < (size_t)Cout * Cin; ++nc)
+                for (int k = 0; k < 9; ++k) w1[nc * 9 + k] = w[nc * 27 + 9 + k];
+            rc = w4.pack(w1.data(), bias.data(), Cout, Cin, 0.7, 1);
+        } else
         rc = tdup ? w4.pack_tdup(w.data(), bias.data(), Cout, Cin, 0.7) : w4.pack(w.data(), bias.data(), Cout, Cin, 0.7);
         if (rc) { printf("pack4: %s\n", i2v_last_error()); return 1; }
     }
@@ -232,6 +245,12 @@ int main(int argc, char** argv) {
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         ms /= n;
         printf("   %-8s %8.3f ms  %7.1f TFLOP/s algorithmic\n", which == 2 ? "F(4,3)" : which ? "F(2,3)" : "direct", ms, flops / ms / 1e9);
+#ifdef W4_TAPTIME
+        if (which == 2) w4_taptime_report();
+#endif
+#ifdef W4_TIMELINE
+        if (which == 2) w4_timeline_report((unsigned)((size_t)B * T * H * W / 512 * ((Cout + 63) / 64)));
+#endif
     }
     return 0;
 }
