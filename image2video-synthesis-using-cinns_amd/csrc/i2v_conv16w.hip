@@ -71,6 +71,8 @@ constexpr int w16_count(int t, int R, int NT, int h) {
     return n;
 }
 
+constexpr int w16_prio(int t, int NT) { return NT == 3 ? 3 - t : (t < 6 ? 3 - t / 2 : 0); }   // 9 taps: 3 3 2 2 1 1 0 0 0
+
 #ifndef W16_RING9
 #define W16_RING9 1   // measurement builds: 0 = six-slot B ring for the 9-tap kernel too
 #endif
@@ -171,7 +173,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     // two coalesced 1 KB loads straight into registers (no LDS staging, no barrier)
     const long cstride = (long)a.CoutPad * 256;          // bytes per (tap, chunk): 4 x x CoutPad x 64
     const long wtap_stride = (long)a.nchunk * cstride;
-    const char* wlane = a.wp + (long)par * a.wset_stride + ((long)xi * (a.CoutPad >> 5) + (n0 >> 5) + nh) * 2048 + lane * 16;
+    // (the fragment address is scalar -- it goes into the loads' SGPR base operand -- plus the lane's 16 bytes)
+    const char* wfrag;
+    {
+        const unsigned long w_ = (unsigned long)(a.wp + (long)par * a.wset_stride + ((long)xi * (a.CoutPad >> 5) + (n0 >> 5) + nh) * 2048);
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w_);          // (the builtin returns int:
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w_ >> 32));  //  no sign extension)
+        wfrag = reinterpret_cast<const char*>((unsigned long)lo_ | ((unsigned long)hi_ << 32));
+    }
+    const unsigned wofs = lane * 16;
 
     // V staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  Piece idx = tid + 512 u
     // (u < 8) -> LDS row (tid >> 2) + 128 u; a wave's instruction fills 1 KB = 16 rows, lane i at base + 16 i, so the LDS
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
         _Pragma("unroll") for (int u = 0; u < 4; ++u) gp_[u] = gq[128 * (4 * (HF) + u)];                             \
         const char* vb_ = a.in + (long)(ch_) * vchunk + vpiece;                                                      \
         _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                              \
-            const char* s_ = gp_[u] >= 0 ? vb_ + (long)((W16_ABLATE & 16) ? gp_[u] & 0xfff : gp_[u]) * 64 : a.zeros; \
+            const char* s_ = gp_[u] >= 0 ? vb_ + (long)gp_[u] * 64 : a.zeros; \
             W16_GLDS(s_, vdst + (unsigned)((VB) * (W16_VROWS * 64) + (4 * (HF) + u) * 8192))                         \
         }                                                                                                            \
     }
@@ -205,79 +215,60 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
     struct AOps { half8 ah[WM], al[WM]; };
     struct BOps { half8 bh, bl; };
     AOps a0, a1;
+    int adn[WM];
     // ring of the B operands of R consecutive taps (requested R - 1 taps ahead).  R = 9 for the 9-tap kernel: no B request
     // younger than a chunk's V request is consumed before the chunk's barrier, so the V brick has the whole chunk to land.
     constexpr int R = (NT == 9 && W16_RING9) ? 9 : 6;
     BOps bq0, bq1, bq2, bq3, bq4, bq5, bq6, bq7, bq8;
-    // A operands of tap TAP (compile-time) from V brick VB
-#define W16_LOAD_A(o, TAP, VB)                                                                                       \
-    {                                                                                                                \
-        const int d_ = (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * W16_VROWS;                                   \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
-            const int r_ = arow[wm] + d_;                                                                            \
-            const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                        \
-            (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                               \
-            (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                        \
-        }                                                                                                            \
-    }
-    // one row block of them (address arithmetic + two ds_read_b128)
-#define W16_LOAD_A1(o, TAP, VB, wm)                                                                                  \
+    // A operands of tap TAP (compile-time) from V brick VB: LDS address of one row block, and its two ds_read_b128
+#define W16_ADDR_A(TAP, VB, wm)                                                                                      \
     {                                                                                                                \
         const int r_ = arow[wm] + (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * W16_VROWS;                        \
-        const int ad_ = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                            \
-        (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + ad_);                                                   \
-        (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (ad_ ^ 16));                                            \
+        adn[wm] = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                                  \
+    }
+#define W16_READ_A(o, wm)                                                                                            \
+    {                                                                                                                \
+        (o).ah[wm] = *reinterpret_cast<const half8*>(v_lds + adn[wm]);                                               \
+        (o).al[wm] = *reinterpret_cast<const half8*>(v_lds + (adn[wm] ^ 16));                                        \
+    }
+#define W16_LOAD_A(o, TAP, VB)                                                                                       \
+    {                                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+            W16_ADDR_A(TAP, VB, wm)                                                                                  \
+            W16_READ_A(o, wm)                                                                                        \
+        }                                                                                                            \
     }
     // B operands of tap TAP of chunk CH (clamped to the last chunk: past the end the stream re-requests harmlessly)
 #define W16_REQUEST_B(q, TAP, CH)                                                                                    \
     {                                                                                                                \
         const int c_ = (CH) < a.nchunk ? (CH) : a.nchunk - 1;                                                        \
-        const char* p_ = wlane + (long)(TAP) * wtap_stride + (long)c_ * cstride;                                     \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"((q).bh) : "v"(p_));                                   \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=&v"((q).bl) : "v"(p_));                       \
+        const char* p_ = wfrag + (long)(TAP) * wtap_stride + (long)c_ * cstride;                                     \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"((q).bh) : "v"(wofs), "s"(p_));                         \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"((q).bl) : "v"(wofs), "s"(p_));             \
     }
     // B operands of the current tap have landed when at most N younger loads are outstanding (loads return in order)
 #define W16_WAIT_B(q, N) asm volatile("s_waitcnt vmcnt(%2)" : "+v"((q).bh), "+v"((q).bl) : "n"(N));
 #define W16_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#ifndef W16_ABLATE
-#define W16_ABLATE 0   // measurement builds only (tools/conv16w_check): 1 no MFMAs, 2 no weight traffic, 4 no V staging, 8 no barriers, 16 V rows wrapped into a 256 KB window per chunk (L2 hits)
-#endif
-#define W16_SYNC() { if (!(W16_ABLATE & 8)) __syncthreads(); }
-#define W16_MFMA(o, q)                                                                                               \
-    if (W16_ABLATE & 1) {                                                                                            \
-        asm volatile("" :: "v"((o).ah[0]), "v"((o).al[0]), "v"((q).bh), "v"((q).bl), "v"((o).ah[1]), "v"((o).al[1]), \
-                     "v"((o).ah[WM - 2]), "v"((o).al[WM - 2]), "v"((o).ah[WM - 1]), "v"((o).al[WM - 1]));            \
-    } else {                                                                                                         \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
-    }
 
-    // the MFMAs of a tap with the NEXT tap's A-operand reads spread between them (round 3): the two waves of a SIMD fall into
-    // step because they share the matrix pipe, so a burst of reads in front of the MFMA block idles the pipe for both
-#define W16_MFMA_LD(o, q, onxt, TAPN, VBN)                                                                           \
-    if (W16_ABLATE & 1) {                                                                                            \
-        W16_LOAD_A(onxt, TAPN, VBN)                                                                                  \
-        W16_MFMA(o, q)                                                                                               \
-    } else {                                                                                                         \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bh, acc[wm], 0, 0, 0);                  \
+    // The 3 WM MFMAs of a tap with everything else the wave issues for the NEXT taps in the 32-cycle shadows between them, one
+    // small piece per gap (see i2v_conv16w4.hip, where the per-tap timing behind this schedule was taken): per row block the
+    // LDS address arithmetic and the two ds_read_b128 of the next tap's A operands, then the weight request of tap U + R - 1.
+#define W16_MFMA_SPREAD(o, q, onxt, TAPN, VBN, QREQ, TAPR, CHR)                                                      \
+    {                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 3 * WM; ++i) {                                                         \
+            const int wm_ = i % WM, term_ = i / WM;                                                                  \
+            acc[wm_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term_ == 2 ? (o).al[wm_] : (o).ah[wm_],                \
+                                                              term_ == 1 ? (q).bl : (q).bh, acc[wm_], 0, 0, 0);      \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
-            W16_LOAD_A1(onxt, TAPN, VBN, wm)                                                                         \
+            if (i < 2 * WM && (i & 1) == 0) W16_ADDR_A(TAPN, VBN, i / 2)                                             \
+            if (i < 2 * WM && (i & 1) == 1) W16_READ_A(onxt, i / 2)                                                  \
+            if (i == 2 * WM) W16_REQUEST_B(QREQ, TAPR, CHR)                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (q).bl, acc[wm], 0, 0, 0);                  \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                            \
-            acc[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (q).bh, acc[wm], 0, 0, 0);                  \
     }
 
-    __syncthreads();  // tables
-    W16_REQUEST_V(0, 0, 0)
-    W16_REQUEST_V(0, 0, 1)
+    // prologue: the first R-1 weight requests do not need the index tables; everything requested here has landed before the
+    // loop starts (the wait counts inside the loop assume the steady state and would under-wait in the first taps otherwise)
     W16_REQUEST_B(bq0, 0 % NT, 0 / NT)
     W16_REQUEST_B(bq1, 1 % NT, 1 / NT)
     W16_REQUEST_B(bq2, 2 % NT, 2 / NT)
@@ -288,40 +279,59 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
         W16_REQUEST_B(bq6, 6 % NT, 6 / NT)
         W16_REQUEST_B(bq7, 7 % NT, 7 / NT)
     }
-    W16_WAIT_VM(2 * (R - 1))   // the V brick of chunk 0 (the B loads behind it stay in flight)
+    __syncthreads();  // tables
+    W16_REQUEST_V(0, 0, 0)
+    W16_REQUEST_V(0, 0, 1)
+    if constexpr (R == 9) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
+                       "+v"(bq3.bl), "+v"(bq4.bh), "+v"(bq4.bl), "+v"(bq5.bh), "+v"(bq5.bl), "+v"(bq6.bh), "+v"(bq6.bl),
+                       "+v"(bq7.bh), "+v"(bq7.bl)
+                     :
+                     : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
+                       "+v"(bq3.bl), "+v"(bq4.bh), "+v"(bq4.bl)
+                     :
+                     : "memory");
+    }
     __syncthreads();
     W16_LOAD_A(a0, 0, 0)
 
     // The loop body is a PAIR of chunks = 2 NT taps, numbered U = 0 .. 2 NT - 1 (a multiple of 6).  Tap U multiplies the A
     // operands in register set U & 1 (read from LDS during the previous tap) with the B operands in ring slot U % R
-    // (requested R - 1 taps ago); meanwhile it requests the B operands of tap U + R - 1 and reads the A operands of tap U + 1.
+    // (requested R - 1 taps ago); meanwhile it reads the A operands of tap U + 1 and requests the B operands of tap U + R - 1.
     // The V brick is double-buffered: chunk c reads buffer c & 1; the next chunk's brick is requested (LDS-DMA) at the
-    // chunk's first tap and published by the chunk's ONE barrier, which sits in front of the last tap's MFMAs (the first A
-    // read of the next chunk follows it).  Everything is compile-time and branch-free; after the last chunk the stream
+    // chunk's first two taps and published by the chunk's ONE barrier, which sits in front of the last tap's MFMAs (the first
+    // A read of the next chunk follows it).  Everything is compile-time and branch-free; after the last chunk the stream
     // re-requests harmlessly.
-    // Wait counts (loads return in order).  B(U) was requested at tap U - (R - 1); younger than it are the B requests of taps
-    // U - R + 2 .. U (2 (R - 1) loads) and the V half-brick requests (4 each) of every chunk's taps 0 and 1 in
-    // U - (R - 1) .. U.  In front of the chunk barrier the V brick requested at taps 0 and 1 must have landed: younger
-    // than it are the B requests of taps 2 .. NT - 1.
+    // Program order of a tap: [V half-request (taps 0, 1)] [chunk barrier (last tap)] [wait for this tap's weights] [MFMAs,
+    // between them the next tap's A operands and then the weight request of tap U + R - 1].  Wait counts (loads return in
+    // order): younger than the weight request of tap U (issued in the middle of tap U - R + 1) are the weight requests of taps
+    // U-R+2 .. U-1 (2 (R-2) loads) and the V half-requests (4 loads each) of every chunk's taps 0 and 1 among taps
+    // U-R+2 .. U.  In front of the chunk barrier the brick requested at taps 0 and 1 must have landed: younger than its second
+    // half are the weight requests of taps 1 .. NT-2.
+    // Priority (s_setprio) falls with the tap index inside a chunk, so that whichever of the two waves of a SIMD is behind
+    // gets the matrix pipe (at equal priority the older wave wins every arbitration and the younger one finishes the chunk alone).
 #define W16_TAP(U, ACUR, ANXT, BCUR, BREQ)                                                                           \
     {                                                                                                                \
         constexpr int cp_ = (U) / NT, t_ = (U) % NT;          /* chunk of the pair, tap of the chunk */             \
         constexpr int un_ = (U) + R - 1, cn_ = un_ / NT, tn_ = un_ % NT;                                             \
-        constexpr int ng_ = w16_count(t_, R, NT, 0) + w16_count(t_, R, NT, 1 % NT);   /* V half-requests among them */ \
-        constexpr int nb_ = ((W16_ABLATE & 2) ? 0 : 2 * (R - 1)) + ((W16_ABLATE & 4) ? 0 : 4 * ng_);                 \
+        constexpr int ng_ = w16_count(t_, R - 1, NT, 0) + w16_count(t_, R - 1, NT, 1 % NT);   /* V half-requests among them */ \
+        constexpr int nb_ = 2 * (R - 2) + 4 * ng_;                                                                   \
+        if constexpr (t_ == 0 || w16_prio(t_, NT) != w16_prio(t_ - 1, NT)) __builtin_amdgcn_s_setprio(w16_prio(t_, NT)); \
         asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[WM - 2]), "+v"(arow[WM - 1]));                     \
-        if (!(W16_ABLATE & 2)) W16_REQUEST_B(BREQ, tn_, ch + cn_)                                                    \
-        if constexpr (t_ < 2 && !(W16_ABLATE & 4))                                                                   \
+        if constexpr (t_ < 2)                                                                                        \
             W16_REQUEST_V(ch + cp_ + 1 < a.nchunk ? ch + cp_ + 1 : ch + cp_, 1 - cp_, t_)                            \
         if constexpr (t_ == NT - 1) {                                                                                \
-            W16_WAIT_VM((W16_ABLATE & 2) ? 0 : 2 * (NT - 2))                                                         \
-            W16_SYNC()                                                                                               \
+            W16_WAIT_VM(2 * (NT - 2))                                                                                \
+            __syncthreads();                                                                                         \
         }                                                                                                            \
-        if (!(W16_ABLATE & 2)) W16_WAIT_B(BCUR, nb_)                                                                 \
+        W16_WAIT_B(BCUR, nb_)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if constexpr (t_ < NT - 1) W16_MFMA_LD(ACUR, BCUR, ANXT, t_ + 1, cp_)                                        \
-        else W16_MFMA_LD(ACUR, BCUR, ANXT, 0, 1 - cp_)                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if constexpr (t_ < NT - 1) W16_MFMA_SPREAD(ACUR, BCUR, ANXT, t_ + 1, cp_, BREQ, tn_, ch + cn_)               \
+        else W16_MFMA_SPREAD(ACUR, BCUR, ANXT, 0, 1 - cp_, BREQ, tn_, ch + cn_)                                      \
     }
 #define W16_TAP6(U0)                                                                                                 \
     {                                                                                                                \
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
         }
     }
 
+    __builtin_amdgcn_s_setprio(0);
     // The stream's harmless last requests (LDS-DMA included) must land before LDS and the ring's registers are reused: the
     // compiler does not know that the ring slots are still being written, so they stay operands of the wait.
     if constexpr (R == 9) {

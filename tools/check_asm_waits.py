@@ -67,6 +67,31 @@ def check_loop(loop_text, iterations=3):
     return bad
 
 
+def check_scalar_operands(text, name_re):
+    """The asm loads that take their address from an SGPR pair: the compiler's hazard recogniser does not look inside inline
+    asm, so a VALU instruction (v_readfirstlane, v_readlane, v_cmp) that writes such an SGPR must not sit within five
+    instructions in front of the load (gfx9: "VALU writes SGPR -> VMEM reads that SGPR: 5 wait states")."""
+    bad = []
+    for name, body in re.findall(r"^(\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M):
+        if not re.search(name_re, name):
+            continue
+        lines = [l.split(";")[0].strip() for l in body.split("\n")]
+        lines = [l for l in lines if l and not l.startswith(".") and not l.endswith(":")]
+        for i, l in enumerate(lines):
+            if not l.startswith(("global_load", "buffer_load")):
+                continue
+            sregs = set()
+            for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", l):
+                sregs.update(range(int(a), int(b) + 1))
+            for k in range(max(0, i - 5), i):
+                m = re.match(r"(v_readfirstlane\w*|v_readlane\w*|v_cmp\w*)\s+s(?:\[(\d+):(\d+)\]|(\d+))", lines[k])
+                if m:
+                    w = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
+                    if w & sregs:
+                        bad.append(f"{name}: '{lines[k]}' {i - k} instructions in front of '{l}'")
+    return bad
+
+
 def main():
     text = open(sys.argv[1]).read()
     name_re = sys.argv[2] if len(sys.argv) > 2 else "."
@@ -78,6 +103,10 @@ def main():
             for b in bad[:20]:
                 print("   ", b)
             rc |= bool(bad)
+    hz = check_scalar_operands(text, name_re)
+    for h in hz[:20]:
+        print("SGPR hazard:", h)
+    rc |= bool(hz)
     return rc
 
 
