@@ -15,9 +15,18 @@ for p in ("p1", "p2"):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             a = agg[k][r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"])
+dur = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob(f"{out}/p1/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        dur[k][0] += 1; dur[k][1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
 for k, cs in agg.items():
     v = {c: s / n for c, (n, s) in cs.items()}
     print(k)
+    if k in dur and dur[k][0] and "GRBM_GUI_ACTIVE" in v:
+        ns = dur[k][1] / dur[k][0]
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs
+        print(f"   -> {ns / 1e3:.1f} us per launch under the counters, clock {v['GRBM_GUI_ACTIVE'] / 8 / ns:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)")
     for c in sorted(v): print(f"   {c:32s} {v[c]:.4g}")
     if "SQ_WAVE_CYCLES" in v:
         wc = v["SQ_WAVE_CYCLES"]
