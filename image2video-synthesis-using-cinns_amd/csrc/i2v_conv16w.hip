@@ -28,7 +28,10 @@
 //     chunk boundaries.
 //   * The loop body is a pair of chunks (ring slot, A register set and V buffer are all compile-time, the body is
 //     branch-free); the loads are asm statements and EVERY wait is counted by hand (tools/check_asm_waits.py replays the
-//     compiled loops against the in-order VMEM queue).
+//     compiled loops against the in-order VMEM queue, and checks that the loop is entered with nothing in flight).
+//   * Within a tap the wave's other work (next tap's LDS address arithmetic and reads, the weight request: scalar base + the
+//     lane's 16 bytes) sits one piece per 32-cycle gap between the MFMAs, and wave priority falls with the tap index inside a
+//     chunk (round 3; the timing behind it was taken on the F(4,3) kernel, i2v_conv16w4.hip).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

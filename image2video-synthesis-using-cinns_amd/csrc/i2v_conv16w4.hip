@@ -23,11 +23,18 @@
 //   epilogue: per 32-channel half the six partial GEMMs of a tile meet in LDS (98 KB), y = A^T M in fp32, then bias,
 //           residual, optional lrelu, fused per-(b,c) statistics, stores of four positions per tile.
 // Workgroup = 512 threads, 128 tiles = 512 output positions (TT x TH x 16 brick) x 64 output channels.
-// Schedule details measured in round 3: the next tap's A-operand reads are spread between the MFMAs of the current tap (the
-// two waves of a SIMD fall into step because they share the matrix pipe; a burst in front of the MFMA block idles it for
-// both: +4.5..10 %), and pass A requests pass B's first brick behind its own last chunk (no V round trip between the passes).
-// Loads are asm statements with hand-counted waits exactly as in i2v_conv16w.hip (tools/check_asm_waits.py replays both
-// compiled loops of every instantiation).
+// Schedule (round 3, from per-tap and per-workgroup timing: -DW4_TAPTIME / -DW4_TIMELINE builds of tools/conv16w_check): an
+// in-order wave that issues its MFMAs back to back sits blocked on the matrix pipe, and whatever it issues outside the MFMA
+// block is time the pipe idles unless the partner wave of the SIMD happens to have an MFMA ready.  So everything a tap has to
+// issue for the NEXT taps -- per row block the LDS address arithmetic and the two ds_read_b128 of the next tap's A operands,
+// then the weight request of tap U + R - 1 (scalar base + the lane's 16 bytes: no vector address arithmetic) -- sits one small
+// piece per 32-cycle gap between the tap's MFMAs; wave priority falls with the tap index inside a chunk, so that whichever of
+// the two waves of a SIMD is behind gets the pipe; pass A requests pass B's first brick behind its own last chunk (no V
+// round trip between the passes).  MFMA pipe busy 0.53 -> 0.62 at 1.71 -> 1.63 GHz (the chip is power-limited: DESIGN.md).
+// Loads are asm statements with hand-counted waits exactly as in i2v_conv16w.hip; every pass waits for ALL of its prologue
+// requests before the loop (the loop's counts assume the steady state).  tools/check_asm_waits.py replays both compiled loops
+// of every instantiation, checks that each is entered with nothing in flight and that no asm load reads a freshly
+// VALU-written SGPR.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

@@ -259,6 +259,10 @@ def test_winograd_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
             assert caw.check_loop(mutated) != [], (name, w)
         checked += 1
     assert checked == 6
+    # every loop is entered with nothing in flight (the replay and the hand-written counts both assume it), and no asm load
+    # reads an SGPR that a VALU instruction wrote within the five wait states the compiler would have inserted for its own loads
+    assert caw.check_loop_entries(text, "conv_wino_f16x3_kernel") == []
+    assert caw.check_scalar_operands(text, "conv_wino_f16x3_kernel") == []
 
 
 def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
@@ -297,6 +301,8 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
             for w in ((b_wait, bar_wait) if nt != 3 else (bar_wait,)):
                 mutated = re.sub(r"s_waitcnt vmcnt\(%d\)" % w, "s_waitcnt vmcnt(%d)" % (w + 1), loop)
                 assert caw.check_loop(mutated) != [], (name, w)
+    assert caw.check_loop_entries(text, "conv_wino4_f16x3_kernel") == []
+    assert caw.check_scalar_operands(text, "conv_wino4_f16x3_kernel") == []
 
 
 def waits_of(loop):

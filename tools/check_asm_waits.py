@@ -34,6 +34,32 @@ def kernel_loops(text, name_re):
         yield name, loops
 
 
+def check_loop_entries(text, name_re):
+    """The replay below starts every loop with an EMPTY queue, and the hand-written wait counts assume the steady state of the
+    loop: both are only right if nothing is in flight when the loop is entered.  So: walking back from the loop header, a
+    `s_waitcnt vmcnt(0)` must come before any load.  (Rounds 2-3 shipped loops whose prologue left its weight requests in
+    flight; the first taps then under-waited -- wrong results once in a few hundred launches of one shape.)"""
+    bad = []
+    for name, body in re.findall(r"^(\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M):
+        if not re.search(name_re, name):
+            continue
+        for m in re.finditer(r"^(\.LBB\d+_\d+):[^\n]*\n((?:(?!^\.LBB).)*?)s_cbranch_\w+ \1\n", body, flags=re.S | re.M):
+            if "v_mfma" not in m.group(2):
+                continue
+            before = [l.split(";")[0].strip() for l in body[:m.start()].split("\n")]
+            verdict = "no s_waitcnt vmcnt(0) in front of the loop"
+            for l in reversed(before):
+                if re.match(r"s_waitcnt\b.*vmcnt\(0\)", l):
+                    verdict = None
+                    break
+                if l.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")):
+                    verdict = f"'{l}' is issued after the last vmcnt(0) in front of the loop"
+                    break
+            if verdict:
+                bad.append(f"{name} loop at {m.group(1)}: {verdict}")
+    return bad
+
+
 def check_loop(loop_text, iterations=3):
     """Returns a list of violation strings (empty = the schedule is safe under in-order VMEM return)."""
     lines = [l.split(";")[0].strip() for l in loop_text.split("\n")]
@@ -103,6 +129,9 @@ def main():
             for b in bad[:20]:
                 print("   ", b)
             rc |= bool(bad)
+    for e in check_loop_entries(text, name_re):
+        print("loop entry:", e)
+        rc = 1
     hz = check_scalar_operands(text, name_re)
     for h in hz[:20]:
         print("SGPR hazard:", h)

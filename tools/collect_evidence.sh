@@ -18,9 +18,17 @@ timeout 400 python tools/pmc_hbm_traffic.py $out/pmc_traffic > $out/pmc_traffic.
 rm -rf $out/pmc_traffic/fetch_size $out/pmc_traffic/write_size
 # round 3 additions: cINN latencies / per-kernel stats, FETCH_SIZE calibration, SQ counters of the F(4,3) kernel on the
 # g_3.conv_1 shape (pass A and pass B are one kernel; MFMA-busy normalised by GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs)
+if [ -z "$EVIDENCE_SKIP_FLOW" ]; then   # (cINN chain and counter calibration: unchanged code -> EVIDENCE_SKIP_FLOW=1 keeps the older files)
 timeout 300 python tools/flowtime.py > $out/flowtime.txt 2>&1
 FLOWTIME_B=64 timeout 300 bash tools/flow_prof.sh evidence_b64 > /dev/null 2>&1; cp gpurun_out/flowprof_evidence_b64.csv $out/kernel_stats_flow_b64.csv 2>/dev/null
 timeout 300 python tools/pmc_hbm_traffic.py $out/pmc_traffic --calibrate > $out/fetch_calibration.log 2>&1
 rm -rf $out/pmc_traffic/fetch_calib
+fi
 timeout 400 bash tools/pmc_sq.sh $out/pmc_sq_f43 tools/conv16w_check 8 16 64 64 128 128 0 1 > $out/pmc_sq_f43_g3conv1.txt 2>&1
 rm -rf $out/pmc_sq_f43
+# per-workgroup phase timeline and per-tap timing of the F(4,3) kernel (instrumented builds of the check tool:
+#   hipcc -O3 --offload-arch=gfx950 -DW4_TIMELINE | -DW4_TAPTIME -I<csrc> tools/conv16w_check.hip <csrc>/i2v_conv16w.hip <csrc>/i2v_conv16w4.hip <csrc>/i2v_conv16.hip <csrc>/i2v_common.hip)
+for s in "8 16 64 64 128 128 0 1" "8 16 64 64 256 128 1 0" "8 16 64 64 64 64 0 1"; do
+  [ -x tools/conv16w_check_tl ] && timeout 100 tools/conv16w_check_tl $s 2>&1 | grep -v "^$" >> $out/f43_timeline.txt
+  [ -x tools/conv16w_check_tt ] && timeout 100 tools/conv16w_check_tt $s 2>&1 | grep -v "^$" >> $out/f43_taptime.txt
+done
