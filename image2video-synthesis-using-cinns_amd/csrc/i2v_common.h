@@ -118,4 +118,28 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes, bool* done) {
     return I2V_OK;
 }
 
+#ifdef __HIPCC__
+// v + (v of lane ^ OFF) for OFF = 8, 16, 32 without the LDS crossbar (a 64-bit __shfl_xor is two ds_bpermute_b32 and their
+// round trip): a DPP rotation inside the 16-lane row, v_permlane16_swap / v_permlane32_swap (gfx950) across rows and halves.
+// Both operands of the add are the same two values in every lane pair, so the result has the bits of the shuffle version.
+template <int OFF>
+__device__ __forceinline__ double wave_xor_add_f64(double v) {
+    static_assert(OFF == 8 || OFF == 16 || OFF == 32, "lane distance");
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    if constexpr (OFF == 8) {
+        const int lo2 = __builtin_amdgcn_update_dpp(0, (int)lo, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+        const int hi2 = __builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xf, 0xf, false);
+        return v + __hiloint2double(hi2, lo2);
+    } else if constexpr (OFF == 16) {
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    } else {
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+}
+#endif
+
 }  // namespace i2v

@@ -467,11 +467,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(WinoArgs a) {
         // B = 8.  fp64 partials keep the totals independent of the tiling.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int off = NQ; off < 64; off <<= 1) {
-                ssum[j] += __shfl_xor(ssum[j], off);
-                ssq[j] += __shfl_xor(ssq[j], off);
-            }
+            if constexpr (NQ <= 8) { ssum[j] = wave_xor_add_f64<8>(ssum[j]); ssq[j] = wave_xor_add_f64<8>(ssq[j]); }
+            ssum[j] = wave_xor_add_f64<16>(ssum[j]); ssq[j] = wave_xor_add_f64<16>(ssq[j]);
+            ssum[j] = wave_xor_add_f64<32>(ssum[j]); ssq[j] = wave_xor_add_f64<32>(ssq[j]);
         }
         __syncthreads();  // E is free
         double* S = reinterpret_cast<double*>(smem);  // [8 waves][BN channels][2]

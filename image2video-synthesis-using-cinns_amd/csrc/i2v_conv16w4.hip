@@ -50,10 +50,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef W4_TIMELINE   // measurement builds (tools/conv16w_check): per-workgroup phase stamps, 100 MHz wall clock
-__device__ unsigned long long w4_tl[8192 * 8];
-#define W4_STAMP(i) { if (tid == 0 && blockIdx.x < 8192) w4_tl[blockIdx.x * 8 + (i)] = wall_clock64(); }
+__device__ unsigned long long w4_tl[8192 * 16];
+#define W4_STAMP(i) { if (tid == 0 && blockIdx.x < 8192) w4_tl[blockIdx.x * 16 + (i)] = wall_clock64(); }
 #else
-#define W4_STAMP(i)
+#define W4_STAMP(i) {}
 #endif
 #ifdef W4_ABLATE_AL   // measurement builds only (wrong results): the lo halves of the A operands are not read from LDS
 #define W4_ABL_AL(x, y) y
@@ -92,6 +92,7 @@ struct W4Args {
     int tdup;
     long wset_stride;
     int TT, TH, TJ, nbT, nbH, nbJ;
+    int th_shift, rt_shift, rs_shift, hh_magic;   // TH, rt, rs are powers of two; hh_magic = ceil(2^20 / (TH + 2)): n / HH == n * hh_magic >> 20 for n * HH < 2^20
     int rt, rs, epi;
     float oscale;
     int tofs;           // LDS byte offset of the index tables
@@ -168,7 +169,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     /* LDS address of one row block of the A operands, and its two ds_read_b128 */
 #define W4_ADDR_A(TAP, VB, wm)                                                                                       \
     {                                                                                                                \
-        const int r_ = arow[wm] + (((TAP) / 3) * HH + ((TAP) % 3)) * a.TJ + (VB) * VROWS;                            \
+        const int r_ = arow[wm] + (((TAP) / 3) * HH + ((TAP) % 3)) * 4 + (VB) * VROWS;                            \
         adn[wm] = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                                  \
     }
 #define W4_READ_A(o, wm)                                                                                             \
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     }
     const int pt = a.tdup ? 1 - par : KT / 2;
     const int HT = a.TT + KT - 1, HH = a.TH + 2;
-    const int plane = HT * HH * a.TJ;
+    const int plane = HT * HH * 4;        // (TJ = 4 tiles along w in every brick of this kernel)
 
     int* gposA = reinterpret_cast<int*>(smem + a.tofs);   // [1024] planes 0..3
     int* gposB = gposA + W4_ROWS_A;                       // [1024] planes 4, 5 in rows 0..511, -1 (zero page) behind
@@ -405,27 +406,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     const int bj = brick % a.nbJ; brick /= a.nbJ;
     const int bh = brick % a.nbH; brick /= a.nbH;
     const int bt = brick % a.nbT; brick /= a.nbT;
-    const int b0 = brick, t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * a.TJ;
+    const int b0 = brick, t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * 4;
     const int n0 = ntile * BN;
 
     if (tid < W4_TILES) {
         int m = tid;
-        const int ij = m % a.TJ; m /= a.TJ;
-        const int ih = m % a.TH; m /= a.TH;
+        const int ij = m & 3; m >>= 2;       // (no integer divisions in the index tables: they cost a workgroup ~1.5 us)
+        const int ih = m & (a.TH - 1); m >>= a.th_shift;
         const int t = t0 + m, h = h0 + ih, w = 4 * (j0 + ij);
         const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + par : t;
         tpos[tid] = ((b0 * To + to) * a.H + h) * a.W + w;
-        const int rbase = ((b0 * (To / a.rt) + to / a.rt) * (a.H / a.rs) + h / a.rs) * (a.W / a.rs);
+        const int rbase = ((b0 * (To >> a.rt_shift) + (to >> a.rt_shift)) * (a.H >> a.rs_shift) + (h >> a.rs_shift)) * (a.W >> a.rs_shift);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) tres[4 * tid + c] = rbase + (w + c) / a.rs;
+        for (int c = 0; c < 4; ++c) tres[4 * tid + c] = rbase + ((w + c) >> a.rs_shift);
     }
     for (int r = tid; r < 2 * W4_ROWS_A; r += 512) {
         const bool pb = r >= W4_ROWS_A;                 // row of pass B's brick
         const int rr = pb ? r - W4_ROWS_A : r;
-        const int x = rr / plane;
+        const int x = (rr >= plane) + (rr >= 2 * plane) + (rr >= 3 * plane) + (rr >= 4 * plane);   // (>= 4: not a row of the brick)
         int q = rr - x * plane;
-        const int ij = q % a.TJ; q /= a.TJ;
-        const int ih = q % HH; q /= HH;
+        const int ij = q & 3; q >>= 2;
+        const int qh = (int)(((unsigned)q * (unsigned)a.hh_magic) >> 20);   // q / HH
+        const int ih = q - qh * HH; q = qh;
         const int t = t0 + q - pt, h = h0 + ih - 1, j = j0 + ij;
         const bool ok = x < (pb ? 2 : 4) && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H;
         const int xg = pb ? 4 + x : x;
@@ -442,9 +444,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
 #pragma unroll
         for (int wm = 0; wm < WMA; ++wm) {
             int m = mha + wm * 32 + l31;
-            const int ij = m % a.TJ; m /= a.TJ;
-            const int ih = m % a.TH; m /= a.TH;
-            arow[wm] = xa * plane + (m * HH + ih) * a.TJ + ij;
+            const int ij = m & 3; m >>= 2;
+            const int ih = m & (a.TH - 1); m >>= a.th_shift;
+            arow[wm] = xa * plane + (m * HH + ih) * 4 + ij;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
         }
@@ -459,9 +461,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
 #pragma unroll
         for (int wm = 0; wm < WMB; ++wm) {
             int m = mhb + wm * 32 + l31;
-            const int ij = m % a.TJ; m /= a.TJ;
-            const int ih = m % a.TH; m /= a.TH;
-            arow[wm] = xb * plane + (m * HH + ih) * a.TJ + ij;
+            const int ij = m & 3; m >>= 2;
+            const int ih = m & (a.TH - 1); m >>= a.th_shift;
+            arow[wm] = xb * plane + (m * HH + ih) * 4 + ij;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accB[wm][r] = 0.f;
         }
@@ -471,11 +473,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     }
     W4_STAMP(4)
 
-    // ---- epilogue, one 32-channel half at a time: E = [6 planes][128 tiles][32 channels] fp32 (98 KB)
+    // ---- epilogue, one 32-channel half at a time: E = [6 planes][128 tiles][32 channels] fp32 (98 KB).  A wave's ds_write_b32
+    // stores the rows m (lanes 0..31) and m + 4 (lanes 32..63) of an accumulator register: 512 bytes apart = the same 32 banks.
+    // Tile m is therefore kept in row m ^ ((m >> 2) & 1), which puts the two halves of the wave on the two halves of the banks.
     constexpr int NQ = 8, TPI = 64, NIT = 2;
     float* E = reinterpret_cast<float*>(smem);
     double* S = reinterpret_cast<double*>(smem + 6 * W4_TILES * 32 * 4);   // [8 waves][32 channels][2] behind E
     const int n4 = tid % NQ;
+    const int e3 = kg * 96, e5 = kg * 160;   // row offsets (in floats) of the wave's upper lanes, see the E writes
 #pragma unroll 1
     for (int half = 0; half < BN / 32; ++half) {
         const int n = n0 + half * 32 + 4 * n4;
@@ -491,13 +496,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                     rres[it][c] = *reinterpret_cast<const f32x4*>(a.res + (long)tres[4 * (tid / NQ + TPI * it) + c] * a.Cout + n);
             }
         __syncthreads();   // the V bricks / the previous half's E are no longer read
+        if (half == 0) W4_STAMP(8)
         if (nha == half) {
 #pragma unroll
             for (int wm = 0; wm < WMA; ++wm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mha + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    E[(xa * W4_TILES + m) * 32 + l31] = accA[wm][r];
+                    // tile m = c + 4 kg sits in row m ^ ((m >> 2) & 1) = c + (r odd ? 3 : 5) kg: two base addresses + immediates
+                    const int c = mha + wm * 32 + (r & 3) + 8 * (r >> 2);
+                    E[(xa * W4_TILES + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accA[wm][r];
                 }
         }
         if (nhb == half) {
@@ -505,11 +512,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             for (int wm = 0; wm < WMB; ++wm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mhb + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    E[((4 + xb) * W4_TILES + m) * 32 + l31] = accB[wm][r];
+                    const int c = mhb + wm * 32 + (r & 3) + 8 * (r >> 2);
+                    E[((4 + xb) * W4_TILES + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accB[wm][r];
                 }
         }
         __syncthreads();
+        if (half == 0) W4_STAMP(9)
         float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.bias && ncol) bias = *reinterpret_cast<const float4*>(a.bias + n);
         const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             float mx[6][4];
 #pragma unroll
             for (int x = 0; x < 6; ++x) {
-                const float4 v = *reinterpret_cast<const float4*>(E + (x * W4_TILES + tile) * 32 + 4 * n4);
+                const float4 v = *reinterpret_cast<const float4*>(E + (x * W4_TILES + (tile ^ ((tile >> 2) & 1))) * 32 + 4 * n4);
                 mx[x][0] = v.x; mx[x][1] = v.y; mx[x][2] = v.z; mx[x][3] = v.w;
             }
 #pragma unroll
@@ -548,16 +556,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                 for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.out + (p + c) * a.Cout + n) = rres[it][c];
             }
         }
+        if (half == 0) W4_STAMP(10)
         if (a.stats) {
             // lanes of a wave that share (lane % NQ) hold the same four channels -> wavefront shuffles; the eight waves'
             // partials meet in LDS (behind E) and one wave issues the 2 x 32 fp64 atomics of this channel half
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int off = NQ; off < 64; off <<= 1) {
-                    ssum[j] += __shfl_xor(ssum[j], off);
-                    ssq[j] += __shfl_xor(ssq[j], off);
-                }
+                if constexpr (NQ <= 8) { ssum[j] = wave_xor_add_f64<8>(ssum[j]); ssq[j] = wave_xor_add_f64<8>(ssq[j]); }
+                ssum[j] = wave_xor_add_f64<16>(ssum[j]); ssq[j] = wave_xor_add_f64<16>(ssq[j]);
+                ssum[j] = wave_xor_add_f64<32>(ssum[j]); ssq[j] = wave_xor_add_f64<32>(ssq[j]);
             }
             if (lane < NQ) {
 #pragma unroll
@@ -705,10 +712,17 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     I2V_REQUIRE(wino4_supported(wts.Cout, wts.Cin, T, H, W, wts.KT), I2V_E_INVALID, "wino4: unsupported shape [%d,%d,%d] %d -> %d (kt = %d)",
                 T, H, W, wts.Cin, wts.Cout, wts.KT);
     a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
+    I2V_REQUIRE((a.rt == 1 || a.rt == 2 || a.rt == 4) && (a.rs == 1 || a.rs == 2 || a.rs == 4), I2V_E_INVALID,
+                "wino4: residual up-sampling factors %d / %d (1, 2 or 4)", a.rt, a.rs);
+    a.rt_shift = a.rt >> 1 == 2 ? 2 : a.rt >> 1; a.rs_shift = a.rs >> 1 == 2 ? 2 : a.rs >> 1;
     a.oscale = (float)std::ldexp(1.0, -wts.wexp);
     int TT = 1, TH = 1;
     (void)wino4_tiling(T, H, W, wts.KT, &TT, &TH);
     a.TT = TT; a.TH = TH; a.TJ = 4; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = a.J / 4;
+    a.th_shift = 0;
+    while ((1 << a.th_shift) < TH) ++a.th_shift;
+    I2V_REQUIRE((1 << a.th_shift) == TH, I2V_E_INVALID, "wino4: brick height %d is not a power of two", TH);
+    a.hh_magic = ((1 << 20) + TH + 1) / (TH + 2);
     const int body = 2 * W4_ROWS_A * 64;   // two V bricks of pass A (pass B and the epilogue's exchange buffer reuse them)
     a.tofs = body;
 #ifdef W4_TAPTIME
@@ -757,20 +771,23 @@ void w4_taptime_report() {
 #ifdef W4_TIMELINE
 void w4_timeline_report(unsigned nwg) {
     if (nwg > 8192) nwg = 8192;
-    std::vector<unsigned long long> h(8192 * 8);
+    std::vector<unsigned long long> h(8192 * 16);
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(w4_tl), h.size() * 8);
     const char* nm[6] = {"tables + first V brick", "pass A loop", "hand-over to pass B", "pass B loop", "epilogue half 0", "epilogue half 1"};
-    double sum[6] = {}, tot = 0;
+    double sum[6] = {}, sub[4] = {}, tot = 0;
     unsigned long long lo = ~0ull, hi = 0;
     for (unsigned w = 0; w < nwg; ++w) {
-        const unsigned long long* t = &h[w * 8];
+        const unsigned long long* t = &h[w * 16];
         for (int i = 0; i < 6; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+        sub[0] += (double)(t[8] - t[4]); sub[1] += (double)(t[9] - t[8]); sub[2] += (double)(t[10] - t[9]); sub[3] += (double)(t[5] - t[10]);
         tot += (double)(t[6] - t[0]);
         lo = std::min(lo, t[0]); hi = std::max(hi, t[6]);
     }
     printf("   F(4,3) timeline over %u workgroups (us, 100 MHz clock): total %.2f per workgroup; kernel span %.1f = %.2f per workgroup slot of 256 CUs\n",
            nwg, tot / nwg / 100.0, (double)(hi - lo) / 100.0, (double)(hi - lo) / 100.0 / (nwg / 256.0));
     for (int i = 0; i < 6; ++i) printf("      %-24s %7.2f\n", nm[i], sum[i] / nwg / 100.0);
+    printf("      epilogue half 0 = residual requests + first barrier %.2f | accumulators -> LDS + barrier %.2f | transform, bias, residual, stores issued %.2f | statistics %.2f\n",
+           sub[0] / nwg / 100.0, sub[1] / nwg / 100.0, sub[2] / nwg / 100.0, sub[3] / nwg / 100.0);
 }
 #endif
 
