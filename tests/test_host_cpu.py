@@ -327,3 +327,34 @@ def test_bench_self_launches_multi_gpu_jobs_from_a_plain_shell():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--dry"],
                        env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "must agree" in r.stderr
+
+
+def test_static_asm_checker_flags_the_hazards_it_exists_for():
+    """tools/check_asm_waits.py on hand-made snippets: a loop entered with a load in flight (the round-2/3 prologues), an asm
+    load behind a VALU-written SGPR, an MFMA that reads a register a load may still write -- and the clean versions of each."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_asm_waits as caw
+
+    def kernel(prologue, loop):
+        return "k1: ; @k1\n" + prologue + ".LBB0_1: ; loop\n" + loop + "\ts_cbranch_scc1 .LBB0_1\n\t.end_amdhsa_kernel\n"
+
+    mfma = "\tv_mfma_f32_32x32x16_f16 v[10:25], v[1:4], v[5:8], v[10:25]\n"
+    load = "\tglobal_load_dwordx4 v[1:4], v0, s[0:1]\n"
+    # loop entry
+    late = kernel("\ts_waitcnt vmcnt(0)\n" + load, mfma)
+    good = kernel(load + "\ts_waitcnt vmcnt(0)\n", mfma)
+    assert caw.check_loop_entries(late, "k1") and "after the last vmcnt(0)" in caw.check_loop_entries(late, "k1")[0]
+    assert caw.check_loop_entries(kernel(load, mfma), "k1")
+    assert caw.check_loop_entries(good, "k1") == []
+    # VALU-written SGPR in front of an asm load: five wait states
+    nops = "\ts_nop 0\n"
+    assert caw.check_scalar_operands(kernel("\tv_readfirstlane_b32 s1, v9\n" + nops * 2 + load, mfma), "k1")
+    assert caw.check_scalar_operands(kernel("\tv_readfirstlane_b32 s1, v9\n" + nops * 5 + load, mfma), "k1") == []
+    assert caw.check_scalar_operands(kernel("\tv_readfirstlane_b32 s7, v9\n" + load, mfma), "k1") == []
+    # in-loop: the weights of the next iteration are requested, the MFMA must not read them before vmcnt says so
+    (name, loops), = caw.kernel_loops(kernel("", load + mfma), "k1")
+    assert caw.check_loop(loops[0]) != []
+    (name, loops), = caw.kernel_loops(kernel("", load + "\ts_waitcnt vmcnt(0)\n" + mfma), "k1")
+    assert caw.check_loop(loops[0]) == []
+    (name, loops), = caw.kernel_loops(kernel("", "\tglobal_load_lds_dwordx4 v[30:31], off\n\ts_barrier\n" + mfma), "k1")
+    assert any("LDS-DMA" in b for b in caw.check_loop(loops[0]))
