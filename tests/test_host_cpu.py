@@ -219,7 +219,7 @@ def test_winograd_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
         pytest.skip("no hipcc")
     src = os.path.join(PKG, "csrc", "i2v_conv16w.hip")
     asm = tmp_path / "w.s"
-    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", src,
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", src,
                     "-o", str(asm)], check=True, capture_output=True, timeout=600)
     text = asm.read_text()
     kernels = re.findall(r"^(_ZN3i2v22conv_wino_f16x3_kernelILi(\d)ELi(\d+)EEEvNS_8WinoArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
@@ -275,7 +275,7 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
         pytest.skip("no hipcc")
     src = os.path.join(PKG, "csrc", "i2v_conv16w4.hip")
     asm = tmp_path / "w4.s"
-    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", src,
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", src,
                     "-o", str(asm)], check=True, capture_output=True, timeout=900)
     text = asm.read_text()
     sys.path.insert(0, os.path.join(REPO, "tools"))
