@@ -358,3 +358,17 @@ def test_static_asm_checker_flags_the_hazards_it_exists_for():
     assert caw.check_loop(loops[0]) == []
     (name, loops), = caw.kernel_loops(kernel("", "\tglobal_load_lds_dwordx4 v[30:31], off\n\ts_barrier\n" + mfma), "k1")
     assert any("LDS-DMA" in b for b in caw.check_loop(loops[0]))
+
+
+def test_every_environment_switch_is_documented():
+    """Every I2V_* environment variable the native code or the Python host reads has a row in INTEGRATION.md."""
+    import glob
+    names = set()
+    for f in glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")):
+        names.update(re.findall(r'(?:getenv|env_int)\("(I2V_[A-Z0-9_]+)"', open(f).read()))
+    for f in glob.glob(os.path.join(PKG, "*.py")) + [os.path.join(REPO, "bench.py"), os.path.join(REPO, "__graft_entry__.py")]:
+        names.update(re.findall(r'environ(?:\.get\(|\[)"(I2V_[A-Z0-9_]+)"', open(f).read()))
+    assert len(names) >= 8, names
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
