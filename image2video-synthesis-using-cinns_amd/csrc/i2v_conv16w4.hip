@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     // Tile m is therefore kept in row m ^ ((m >> 2) & 1), which puts the two halves of the wave on the two halves of the banks.
     constexpr int NQ = 8, TPI = 64, NIT = 2;
     float* E = reinterpret_cast<float*>(smem);
-    double* S = reinterpret_cast<double*>(smem + 6 * W4_TILES * 32 * 4);   // [8 waves][32 channels][2] behind E
+    double* S = reinterpret_cast<double*>(smem + 6 * W4_TILES * 32 * 4);   // [2 halves][8 waves][32 channels][2] behind E
     const int n4 = tid % NQ;
     const int e3 = kg * 96, e5 = kg * 160;   // row offsets (in floats) of the wave's upper lanes, see the E writes
 #pragma unroll 1
@@ -559,35 +559,42 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         if (half == 0) W4_STAMP(10)
         if (a.stats) {
             // lanes of a wave that share (lane % NQ) hold the same four channels -> wavefront shuffles; the eight waves'
-            // partials meet in LDS (behind E) and one wave issues the 2 x 32 fp64 atomics of this channel half
+            // partials meet in LDS (behind E) and one wave per channel half issues its 2 x 32 fp64 atomics
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (NQ <= 8) { ssum[j] = wave_xor_add_f64<8>(ssum[j]); ssq[j] = wave_xor_add_f64<8>(ssq[j]); }
                 ssum[j] = wave_xor_add_f64<16>(ssum[j]); ssq[j] = wave_xor_add_f64<16>(ssq[j]);
                 ssum[j] = wave_xor_add_f64<32>(ssum[j]); ssq[j] = wave_xor_add_f64<32>(ssq[j]);
             }
+            // (each half has its own 4 KB of S: the cross-wave sums and the atomics of both halves wait until after the loop,
+            //  one barrier and two waves instead of a barrier and a serial section of wave 0 per half)
+            double* Sh = S + half * (8 * 32 * 2);
             if (lane < NQ) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    S[(wave * 32 + 4 * lane + j) * 2] = ssum[j];
-                    S[(wave * 32 + 4 * lane + j) * 2 + 1] = ssq[j];
+                    Sh[(wave * 32 + 4 * lane + j) * 2] = ssum[j];
+                    Sh[(wave * 32 + 4 * lane + j) * 2 + 1] = ssq[j];
                 }
-            }
-            __syncthreads();
-            if (wave == 0 && lane < 32 && n0 + half * 32 + lane < a.Cout) {
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) {
-                    s0 += S[(w * 32 + lane) * 2];
-                    s1 += S[(w * 32 + lane) * 2 + 1];
-                }
-                double* dst = a.stats + ((long)b0 * a.Cout + n0 + half * 32 + lane) * 2;
-                atomicAdd(dst, s0);
-                atomicAdd(dst + 1, s1);
             }
         }
         W4_STAMP(5 + half)
     }
+    if (a.stats) {
+        __syncthreads();
+        if (wave < BN / 32 && lane < 32 && n0 + wave * 32 + lane < a.Cout) {   // wave h sums channel half h
+            const double* Sh = S + wave * (8 * 32 * 2);
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                s0 += Sh[(w * 32 + lane) * 2];
+                s1 += Sh[(w * 32 + lane) * 2 + 1];
+            }
+            double* dst = a.stats + ((long)b0 * a.Cout + n0 + wave * 32 + lane) * 2;
+            atomicAdd(dst, s0);
+            atomicAdd(dst + 1, s1);
+        }
+    }
+    W4_STAMP(7)
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -774,20 +781,21 @@ void w4_timeline_report(unsigned nwg) {
     std::vector<unsigned long long> h(8192 * 16);
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(w4_tl), h.size() * 8);
     const char* nm[6] = {"tables + first V brick", "pass A loop", "hand-over to pass B", "pass B loop", "epilogue half 0", "epilogue half 1"};
-    double sum[6] = {}, sub[4] = {}, tot = 0;
+    double sum[6] = {}, sub[5] = {}, tot = 0;
     unsigned long long lo = ~0ull, hi = 0;
     for (unsigned w = 0; w < nwg; ++w) {
         const unsigned long long* t = &h[w * 16];
         for (int i = 0; i < 6; ++i) sum[i] += (double)(t[i + 1] - t[i]);
         sub[0] += (double)(t[8] - t[4]); sub[1] += (double)(t[9] - t[8]); sub[2] += (double)(t[10] - t[9]); sub[3] += (double)(t[5] - t[10]);
-        tot += (double)(t[6] - t[0]);
-        lo = std::min(lo, t[0]); hi = std::max(hi, t[6]);
+        tot += (double)(t[7] - t[0]);
+        lo = std::min(lo, t[0]); hi = std::max(hi, t[7]);
+        sub[4] += (double)(t[7] - t[6]);
     }
     printf("   F(4,3) timeline over %u workgroups (us, 100 MHz clock): total %.2f per workgroup; kernel span %.1f = %.2f per workgroup slot of 256 CUs\n",
            nwg, tot / nwg / 100.0, (double)(hi - lo) / 100.0, (double)(hi - lo) / 100.0 / (nwg / 256.0));
     for (int i = 0; i < 6; ++i) printf("      %-24s %7.2f\n", nm[i], sum[i] / nwg / 100.0);
-    printf("      epilogue half 0 = residual requests + first barrier %.2f | accumulators -> LDS + barrier %.2f | transform, bias, residual, stores issued %.2f | statistics %.2f\n",
-           sub[0] / nwg / 100.0, sub[1] / nwg / 100.0, sub[2] / nwg / 100.0, sub[3] / nwg / 100.0);
+    printf("      epilogue half 0 = residual requests + first barrier %.2f | accumulators -> LDS + barrier %.2f | transform, bias, residual, stores issued %.2f | statistics (per-wave part) %.2f; cross-wave sums + atomics of both halves %.2f\n",
+           sub[0] / nwg / 100.0, sub[1] / nwg / 100.0, sub[2] / nwg / 100.0, sub[3] / nwg / 100.0, sub[4] / nwg / 100.0);
 }
 #endif
 
