@@ -4,6 +4,13 @@
 // and, where the shape allows it, of the F(4,3) kernel (csrc/i2v_conv16w4.hip) next to them.
 // Build: hipcc -O3 --offload-arch=gfx950 -I<csrc> tools/conv16w_check.hip <csrc>/i2v_conv16w.hip <csrc>/i2v_conv16w4.hip
 //        <csrc>/i2v_conv16.hip <csrc>/i2v_common.hip -o tools/conv16w_check
+// Measurement builds of the F(4,3) kernel (same command plus):
+//   -DW4_TIMELINE   wall-clock stamps per workgroup phase (tables + first brick, pass A, hand-over, pass B, epilogue halves and
+//                   the sub-phases of the first half), printed as means over the workgroups
+//   -DW4_TAPTIME    s_memtime between the starts of consecutive taps, per wave and tap slot of the chunk pair
+//   -DW4_ABLATE_AL / -DW4_ABLATE_BL   half of the LDS operand reads / of the weight cache lines removed (results wrong)
+//   -DW4_PRIO=0     no s_setprio in the tap loop
+// T = 1 without tdup runs the 1x3x3 variants (SPADE's 2-D convs) of all three kernels.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
