@@ -159,7 +159,8 @@ struct ConvImgMfmaWeights {
     int pack(const float* w_src, const float* bias_src, int cin);
 };
 bool conv_img_mfma_supported(int T, int H, int W, int C);
-int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st);
+int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st,
+                          int* range_flag = nullptr);
 // in: fp32 channels-last [B][T][H][W][Cin]; out: frames [B][T][3][H][W] with tanh applied
 int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st);
 

@@ -629,6 +629,8 @@ int wino16_forward(const Wino16Weights& wts, const void* v_hl16, float* out, con
     I2V_REQUIRE(!stats || (long)TT * TH * TJ <= (long)T * H * J, I2V_E_INVALID, "wino16: fused statistics need bricks inside one sample");
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino16: grid of %ld workgroups", nblk);
+    I2V_REQUIRE((long)B * T * a.nchunk * 4 * H * J < (1L << 31) && (long)B * (wts.tdup ? 2 * T : T) * H * W < (1L << 31), I2V_E_INVALID,
+                "wino16: batch %d too large for the 32-bit row indices of this kernel ([%d,%d,%d] x %d chunks)", B, T, H, W, a.nchunk);
     if (BN == 64) {
         if (KT == 3) return launch_wino<9, 64>(a, (unsigned)nblk, lds, st);
         if (KT == 2) return launch_wino<6, 64>(a, (unsigned)nblk, lds, st);

@@ -742,6 +742,9 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     const int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
+    // the kernel's index tables (gpos: V rows, tpos / tres: output and residual positions) are 32-bit
+    I2V_REQUIRE((long)B * T * a.nchunk * 6 * H * a.J < (1L << 31) && (long)B * (wts.tdup ? 2 * T : T) * H * W < (1L << 31), I2V_E_INVALID,
+                "wino4: batch %d too large for the 32-bit row indices of this kernel ([%d,%d,%d] x %d chunks)", B, T, H, W, a.nchunk);
     if (getenv("I2V_W4_TRACE")) {
         fprintf(stderr, "wino4: B %d T %d H %d W %d Cin %d Cout %d pad %d KT %d tdup %d TT %d TH %d res %p rt %d rs %d stats %p epi %d nblk %ld lds %zu\n", B, T, H, W,
                 a.Cin, a.Cout, a.CoutPad, wts.KT, a.tdup, TT, TH, (const void*)res, a.rt, a.rs, (void*)stats, epi, nblk, lds);

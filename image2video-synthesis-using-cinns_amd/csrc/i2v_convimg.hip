@@ -161,8 +161,9 @@ constexpr int CM_LD = CM_NB * 32;                    // 352 columns per plane ro
 template <int KS>   // KS = Cin / 16 k-steps
 __global__ __launch_bounds__(256) void conv_img_mfma_kernel(const float* __restrict__ in, const ci_half8* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ out, int B, int T,
-                                                            int H, int W) {
+                                                            int H, int W, int* __restrict__ range_flag) {
     __shared__ float Y[32 * CM_LD];
+    bool bad = false;   // an activation left the fp16 range of its hi part (sticky flag like every other hl16 producer)
     constexpr int C = 16 * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void conv_img_mfma_kernel(const float* __restr
                 for (int j = 0; j < 8; ++j) {
                     const float v = xv[ks][j >> 2][j & 3];
                     const _Float16 hi = (_Float16)v;
+                    bad |= !(fabsf(v) <= 65504.f);
                     bh_[j] = hi;
                     bl_[j] = (_Float16)(v - (float)hi);
                 }
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(256) void conv_img_mfma_kernel(const float* __restr
     const size_t HWo = (size_t)H * W;
     float* o = out + (((size_t)b * T + t) * 3) * HWo + (size_t)(h0 + oh) * W + w0 + ow;
     o[0] = tanhf(o0 + bias[0]); o[HWo] = tanhf(o1 + bias[1]); o[2 * HWo] = tanhf(o2 + bias[2]);
+    if (bad && range_flag) atomicOr(range_flag, 1);
 }
 
 int ConvImgMfmaWeights::pack(const float* w_src, const float* bias_src, int cin) {
@@ -271,7 +274,8 @@ bool conv_img_mfma_supported(int T, int H, int W, int C) {
     return T >= 1 && H % CM_TH == 0 && W % CM_TW == 0 && (C == 16 || C == 32 || C == 48 || C == 64);
 }
 
-int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st) {
+int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st,
+                          int* range_flag) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv_img (MFMA): weights not packed");
     I2V_REQUIRE(conv_img_mfma_supported(T, H, W, wts.Cin), I2V_E_INVALID, "conv_img (MFMA): unsupported geometry");
     const long nblk = (long)B * T * (H / CM_TH) * (W / CM_TW);
@@ -279,10 +283,10 @@ int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float*
     const dim3 grid((unsigned)nblk), block(256);
     const ci_half8* wp = wts.w.as<ci_half8>();
     switch (wts.Cin / 16) {
-        case 1: hipLaunchKernelGGL(conv_img_mfma_kernel<1>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W); break;
-        case 2: hipLaunchKernelGGL(conv_img_mfma_kernel<2>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W); break;
-        case 3: hipLaunchKernelGGL(conv_img_mfma_kernel<3>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W); break;
-        default: hipLaunchKernelGGL(conv_img_mfma_kernel<4>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W); break;
+        case 1: hipLaunchKernelGGL(conv_img_mfma_kernel<1>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag); break;
+        case 2: hipLaunchKernelGGL(conv_img_mfma_kernel<2>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag); break;
+        case 3: hipLaunchKernelGGL(conv_img_mfma_kernel<3>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag); break;
+        default: hipLaunchKernelGGL(conv_img_mfma_kernel<4>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag); break;
     }
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;

@@ -126,14 +126,44 @@ __global__ void coef_kernel(const double* __restrict__ sums, float2* __restrict_
 // i2v_conv16.hip (8 x fp16 hi | 8 x fp16 lo per 8 channels, lo = x - hi) instead of fp32.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
+// Underflow side of the range guard.  The lo part of a split-fp16 operand is an fp16 subnormal for |x| < 2^-3, i.e. the format
+// has an ABSOLUTE error floor of ~2^-25: a conv whose whole operand tensor sits below ~2^-11 loses the 1e-4 gate (measured:
+// INTEGRATION.md §3) although nothing overflows.  Every operand writer therefore publishes the largest |activation| it wrote
+// (before the Winograd transform) into its own slot (float bits, atomicMax); status_finish_kernel turns "non-zero tensor whose
+// maximum is below I2V_UNDERFLOW_MAX" into status bit 1 (value 2) at the end of the forward.
+constexpr float I2V_UNDERFLOW_MAX = 0x1p-10f;
+constexpr int I2V_STATUS_WORDS = 64;   // [0] flag word, [1 ..] per-writer maxima
+
+__device__ __forceinline__ void publish_umax(int* slot, float m) {
+    if (!slot) return;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) {
+        const int bits = __float_as_int(m);   // m >= 0: the integer order of the bit patterns is the float order
+        if (bits > *reinterpret_cast<volatile int*>(slot)) atomicMax(slot, bits);
+    }
+}
+
+__global__ void status_finish_kernel(int* __restrict__ status) {
+    int f = 0;
+    for (int i = 1; i < I2V_STATUS_WORDS; ++i) {
+        const int v = status[i];
+        if (v != 0 && __int_as_float(v) < I2V_UNDERFLOW_MAX) f = 2;
+        status[i] = 0;
+    }
+    if (f) atomicOr(status, f);
+}
+
 template <bool HL16>
 __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
                                                        const float* __restrict__ gb, float* __restrict__ out, int T, int H,
-                                                       int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag) {
+                                                       int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag,
+                                                       int* __restrict__ umax) {
     const int C8 = C >> 3;
     const int b = blockIdx.y;
     const int per = H * W * C8;  // threads per sample
     bool bad = false;  // HL16: a value left the fp16 range of the hi part (sticky flag, see i2v_dec_status)
+    float vmax = 0.f;  // HL16: largest |activation| written (underflow guard)
     const int Hl = H / us, Wl = W / us, Tl = T / ut;
     const float2* cp0 = coef + (long)b * C;
     const float* xb = x + (long)b * Tl * Hl * Wl * C;
@@ -184,6 +214,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
                 for (int j = 0; j < 8; ++j) {
                     const _Float16 hh = (_Float16)r[j];
                     bad |= !(fabsf(r[j]) <= 65504.f);
+                    vmax = fmaxf(vmax, fabsf(r[j]));
                     hi[j] = hh;
                     lo[j] = (_Float16)(r[j] - (float)hh);
                 }
@@ -196,6 +227,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
         }
     }
     if (HL16 && bad && range_flag) atomicOr(range_flag, 1);
+    if (HL16) publish_umax(umax, vmax);
 }
 
 // The same modulation, written as the Winograd-transformed operand V = B^T d of i2v_conv16w.hip:
@@ -228,7 +260,7 @@ __device__ __forceinline__ void mod_pos_init(ModPos& m, const float* ca, const f
     }
 }
 
-__device__ __forceinline__ void mod_pos_eval(const ModPos& m, long toff, int lrelu, float* d) {
+__device__ __forceinline__ void mod_pos_eval(const ModPos& m, long toff, int lrelu, float* d, float& vmax) {
     const float* p = m.xp + toff;
     const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
     const float r0[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -236,13 +268,16 @@ __device__ __forceinline__ void mod_pos_eval(const ModPos& m, long toff, int lre
     for (int c = 0; c < 8; ++c) {
         const float r = fmaf(r0[c], m.a[c], m.b[c]);
         d[c] = (lrelu && r < 0.f) ? 0.2f * r : r;
+        vmax = fmaxf(vmax, fabsf(d[c]));
     }
 }
 
 __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
                                                             const float* __restrict__ gb, char* __restrict__ out, int T, int H,
-                                                            int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag) {
+                                                            int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag,
+                                                            int* __restrict__ umax) {
     bool bad = false;
+    float vmax = 0.f;
     const int C8 = C >> 3, J = W >> 1;
     const int b = blockIdx.y;
     // Thread = (h, chunk, j, piece p): piece p of a 64-byte V row is [hi | lo] (p & 1) of the 8 channels c8 = 2 chunk + (p >> 1).
@@ -295,9 +330,9 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
         for (int t = 0; t < T; ++t) {
             if (t % ut == 0) {
                 const long toff = (long)(t / ut) * xstride;
-                mod_pos_eval(m1, toff, lrelu, d1);
-                mod_pos_eval(m2, toff, lrelu, d2);
-                if (left_own || right_own) mod_pos_eval(me, toff, lrelu, de);
+                mod_pos_eval(m1, toff, lrelu, d1, vmax);
+                mod_pos_eval(m2, toff, lrelu, d2, vmax);
+                if (left_own || right_own) mod_pos_eval(me, toff, lrelu, de, vmax);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float up = __shfl_up(d2[c], 4), dn = __shfl_down(d1[c], 4);
@@ -321,6 +356,7 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
         }
     }
     if (bad && range_flag) atomicOr(range_flag, 1);
+    publish_umax(umax, vmax);
 }
 
 // The operand of the F(4,3) kernel (i2v_conv16w4.hip): V[b][t][c/16][x][h][j][c%16], x = 0..5, j = tile of four output
@@ -331,8 +367,10 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
 // evaluates its OWN four positions (d1..d4), gets d0 / d5 from the neighbouring tiles by lane shuffle and loops over the frames.
 __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
                                                              const float* __restrict__ gb, char* __restrict__ out, int T, int H,
-                                                             int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag) {
+                                                             int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag,
+                                                             int* __restrict__ umax) {
     bool bad = false;
+    float vmax = 0.f;
     const int C8 = C >> 3, J = W >> 2;
     const int b = blockIdx.y;
     const int per = H * J * C8 * 2;
@@ -377,11 +415,11 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
         for (int t = 0; t < T; ++t) {
             if (t % ut == 0) {
                 const long toff = (long)(t / ut) * xstride;
-                mod_pos_eval(m1, toff, lrelu, d1);
-                mod_pos_eval(m2, toff, lrelu, d2);
-                mod_pos_eval(m3, toff, lrelu, d3);
-                mod_pos_eval(m4, toff, lrelu, d4);
-                if (left_own || right_own) mod_pos_eval(me, toff, lrelu, de);
+                mod_pos_eval(m1, toff, lrelu, d1, vmax);
+                mod_pos_eval(m2, toff, lrelu, d2, vmax);
+                mod_pos_eval(m3, toff, lrelu, d3, vmax);
+                mod_pos_eval(m4, toff, lrelu, d4, vmax);
+                if (left_own || right_own) mod_pos_eval(me, toff, lrelu, de, vmax);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float up = __shfl_up(d4[c], 4), dn = __shfl_down(d1[c], 4);
@@ -411,6 +449,7 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
         }
     }
     if (bad && range_flag) atomicOr(range_flag, 1);
+    publish_umax(umax, vmax);
 }
 
 // conv_img (decoder.py:117: Conv3d(nf, 3, 3, padding 1) + tanh) in split-fp16 mode.  With three output channels a tiled
@@ -583,6 +622,7 @@ namespace {
 
 struct DecWs {
     size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, splitk, splitk_floats, y1v, total;
+    bool has_y1v = false;
 };
 
 bool want_wino0(const i2v_dec* d, const Block& b, const Level& l);
@@ -590,8 +630,17 @@ bool want_wino1(const i2v_dec* d, const Block& b, const Level& l);
 bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l);
 bool want_w4_1(const i2v_dec* d, const Block& b, const Level& l);
 
+// SPADE's gamma|beta Conv2d(128, 2C, 3) on a Winograd kernel (F(4,3) 1x3x3 variant, else F(2,3)): the predicate of
+// i2v_dec_load's packing and of the y1v workspace
+bool spade_w4_wanted(const i2v_dec* d, const Block& b, const Level& l) {
+    return d->cfg.mma == 1 && d->wino && d->spw && d->wino4 && (2 * b.n_in) % 64 == 0 && wino4_supported(2 * b.n_in, 128, 1, l.H, l.W, 1);
+}
+bool spade_wino_wanted(const i2v_dec* d, const Block& b, const Level& l) {
+    return spade_w4_wanted(d, b, l) || (d->cfg.mma == 1 && d->wino && d->spw && wino16_supported(2 * b.n_in, 128, 1, l.H, l.W, 1));
+}
+
 DecWs dec_ws(const i2v_dec* d, int B) {
-    size_t mx_x = (size_t)16 * d->blk[0].n_in, mx_a = 0, mx_dx = 0, mx_xsin = 0, mx_xslow = 0, mx_y = 0, mx_gb = 0;
+    size_t mx_x = (size_t)16 * d->blk[0].n_in, mx_a = 0, mx_dx = 0, mx_xsin = 0, mx_xslow = 0, mx_y = 0, mx_gb = 0, mx_yv = 0;
     int cmax = 0;
     for (int k = 0; k < 6; ++k) {
         const Block& b = d->blk[k];
@@ -604,6 +653,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
         mx_dx = std::max(mx_dx, P * b.n_mid);
         if (b.learned) { mx_xsin = std::max(mx_xsin, Pl * b.n_in); mx_xslow = std::max(mx_xslow, Pl * b.n_out); }
         mx_y = std::max(mx_y, (size_t)l.H * l.W);
+        if (spade_wino_wanted(d, b, l)) mx_yv = std::max(mx_yv, (size_t)l.H * l.W);   // only levels whose gamma|beta conv runs a Winograd kernel
         mx_gb = std::max(mx_gb, (size_t)l.H * l.W * 2 * b.n_in);
         cmax = std::max(cmax, std::max(b.n_in, b.n_mid));
     }
@@ -615,7 +665,8 @@ DecWs dec_ws(const i2v_dec* d, int B) {
     L.a = take(B * mx_a); L.dx = take(B * mx_dx);
     L.xs_in = take(B * mx_xsin); L.xs_low = take(B * mx_xslow);
     L.y0 = take(B * mx_y * 16); L.y1 = take(B * mx_y * 128); L.gb = take(B * mx_gb);
-    L.y1v = take(B * mx_y * 256);   // Winograd operand V of SPADE's 128-channel activation (8 bytes per activation)
+    L.y1v = take(B * mx_yv * 256);  // Winograd operand V of SPADE's 128-channel activation (8 bytes per activation)
+    L.has_y1v = mx_yv > 0;
     L.zl = take((size_t)B * d->Nz);
     L.sums1 = take((size_t)B * cmax * 4); L.sums2 = take((size_t)B * cmax * 4);  // doubles: 2 per channel
     L.coef = take((size_t)B * cmax * 2);
@@ -656,43 +707,43 @@ int run_coef(const double* sums, float* coef, int B, int C, int groups, double c
 }
 
 int run_modulate(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
-                 int us, int lrelu, hipStream_t st, bool hl16 = false, int* range_flag = nullptr) {
+                 int us, int lrelu, hipStream_t st, bool hl16 = false, int* range_flag = nullptr, int* umax = nullptr) {
     I2V_REQUIRE(C % 8 == 0, I2V_E_INVALID, "modulate: channels %d not a multiple of 8", C);
     const long per = (long)H * W * (C / 8);  // threads per sample (each loops over the T frames)
     I2V_REQUIRE(per * T < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
     if (hl16)
         hipLaunchKernelGGL(modulate_kernel<true>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb, out,
-                           T, H, W, C, ut, us, lrelu, range_flag);
+                           T, H, W, C, ut, us, lrelu, range_flag, umax);
     else
         hipLaunchKernelGGL(modulate_kernel<false>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb, out,
-                           T, H, W, C, ut, us, lrelu, range_flag);
+                           T, H, W, C, ut, us, lrelu, range_flag, umax);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
 
 int run_modulate_wino4(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
-                       int us, int lrelu, hipStream_t st, int* range_flag) {
+                       int us, int lrelu, hipStream_t st, int* range_flag, int* umax = nullptr) {
     I2V_REQUIRE(C % 32 == 0 && W % 4 == 0, I2V_E_INVALID, "modulate (F(4,3) operand): channels %d / width %d", C, W);
     const long per = (long)H * (W / 4) * (C / 8) * 2;
     I2V_REQUIRE(per % 64 == 0, I2V_E_INVALID, "modulate (F(4,3) operand): %ld threads per sample (need whole wavefronts)", per);
     I2V_REQUIRE(per * T * 6 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
     hipLaunchKernelGGL(modulate_wino4_kernel, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
-                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag);
+                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
 
 int run_modulate_wino(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
-                      int us, int lrelu, hipStream_t st, int* range_flag) {
+                      int us, int lrelu, hipStream_t st, int* range_flag, int* umax = nullptr) {
     I2V_REQUIRE(C % 32 == 0 && W % 2 == 0, I2V_E_INVALID, "modulate (Winograd operand): channels %d / width %d", C, W);
     const long per = (long)H * (W / 2) * (C / 8) * 2;
     I2V_REQUIRE(per % 64 == 0, I2V_E_INVALID, "modulate (Winograd operand): %ld threads per sample (need whole wavefronts)", per);
     I2V_REQUIRE(per * T * 4 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
     hipLaunchKernelGGL(modulate_wino_kernel, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
-                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag);
+                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -855,10 +906,13 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     const bool q0 = use_w4_0(d, b, l), q1 = use_w4_1(d, b, l);          // F(4,3)
     const bool w0 = !q0 && use_wino0(d, b, l), w1 = !q1 && use_wino1(d, b, l);   // F(2,3)
     int* flag = d->status_dev;
-    if (q0) rc = run_modulate_wino4(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag);
-    else if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag);
-    else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true, flag);
-    else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16, flag);
+    // underflow guard: the two operand tensors of this block publish their maxima in slots 1 + 2k / 2 + 2k
+    int* um0 = f16 && flag ? flag + 1 + 2 * (k % 24) : nullptr;
+    int* um1 = um0 ? um0 + 1 : nullptr;
+    if (q0) rc = run_modulate_wino4(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
+    else if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
+    else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true, flag, um0);
+    else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16, flag, um0);
     if (rc) return rc;
     if ((rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
     const bool fuse = f16 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
@@ -873,9 +927,9 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // ADAIN (normalization_layer.py:47-51) + leaky_relu
     if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
     if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, zstride, b.zoff, nullptr, nullptr, st))) return rc;
-    if (q1) rc = run_modulate_wino4(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag);
-    else if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag);
-    else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16, flag);
+    if (q1) rc = run_modulate_wino4(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
+    else if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
+    else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16, flag, um1);
     if (rc) return rc;
     if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
     // shortcut (decoder.py:44-49) at low resolution
@@ -960,8 +1014,8 @@ int sn_pack_tdup(const StateDict& sd, const std::string& name, bool spectral, in
 int init_status(i2v_dec* d) {
     I2V_HIP_CHECK(hipGetDevice(&d->device));
     { const char* zp = nullptr; if (int rcz = zero_page(&zp)) return rcz; }  // the conv kernels' zero page: allocated here, not inside a forward
-    I2V_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->status_dev), sizeof(int)));
-    I2V_HIP_CHECK(hipMemset(d->status_dev, 0, sizeof(int)));
+    I2V_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->status_dev), I2V_STATUS_WORDS * sizeof(int)));   // [0] flags, [1..] underflow maxima
+    I2V_HIP_CHECK(hipMemset(d->status_dev, 0, I2V_STATUS_WORDS * sizeof(int)));
     I2V_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->status_host), sizeof(int), hipHostMallocDefault));
     *d->status_host = 0;
     return I2V_OK;
@@ -1126,11 +1180,9 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         if (d->cfg.mma == 1) rc = b.sp_gb16.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
         else rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
         if (rc) return rc;
-        if (d->cfg.mma == 1 && d->wino && d->spw && d->wino4 && (2 * b.n_in) % 64 == 0 &&
-            wino4_supported(2 * b.n_in, 128, 1, d->lvl[k].H, d->lvl[k].W, 1)) {
+        if (spade_w4_wanted(d, b, d->lvl[k])) {
             if ((rc = b.sp_gb_w4.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1.0, 1))) return rc;
-        } else if (d->cfg.mma == 1 && d->wino && d->spw && wino16_supported(2 * b.n_in, 128, 1, d->lvl[k].H, d->lvl[k].W, 1) &&
-            (rc = b.sp_gb_w.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 1.0)))
+        } else if (spade_wino_wanted(d, b, d->lvl[k]) && (rc = b.sp_gb_w.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 1.0)))
             return rc;
         // ADAIN linear rows into the shared z-GEMM
         const float* lw = sd.f32(p + "norm_1.linear.weight", (int64_t)2 * b.n_mid * zd);
@@ -1271,7 +1323,7 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     float* x = xA;
     float* xn = xB;
     bool x_stats_ready = false;
-    BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, sums1, sums2, F(L.splitk), L.splitk_floats, F(L.y1v)};
+    BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, sums1, sums2, F(L.splitk), L.splitk_floats, L.has_y1v ? F(L.y1v) : nullptr};
     for (int k = 0; k < 6; ++k) {
         if ((rc = block_forward(d, k, d->blk[k], d->lvl[k], x, xn, img, img_h, img_w, zl, d->Nz, B, bufs, x_stats_ready, k == 5, st)))
             return rc;
@@ -1279,7 +1331,7 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     }
     {
         const Level& l = d->lvl[5];
-        if (d->conv_img_m.w.p) rc = conv_img_mfma_forward(d->conv_img_m, x, out, B, l.T, l.H, l.W, st);
+        if (d->conv_img_m.w.p) rc = conv_img_mfma_forward(d->conv_img_m, x, out, B, l.T, l.H, l.W, st, d->status_dev);
         else if (d->conv_img16.w.p) {
             const long P = (long)l.T * l.H * l.W, tot = (long)B * P;
             I2V_REQUIRE((tot + 255) / 256 < (1L << 31), I2V_E_INVALID, "conv_img: %ld positions", tot);
@@ -1291,7 +1343,11 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
         else rc = conv_forward(d->conv_img, x, d->nf, out, nullptr, 1, 1, B, l.T, l.H, l.W, EPI_FRAMES, st);
         if (rc) return rc;
     }
-    if (d->cfg.mma == 1) I2V_HIP_CHECK(hipMemcpyAsync(d->status_host, d->status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (d->cfg.mma == 1) {
+        hipLaunchKernelGGL(status_finish_kernel, dim3(1), dim3(1), 0, st, d->status_dev);
+        I2V_HIP_CHECK(hipGetLastError());
+        I2V_HIP_CHECK(hipMemcpyAsync(d->status_host, d->status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     return I2V_OK;
 }
 
@@ -1488,8 +1544,11 @@ int i2v_gblock_forward(i2v_gblock* g, const float* x, const float* z, const floa
                             false, st)))
         return rc;
     if ((rc = run_transpose(F(L.out_cl), out, batch, b.n_out, P, false, st))) return rc;
-    if (g->ctx.cfg.mma == 1)
+    if (g->ctx.cfg.mma == 1) {
+        hipLaunchKernelGGL(status_finish_kernel, dim3(1), dim3(1), 0, st, g->ctx.status_dev);
+        I2V_HIP_CHECK(hipGetLastError());
         I2V_HIP_CHECK(hipMemcpyAsync(g->ctx.status_host, g->ctx.status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     return I2V_OK;
 }
 

@@ -17,8 +17,7 @@
 //
 // Two implementations of the launch chain, both replayed from one hipGraph per direction:
 //   * i2v_flow_tile.hip (default for the shipped geometry: 64 channels, hidden 128..512, depth >= 1): every Linear on
-//     16 x 16 tiles of v_mfma_f32_16x16x4_f32, tile-major activations, last layer fused into the last hidden layer,
-//     L2 warming of the next launch's weights;
+//     16 x 16 tiles of v_mfma_f32_16x16x4_f32, tile-major activations, last layer fused into the last hidden layer;
 //   * the generic vector-ALU kernels below (any hidden_dim that is a multiple of 64, depth 0; I2V_FLOW_TILE=0 selects them
 //     for A/B measurements).
 // Generic kernels (121 launches per pass)
@@ -249,6 +248,12 @@ struct i2v_flow {
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     int g_B[2] = {-1, -1};
     void* g_ws[2] = {nullptr, nullptr};
+    // One handle = one FlowIo block + (normally) one workspace: passes on a handle are serialised.  A call that arrives on
+    // another stream than the previous one (LatentPrefetcher's side stream next to the main stream) first waits for the
+    // previous pass (event recorded behind every pass), so that its set_io kernel / state buffers cannot overtake it.
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_done = nullptr;
+    bool have_last = false;
     void drop_graphs() {
         for (auto& g : gexec) {
             if (g) (void)hipGraphExecDestroy(g);
@@ -259,6 +264,7 @@ struct i2v_flow {
     ~i2v_flow() {
         drop_graphs();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (last_done) (void)hipEventDestroy(last_done);
     }
 };
 
@@ -435,6 +441,14 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_flow: workspace %zu < required %zu",
                 workspace_bytes, L.total);
     char* ws = static_cast<char*>(workspace);
+    if (f->have_last && f->last_stream != st) I2V_HIP_CHECK(hipStreamWaitEvent(st, f->last_done, 0));
+    struct Mark {   // records the end of this pass on its stream (also on the error paths: whatever was enqueued is ordered)
+        i2v_flow* f; hipStream_t st;
+        ~Mark() {
+            if (!f->last_done && hipEventCreateWithFlags(&f->last_done, hipEventDisableTiming) != hipSuccess) { f->last_done = nullptr; return; }
+            if (hipEventRecord(f->last_done, st) == hipSuccess) { f->last_stream = st; f->have_last = true; }
+        }
+    } mark{f, st};
     if (f->tile.ok) return run_pass_tile(f, reverse, xin, embed, xout, logdet, ws, B, st);
     {
         const int na = B * 64, nb = B * f->E;

@@ -32,7 +32,7 @@ class LatentPrefetcher:
             z = self.latent_fn(*args, **kwargs)
             done = torch.cuda.Event()
             done.record()
-        for a in args:
+        for a in list(args) + list(kwargs.values()):
             if torch.is_tensor(a) and a.is_cuda:
                 a.record_stream(self.stream)      # the caller may drop its reference while the side stream still reads it
         return (z, done)

@@ -172,7 +172,12 @@ int i2v_dec_get_layer_profile(i2v_dec* d, int32_t layer, char* name, int32_t nam
  * test reaches, but a released checkpoint with a large SPADE (1 + gamma) might).  Nothing synchronises on the fast path:
  * every i2v_dec_forward ends with an async copy of the flag to pinned host memory, and the NEXT i2v_dec_forward (or
  * i2v_gblock_forward) on the handle returns I2V_E_RANGE when it finds it set.  i2v_dec_status synchronises `stream`, reads
- * the flag (bit 0 = overflow seen) and optionally clears it; use mma = 0 (exact fp32 MFMA) for such checkpoints. */
+ * the flag (bit 0 = overflow seen) and optionally clears it; use mma = 0 (exact fp32 MFMA) for such checkpoints.
+ * Bit 1 (value 2) = UNDERFLOW warning: the format has an absolute error floor of ~2^-25 (the lo part is an fp16 subnormal
+ * below |x| = 2^-3), so a conv whose whole operand tensor lies below 2^-10 no longer holds the 1e-4 gate (measured table:
+ * INTEGRATION.md §3).  Every operand writer publishes the largest |activation| it wrote; a non-zero tensor whose maximum is
+ * below 2^-10 sets bit 1.  It is reported by i2v_dec_status only (sticky until reset) and does NOT make the next call fail:
+ * the output is finite and merely less precise; mma = 0 is exact there too. */
 int i2v_dec_status(i2v_dec* d, int32_t* flags, int32_t reset, void* stream);
 
 int i2v_dec_debug_tap(i2v_dec* d, int32_t block, int32_t which, float* dst, size_t max_floats);
