@@ -76,6 +76,7 @@ __device__ unsigned long long w4_tt[2 * 8 * 18 * 2];   // [pass][wave][tap slot]
 #else
 #define W4_TT(U)
 #endif
+constexpr int W4_DEFAULT_ORDER = 0;   // brick -> XCD order (kernel comment); I2V_W4_ORDER overrides for A/B runs
 constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
 constexpr int W4_KC = 16;       // input channels per K chunk
 constexpr int W4_ROWS_A = 1024; // staged V rows per buffer, pass A (4 planes); pass B stages 512 (2 planes)
@@ -96,6 +97,7 @@ struct W4Args {
     int rt, rs, epi;
     float oscale;
     int tofs;           // LDS byte offset of the index tables
+    int order;          // brick -> XCD order (see the kernel): 0 round-robin over the flat brick index, 1 / 2 one w-column per XCD
 };
 
 // Wave priority inside a chunk.  The two waves of a SIMD share the matrix pipe, arbitrated by priority, then age: at equal
@@ -377,20 +379,45 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     const int kg = lane >> 5, l31 = lane & 31;
     W4_STAMP(0)
 
-    // tile order and the XCDs: as in i2v_conv16w.hip (all workgroups reading the same V brick on one XCD, consecutively)
+    // Workgroup -> (brick, channel tile, frame parity).  All workgroups that read the same V brick (channel tiles, frame
+    // parities) take consecutive dispatch slots of ONE XCD (workgroup i runs on XCD i % 8).  Which bricks an XCD gets decides what
+    // its 4 MB L2 can share between them (every brick re-reads a t-halo of 2 / TT and an h-halo of 2 / TH of its rows):
+    //   order 0  XCD x owns the flat brick indices x, x + 8, ... (bj fastest, then bh): one w-column and every SECOND bh -- the
+    //            h-neighbours of a brick always sit on another XCD;
+    //   order 1  XCD x owns whole (sample, w-column) columns x, x + 8, ...; inside a column bh runs fastest, then bt: the ~16
+    //            bricks an XCD has in flight form a contiguous (t, h) slab whose inner halos are shared through its L2;
+    //   order 2  the same with bt fastest.
     const int nNt = a.CoutPad / BN;
     const int npar = a.tdup ? 2 : 1;
     const int per_brick = nNt * npar;
     const int nbrick = (int)(gridDim.x / per_brick);
-    int par, tile_id;
+    int par, ntile, b0, bt, bh, bj;
     if ((nbrick & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int sub = slot % per_brick, brick_ = (slot / per_brick) * 8 + xcd;
+        const int sub = slot % per_brick, q = slot / per_brick;   // q: this XCD's q-th brick
         par = a.tdup ? sub & 1 : 0;
-        tile_id = brick_ * nNt + (a.tdup ? sub >> 1 : sub);
+        ntile = a.tdup ? sub >> 1 : sub;
+        const int ncol = a.B * a.nbJ;
+        if (a.order && (ncol & 7) == 0) {
+            const int bpc = a.nbT * a.nbH;
+            const int colq = q / bpc, r = q - colq * bpc;
+            const int col = colq * 8 + xcd;
+            b0 = col / a.nbJ; bj = col - b0 * a.nbJ;
+            if (a.order == 1) { bt = r / a.nbH; bh = r - bt * a.nbH; }
+            else { bh = r / a.nbT; bt = r - bh * a.nbT; }
+        } else {
+            int brick = q * 8 + xcd;
+            bj = brick % a.nbJ; brick /= a.nbJ;
+            bh = brick % a.nbH; brick /= a.nbH;
+            bt = brick % a.nbT; b0 = brick / a.nbT;
+        }
     } else {
         par = a.tdup ? (int)(blockIdx.x >= (gridDim.x >> 1)) : 0;
-        tile_id = a.tdup ? (int)(blockIdx.x % (gridDim.x >> 1)) : (int)blockIdx.x;
+        int brick = a.tdup ? (int)(blockIdx.x % (gridDim.x >> 1)) : (int)blockIdx.x;
+        ntile = brick % nNt; brick /= nNt;
+        bj = brick % a.nbJ; brick /= a.nbJ;
+        bh = brick % a.nbH; brick /= a.nbH;
+        bt = brick % a.nbT; b0 = brick / a.nbT;
     }
     const int pt = a.tdup ? 1 - par : KT / 2;
     const int HT = a.TT + KT - 1, HH = a.TH + 2;
@@ -401,12 +428,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     int* tpos = gposB + W4_ROWS_A;                        // [128] output position of a tile's first column
     int* tres = tpos + W4_TILES;                          // [128][4] residual rows of the tile's four columns
 
-    const int ntile = tile_id % nNt;
-    int brick = tile_id / nNt;
-    const int bj = brick % a.nbJ; brick /= a.nbJ;
-    const int bh = brick % a.nbH; brick /= a.nbH;
-    const int bt = brick % a.nbT; brick /= a.nbT;
-    const int b0 = brick, t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * 4;
+    const int t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * 4;
     const int n0 = ntile * BN;
 
     if (tid < W4_TILES) {
@@ -739,7 +761,11 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
 #endif
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino4: LDS %zu bytes", lds);
     I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
-    const int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
+    int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
+    static const int env_bn = getenv("I2V_W4_BN") ? atoi(getenv("I2V_W4_BN")) : 0;        // measurement switches
+    static const int env_order = getenv("I2V_W4_ORDER") ? atoi(getenv("I2V_W4_ORDER")) : W4_DEFAULT_ORDER;
+    if (env_bn == 32 && wts.KT != 1) BN = 32;
+    a.order = env_order;
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
     // the kernel's index tables (gpos: V rows, tpos / tres: output and residual positions) are 32-bit

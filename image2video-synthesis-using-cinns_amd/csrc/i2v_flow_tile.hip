@@ -23,12 +23,29 @@
 // (L2-resident) weights the pass is only 23 us faster, i.e. the weight fetch is not what a launch waits for.
 #include "i2v_flow_tile.h"
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 namespace i2v {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+#ifdef FLOW_TIMELINE   // measurement build (tools/flow_timeline.py): wall-clock stamps (100 MHz) per launch and workgroup phase
+constexpr int FTL_LAUNCHES = 512, FTL_WGS = 64, FTL_ST = 8;
+__device__ unsigned long long flow_tl[FTL_LAUNCHES * FTL_WGS * FTL_ST];
+__device__ unsigned long long flow_tl_span[FTL_LAUNCHES * 2];   // [launch]{earliest start, latest end} over ALL workgroups
+#define FTL_STAMP(seq, i) { if (threadIdx.x == 0 && (seq) < FTL_LAUNCHES && blockIdx.x < FTL_WGS) flow_tl[((seq) * FTL_WGS + blockIdx.x) * FTL_ST + (i)] = wall_clock64(); }
+#define FTL_BEGIN(seq) { if (threadIdx.x == 0 && (seq) < FTL_LAUNCHES) atomicMin(&flow_tl_span[(seq) * 2], wall_clock64()); FTL_STAMP(seq, 0) }
+#define FTL_END(seq) { if (threadIdx.x == 0 && (seq) < FTL_LAUNCHES) atomicMax(&flow_tl_span[(seq) * 2 + 1], wall_clock64()); }
+#define FTL_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // "operands landed" needs an explicit wait to be timed
+#else
+#define FTL_STAMP(seq, i) {}
+#define FTL_BEGIN(seq) {}
+#define FTL_END(seq) {}
+#define FTL_LANDED() {}
+#endif
 
 namespace {
 
@@ -49,6 +66,7 @@ struct PreTileArgs {
     const FlowIo* io;
     float* pre;        // [S][NST][NRT][256]
     int NRT, NST, KE16, E, B, Rtiles, nblk;
+    int seq;           // launch number inside the pass (timeline builds)
 };
 
 constexpr int PRE_SC = 4;        // sample tiles per workgroup: the weight fragments stay in registers across them
@@ -60,6 +78,7 @@ __global__ __launch_bounds__(512) void flow_pre_tile_kernel(PreTileArgs a) {
     __shared__ __attribute__((aligned(16))) float es[PRE_SC * 16][PRE_LD];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
+    FTL_BEGIN(a.seq)
     const int sc = blockIdx.x / a.nblk, blk = blockIdx.x - sc * a.nblk;
     const int R = blk * 8 + w;
     const bool rok = R < a.Rtiles;
@@ -92,6 +111,7 @@ __global__ __launch_bounds__(512) void flow_pre_tile_kernel(PreTileArgs a) {
             }
         st4(a.pre + (((size_t)step * a.NST + st) * a.NRT + rt) * 256 + lane * 4, D);
     }
+    FTL_END(a.seq)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -104,12 +124,14 @@ struct HidTileArgs {
     const float* W3P;   // [NRT][2][256] or null
     float* P;           // [NST][NRT][2][256] partial products of the final Linear
     int NRT, NST;
+    int seq;
 };
 
 template <int KPW, int NS>
 __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
     __shared__ v4f red[8][NS][64];
     constexpr int HB = 8 * KPW;
+    FTL_BEGIN(a.seq)
     // Workgroup b runs on XCD b % 8 (speed only).  XCDs 0-3 take the s-net's row tiles, 4-7 the t-net's: an XCD's L2 then
     // fetches the activations of ONE net (its workgroups read nothing else) and every weight tile exactly once.
     const int id = blockIdx.x;
@@ -140,6 +162,9 @@ __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
     v4f D[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) D[s] = v4f{0.f, 0.f, 0.f, 0.f};
+    FTL_STAMP(a.seq, 1)   // requests issued
+    FTL_LANDED()
+    FTL_STAMP(a.seq, 2)   // operands landed
 #pragma unroll
     for (int i = 0; i < KPW; ++i)
 #pragma unroll
@@ -148,7 +173,9 @@ __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
             for (int s = 0; s < NS; ++s) D[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][j], Bv[s][i][j], D[s], 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < NS; ++s) red[w][s][lane] = D[s];
+    FTL_STAMP(a.seq, 3)   // MFMAs done, partial tiles parked
     __syncthreads();
+    FTL_STAMP(a.seq, 4)   // barrier passed
     if (!epi) return;
     const int st = st0 + es;
     if (st >= a.NST) return;
@@ -164,6 +191,8 @@ __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
         for (int j = 0; j < 4; ++j) d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[j], h[j], d3, 0, 0, 0);
         st4(a.P + (((size_t)st * a.NRT + rt) * 2 + cb) * 256 + lane * 4, d3);
     }
+    FTL_STAMP(a.seq, 5)   // reduce + epilogue MFMA + stores issued
+    FTL_END(a.seq)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -189,6 +218,7 @@ struct TailTileArgs {
     const float* W0T;   // [NRT][2][256]
     const float* pre;   // [NST][NRT][256]
     float* h0;          // [NST][NRT][256]
+    int seq;
 };
 
 __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
@@ -202,6 +232,7 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
     // all row groups of a sample tile on one XCD (they sum the same 2 x 32 partial tiles)
     const int st = (id >> 6) * 8 + (id & 7), rq = (id >> 3) & 7;
     if (st >= a.NST) return;
+    FTL_BEGIN(a.seq)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, n = lane & 15;
     const int HB = 2 * a.HB2;
@@ -241,6 +272,9 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
         const int c = tid - 320;
         sidx[c] = a.shuf ? a.shuf[c] : c;
     }
+    FTL_STAMP(a.seq, 1)   // requests issued
+    FTL_LANDED()
+    FTL_STAMP(a.seq, 2)   // partial tiles, state, weights landed
     if (a.P) {
         v4f s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -249,6 +283,7 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
         ps[w][lane] = s;
     }
     __syncthreads();
+    FTL_STAMP(a.seq, 3)   // partial sums parked, barrier
     // ---- affine coupling of the transformed half x[32..63] (flow_blocks.py:91-93 / 103): waves 0, 1 = channel blocks
     if (a.P && w < 2) {
         const int cb = w;
@@ -299,7 +334,8 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
             if (a.io_out && bb < a.B && a.io->logdet_out) a.io->logdet_out[bb] = v;
         }
     }
-    if (!a.l1) return;  // (uniform)
+    FTL_STAMP(a.seq, 4)   // coupling + block boundary done
+    if (!a.l1) { FTL_END(a.seq) return; }  // (uniform)
     __syncthreads();
     // ---- first Linear of the next half-step (modules.py:14-17, slope 0.01): K = the 32 passive state channels
     if (l0) {
@@ -313,6 +349,8 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
         }
         st4(a.h0 + ((size_t)st * a.NRT + rt) * 256 + lane * 4, lrelu4(D, 0.01f));
     }
+    FTL_STAMP(a.seq, 5)   // first Linear of the next half-step stored
+    FTL_END(a.seq)
 }
 
 __global__ void flow_set_io_kernel(FlowIo* dst, FlowIo v) { *dst = v; }
@@ -423,9 +461,11 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     int ns = NST <= 4 ? 1 : NST <= 8 ? 2 : 4;   // sample tiles per hidden-layer workgroup: keep ~256 workgroups
     if (const int e = env_int("I2V_FLOW_NS", 0)) ns = e >= 4 ? 4 : e >= 2 ? 2 : 1;
     const int groups = (NST + ns - 1) / ns;
+    int seq = 0;   // launch number inside the pass
 
     {   // embedding part of every first layer of the pass
         PreTileArgs a{};
+        a.seq = seq++;
         a.W0E = p.W0E.as<float>(); a.b0 = c.b0; a.io = io; a.pre = pre;
         a.NRT = NRT; a.NST = NST; a.KE16 = p.KE16; a.E = p.E; a.B = B; a.Rtiles = S * NRT; a.nblk = (a.Rtiles + 7) / 8;
         hipLaunchKernelGGL(flow_pre_tile_kernel, dim3(a.nblk * ((NST + PRE_SC - 1) / PRE_SC)), dim3(512), 0, st, a);
@@ -438,6 +478,7 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     };
     auto tail = [&](bool coupling, int step, int shuf_block, int an_block, bool lrelu, bool swap, int next_step, bool first, bool last) -> int {
         TailTileArgs t{};
+        t.seq = seq++;
         t.P = coupling ? P : nullptr;
         t.b3 = c.b3 + (size_t)step * 64;
         t.x = xbuf[xcur]; t.xo = xbuf[xcur ^ 1];
@@ -474,6 +515,7 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
         float* nxt = hB;
         for (int d = 0; d < D; ++d) {
             HidTileArgs m{};
+            m.seq = seq++;
             m.WT = p.WT.as<float>() + ((size_t)step * D + d) * NRT * HB * 256;
             m.bias = c.bmid + ((size_t)step * D + d) * N2;
             m.in = cur;
@@ -511,4 +553,58 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     return I2V_OK;
 }
 
+#ifdef FLOW_TIMELINE
 }  // namespace i2v
+// measurement build only: kind[launch]: 0 pre-GEMM, 1 tail, 2 hidden layer (the launch order of one pass is fixed: pre, tail, then
+// (hid x depth, tail) per half-step); prints mean phase durations per kind and the launch-to-launch gaps
+extern "C" int i2v_flow_timeline_report(int n_launches, int depth, int reset) {
+    using namespace i2v;
+    std::vector<unsigned long long> tl((size_t)FTL_LAUNCHES * FTL_WGS * FTL_ST), span((size_t)FTL_LAUNCHES * 2);
+    if (reset) {
+        std::fill(tl.begin(), tl.end(), 0ull);
+        for (int i = 0; i < FTL_LAUNCHES; ++i) { span[2 * i] = ~0ull; span[2 * i + 1] = 0ull; }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(flow_tl), tl.data(), tl.size() * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(flow_tl_span), span.data(), span.size() * 8);
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(flow_tl), tl.size() * 8);
+    (void)hipMemcpyFromSymbol(span.data(), HIP_SYMBOL(flow_tl_span), span.size() * 8);
+    if (n_launches > FTL_LAUNCHES) n_launches = FTL_LAUNCHES;
+    auto kind = [&](int l) { return l == 0 ? 0 : ((l - 1) % (depth + 1) == 0 ? 1 : 2); };
+    const char* kn[3] = {"flow_pre_tile_kernel", "flow_tail_tile_kernel", "flow_hid_tile_kernel"};
+    const char* ph[2][5] = {{"entry -> requests issued", "requests -> operands landed (P tiles, state, weights)", "partial sums + barrier",
+                             "coupling, log-det, block boundary", "first Linear of the next half-step + store"},
+                            {"entry -> requests issued", "requests -> operands landed (weights, activations)", "MFMAs + partials to LDS",
+                             "barrier", "reduce, bias, lrelu, final-Linear MFMA, store"}};
+    double dur[3] = {}, gap[3] = {}, phs[3][5] = {};
+    int cnt[3] = {}, gcnt[3] = {}, pcnt[3] = {};
+    for (int l = 0; l < n_launches; ++l) {
+        const int k = kind(l);
+        if (span[2 * l] == ~0ull) continue;
+        dur[k] += (double)(span[2 * l + 1] - span[2 * l]); cnt[k]++;
+        if (l + 1 < n_launches && span[2 * (l + 1)] != ~0ull) { gap[k] += (double)((long long)span[2 * (l + 1)] - (long long)span[2 * l + 1]); gcnt[k]++; }
+        if (k == 0) continue;
+        for (int w = 0; w < FTL_WGS; ++w) {
+            const unsigned long long* t = &tl[((size_t)l * FTL_WGS + w) * FTL_ST];
+            if (!t[0] || !t[5]) continue;
+            for (int i = 0; i < 5; ++i) phs[k][i] += (double)(t[i + 1] - t[i]);
+            pcnt[k]++;
+        }
+    }
+    printf("cINN launch timeline (us, 100 MHz wall clock; one pass = %d launches)\n", n_launches);
+    for (int k = 0; k < 3; ++k) {
+        if (!cnt[k]) continue;
+        printf("  %-22s x %3d: first workgroup start -> last workgroup end %.2f; gap to the next launch's first start %.2f\n", kn[k], cnt[k],
+               dur[k] / cnt[k] / 100.0, gcnt[k] ? gap[k] / gcnt[k] / 100.0 : 0.0);
+        if (k && pcnt[k])
+            for (int i = 0; i < 5; ++i) printf("      %-58s %.2f\n", ph[k - 1][i], phs[k][i] / pcnt[k] / 100.0);
+    }
+    double total = 0;
+    if (n_launches > 1 && span[0] != ~0ull) total = (double)(span[2 * (n_launches - 1) + 1] - span[0]) / 100.0;
+    printf("  pass, first start -> last end: %.1f us\n", total);
+    return 0;
+}
+#else
+}  // namespace i2v
+#endif

@@ -197,15 +197,62 @@ def test_bench_evidence_files_parse():
     assert per_pass is not None and 189e6 < per_pass < 2e9  # at least the parameters, not absurdly more
     assert src.startswith("static: profiles/") and os.path.exists(os.path.join(REPO, src.split(": ", 1)[1]))
     prof = {"conv3_ms": 10.0, "conv3_flops": 4e12, "conv3_mfma_flops": 1e13, "conv3_launches": 12}
-    layers = [{"layer": "g_3.conv_0", "kernel": "conv_wino_f16x3", "launches": 2, "ms": 5.0, "flops": 2e12, "mfma_flops": 4e12}]
-    r = bench.roofline(prof, 0.06, 1, default_workload=True, layers=layers, steps=2)
-    assert r["traffic"] is not None and r["traffic"] > 1e9 and r["traffic_source"].startswith("static: profiles/")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["bound"] == "mfma"
-    assert r["per_layer"][0]["launches_per_step"] == 1 and abs(r["per_layer"][0]["tflops_algorithmic"] - 400.0) < 1e-9
+    layers = [{"layer": "g_3.conv_0", "kernel": "conv_wino4_f16x3", "launches": 2, "ms": 5.0, "flops": 2e12, "mfma_flops": 4e12},
+              {"layer": "g_3.conv_1", "kernel": "conv_wino4_f16x3", "launches": 2, "ms": 3.0, "flops": 1e12, "mfma_flops": 2e12},
+              {"layer": "g_1.conv_1", "kernel": "conv_wino_f16x3", "launches": 2, "ms": 2.0, "flops": 1e12, "mfma_flops": 4e12}]
+    both = bench.roofline(prof, 0.06, 1, default_workload=True, layers=layers, steps=2)
+    r, ra = both["roofline"], both["roofline_all_conv3"]
+    # `roofline` is the dominant kernel ALONE: the one with the largest summed duration, here F(4,3) with 8 of the 10 ms
+    assert r["kernel_name"] == "conv_wino4_f16x3_kernel" and "F(4,3)" in r["kernel"] and r["layers"] == ["g_3.conv_0", "g_3.conv_1"]
+    assert abs(r["achieved"] - 3e12 / 8e-3 / 1e12) < 1e-9 and r["launches"] == 4 and abs(r["avg_launch_ms"] - 2.0) < 1e-12
+    assert r["traffic"] is not None and r["traffic"] > 1e9 and r["traffic_source"].startswith("static (not measured by this run): profiles/")
+    assert "conv_wino4_f16x3_kernel" in r["traffic_source"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["bound"] == "mfma" and r["peak"] == 2500.0
+    assert abs(ra["achieved"] - 400.0) < 1e-9 and set(ra["kernels"]) == {"conv_wino4_f16x3", "conv_wino_f16x3"}
+    assert ra["per_layer"][0]["launches_per_step"] == 1 and abs(ra["per_layer"][0]["tflops_algorithmic"] - 400.0) < 1e-9
     assert bench.cinn_measured_bytes(False) == (None, None)
     # every BASELINE configuration is a bench workload
     assert {"bair64", "land128", "dtdb128", "iper128_t32"} <= set(bench.CONFIGS)
     assert bench.CONFIGS["dtdb128"]["batch"] == 256 and bench.CONFIGS["iper128_t32"]["vid"] == 32
+
+
+def test_bench_line_schema():
+    """bench.validate_line is what bench.py runs on its own line before printing it: the contract keys, ONE dominant kernel in
+    `roofline`, a checksum for every timed step, single_call / sustained / exact_fp32 next to `value`.  Checked here on a
+    hand-made line and on the newest committed round-4 line (profiles/r04_*_bench_bair64.json) when there is one."""
+    import copy
+    import glob
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    line = {"metric": "m", "value": 1.0, "unit": "frames/s", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 1.0,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "w"}, "value_is": "pipelined", "rank_ms_per_step": [1.0], "output_check": {"finite": True},
+            "roofline": {"kernel": "conv_wino4_f16x3_kernel (...)", "kernel_name": "conv_wino4_f16x3_kernel", "bound": "mfma",
+                         "achieved": 1000.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.4, "traffic": None},
+            "roofline_all_conv3": {"achieved": 900.0}, "roofline_cinn": {"frac": 0.05},
+            "steps_check": {"steps_checked": 2, "all_bit_identical_to_serial_reference": True},
+            "single_call": {"ms": 1.0, "frames_per_s": 1.0}, "sustained": {"seconds": 10.5, "ms_per_step": 1.0},
+            "exact_fp32": {"ms_per_step": 5.0, "frames_per_s": 0.2, "frac": 0.7},
+            "cpu_baseline": {"value": 1.0, "unit": "frames/s", "cores": 64, "kind": "port", "sample": "s"}}
+    assert bench.validate_line(line)
+    for breaker in (lambda d: d.pop("single_call"), lambda d: d["steps_check"].update(steps_checked=1),
+                    lambda d: d["roofline"].update(frac=0.5), lambda d: d["sustained"].update(seconds=3.0),
+                    lambda d: d.update(rank_ms_per_step=[1.0, 1.0]), lambda d: d.pop("value"),
+                    lambda d: d["roofline"].update(kernel="a (...) for g_1..g_4; b")):
+        bad = copy.deepcopy(line)
+        breaker(bad)
+        with pytest.raises(ValueError):
+            bench.validate_line(bad)
+    slim = copy.deepcopy(line)
+    for k in ("cpu_baseline", "sustained", "exact_fp32", "single_call"):
+        slim[k] = None
+    assert bench.validate_line(slim, full=False)
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r04_*_bench_bair64.json")))[-1:]:
+        with open(path) as f:
+            assert bench.validate_line(json.loads(f.read().strip().splitlines()[-1]))
 
 
 def test_winograd_kernel_keeps_its_hand_counted_waits_valid(tmp_path):

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Measurement builds (run in the build container; the .so / binaries travel to the GPU box with gpurun):
+#   tools/_tl/libi2v_hip_flowtl.so   the library with -DFLOW_TIMELINE (per-launch / per-phase stamps of the cINN tile chain,
+#                                    read by tools/flow_timeline.py)
+#   tools/conv16w_check[_tl|_tt]     the conv check tool: plain, -DW4_TIMELINE, -DW4_TAPTIME
+set -e
+cd "$(dirname "$0")/.."
+CS=image2video-synthesis-using-cinns_amd/csrc
+mkdir -p tools/_tl
+if [ "$1" != "conv" ]; then
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DFLOW_TIMELINE -Wno-unused-function -shared -I$CS -Iinclude \
+    $CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip \
+    $CS/i2v_conv16w4.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip -o tools/_tl/libi2v_hip_flowtl.so &
+fi
+if [ "$1" != "flow" ]; then
+  SRC="tools/conv16w_check.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_conv16.hip $CS/i2v_common.hip"
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$CS -Iinclude $SRC -o tools/conv16w_check &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DW4_TIMELINE -I$CS -Iinclude $SRC -o tools/conv16w_check_tl &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DW4_TAPTIME -I$CS -Iinclude $SRC -o tools/conv16w_check_tt &
+fi
+wait
+ls -la tools/_tl tools/conv16w_check*
