@@ -51,7 +51,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef W4_TIMELINE   // measurement builds (tools/conv16w_check): per-workgroup phase stamps, 100 MHz wall clock
 __device__ unsigned long long w4_tl[8192 * 16];
-#define W4_STAMP(i) { if (tid == 0 && blockIdx.x < 8192) w4_tl[blockIdx.x * 16 + (i)] = wall_clock64(); }
+#define W4_STAMP(i) { if (tid == 0 && w4_tlv_ < 8192) w4_tl[w4_tlv_ * 16 + (i)] = wall_clock64(); }   // w4_tlv_: the virtual workgroup
 #else
 #define W4_STAMP(i) {}
 #endif
@@ -76,6 +76,7 @@ __device__ unsigned long long w4_tt[2 * 8 * 18 * 2];   // [pass][wave][tap slot]
 #else
 #define W4_TT(U)
 #endif
+constexpr int W4_DEFAULT_PIPE = 1;    // 1: software-pipelined persistent kernel (I2V_W4_PIPE=0: one workgroup per brick, round 3's structure)
 constexpr int W4_DEFAULT_ORDER = 0;   // brick -> XCD order (kernel comment); I2V_W4_ORDER overrides for A/B runs
 constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
 constexpr int W4_KC = 16;       // input channels per K chunk
@@ -97,7 +98,8 @@ struct W4Args {
     int rt, rs, epi;
     float oscale;
     int tofs;           // LDS byte offset of the index tables
-    int order;          // brick -> XCD order (see the kernel): 0 round-robin over the flat brick index, 1 / 2 one w-column per XCD
+    int order;          // brick -> XCD order (see w4_decode): 0 round-robin over the flat brick index, 1 / 2 one w-column per XCD
+    int nvirt;          // virtual workgroups = bricks x channel tiles x frame parities (PIPE: looped over by gridDim.x workgroups)
 };
 
 // Wave priority inside a chunk.  The two waves of a SIMD share the matrix pipe, arbitrated by priority, then age: at equal
@@ -123,16 +125,33 @@ constexpr int w4_count(int t, int R, int NT, int h) {
 // gposN / PRE: hand-over between the passes.  The request a chunk issues for "the next chunk" is a harmless repeat behind the
 // LAST chunk; pass A instead requests chunk 0 of pass B's brick there (table gposN: its rows in front, -1 behind), into the
 // buffer pass B reads first, so that pass B (PRE = true) starts without a V round trip.
-template <int NT, int WM, int VH, bool PRE>
+// PIPE (software-pipelined persistent kernel): the pass's two V buffers start at the LDS rows rb0 / rb1 (they alternate
+// between the two 64 KB regions from brick to brick), chunk 0 of pass A's brick is already in LDS when the pass starts (it was
+// requested during the PREVIOUS brick's pass B), `between` runs between the prologue's weight requests and their wait (the next
+// brick's index tables are built there), and pass B carries the next brick's first V brick as two extra LDS-DMA loads per
+// half-request: in its first two chunks they are the eight 16-byte pieces per thread of that brick (table nq, destination
+// ndst = the region this brick's pass B does not use), behind them -- and when there is no next brick -- zero-page reads into a
+// 1 KB dump row, so that the loop body and its wait counts stay the same for every chunk.
+struct W4Next {
+    const int* nq;      // next brick's gposA table + (tid >> 2), or the current one when there is no next brick
+    unsigned ndst;      // LDS byte address of the wave's slice of the free region
+    unsigned dump;      // LDS byte address of the dump row
+    int valid;          // there is a next brick
+};
+
+template <int NT, int WM, int VH, bool PRE, bool PIPE, class Between>
 __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* gpos, const int* gposN, f32x16 (&acc)[WM],
-                                        int (&arow)[WM], const char* wfrag, int HH, int tid, int lane, int wave) {
+                                        int (&arow)[WM], const char* wfrag, int HH, int tid, int lane, int wave, int rb0, int rb1,
+                                        const W4Next& nxt, Between&& between, int w4_tlv_) {
     constexpr int VROWS = VH * 2 * 128;
+    constexpr int VX = PIPE && PRE ? 2 : 0;   // extra LDS-DMA loads per half-request (the next brick's first V brick)
     const int kg = lane >> 5;
     char* v_lds = smem;
     const long cstride = (long)a.CoutPad * 384;          // bytes per (tap, chunk): 6 planes x CoutPad x 64
     const long wtap_stride = (long)a.nchunk * cstride;
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
     const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+    const unsigned voff0 = __builtin_amdgcn_readfirstlane(rb0 * 64), voff1 = __builtin_amdgcn_readfirstlane(rb1 * 64);   // byte offsets of the two V buffers
     const int* gq = gpos + (tid >> 2);
     const int* gqn = gposN + (tid >> 2);
     const long vpiece = (long)((tid & 3) ^ ((tid >> 4) & 3)) * 16;
@@ -159,7 +178,18 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         const char* vb_ = a.in + (long)(nx_ ? 0 : (ch_)) * vchunk + vpiece;                                          \
         _Pragma("unroll") for (int u = 0; u < VH; ++u) {                                                             \
             const char* s_ = gp_[u] >= 0 ? vb_ + (long)gp_[u] * 64 : a.zeros;                     \
-            W4_GLDS(s_, vdst + (unsigned)((VB) * (VROWS * 64) + (VH * (HF) + u) * 8192))                             \
+            W4_GLDS(s_, vdst + ((VB) ? voff1 : voff0) + (unsigned)((VH * (HF) + u) * 8192))                           \
+        }                                                                                                            \
+        if constexpr (VX > 0) {   /* the next brick's first V brick, pieces (chunk parity, half, u); real in chunks 0, 1 */ \
+            constexpr int pc_ = ((1 - (VB)) * 2 + (HF)) * 2;   /* (the requesting chunk's parity is 1 - VB) */         \
+            const bool real_ = nxt.valid && (ch_) <= 2;        /* requested by chunks 0 and 1 */                       \
+            int gx_[2];                                                                                              \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) gx_[u] = nxt.nq[128 * (pc_ + u)];                          \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                          \
+                const char* s_ = real_ && gx_[u] >= 0 ? a.in + vpiece + (long)gx_[u] * 64 : a.zeros;                 \
+                const unsigned d_ = real_ ? nxt.ndst + (unsigned)((pc_ + u) * 8192) : nxt.dump;                      \
+                W4_GLDS(s_, d_)                                                                                      \
+            }                                                                                                        \
         }                                                                                                            \
     }
     struct AOps { half8 ah[WM], al[WM]; };
@@ -171,7 +201,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     /* LDS address of one row block of the A operands, and its two ds_read_b128 */
 #define W4_ADDR_A(TAP, VB, wm)                                                                                       \
     {                                                                                                                \
-        const int r_ = arow[wm] + (((TAP) / 3) * HH + ((TAP) % 3)) * 4 + (VB) * VROWS;                            \
+        const int r_ = arow[wm] + (((TAP) / 3) * HH + ((TAP) % 3)) * 4 + ((VB) ? rb1 : rb0);                       \
         adn[wm] = (r_ << 6) + (((kg << 1) ^ ((r_ >> 2) & 3)) << 4);                                                  \
     }
 #define W4_READ_A(o, wm)                                                                                             \
@@ -234,11 +264,12 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         W4_REQUEST_B(bq6, 6 % NT, 6 / NT)
         W4_REQUEST_B(bq7, 7 % NT, 7 / NT)
     }
-    if constexpr (!PRE) {
+    if constexpr (!PRE && !PIPE) {
         __syncthreads();  // tables written
         W4_REQUEST_V(0, 0, 0)
         W4_REQUEST_V(0, 0, 1)
     }
+    between();
     if constexpr (R == 9) {
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(bq0.bh), "+v"(bq0.bl), "+v"(bq1.bh), "+v"(bq1.bl), "+v"(bq2.bh), "+v"(bq2.bl), "+v"(bq3.bh),
@@ -274,7 +305,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         constexpr int cp_ = (U) / NT, t_ = (U) % NT;                                                                 \
         constexpr int un_ = (U) + R - 1, cn_ = un_ / NT, tn_ = un_ % NT;                                             \
         constexpr int ng_ = w4_count(t_, R - 1, NT, 0) + w4_count(t_, R - 1, NT, 1 % NT);                            \
-        constexpr int nb_ = 2 * (R - 2) + VH * ng_;                                                                  \
+        constexpr int nb_ = 2 * (R - 2) + (VH + VX) * ng_;                                                           \
         W4_TT(U)                                                                                                     \
         if constexpr (W4_PRIO && (t_ == 0 || w4_prio(t_, NT) != w4_prio(t_ - 1, NT)))                                \
             __builtin_amdgcn_s_setprio(w4_prio(t_, NT));                                                             \
@@ -365,35 +396,25 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
 #undef W4_TAP18R9
 }
 
-// NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time slice (1x3x3: Conv2d).
-// BN: output channels per workgroup.  64: as described above.  32 (layers with 32 output channels): pass A wave = (plane,
-// tile half) with 2 row blocks, pass B wave = (plane, tile quarter) with 1 row block, one epilogue pass.
-template <int NT, int BN>
-__global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
-    constexpr int WMA = BN == 64 ? 4 : 2, WMB = BN == 64 ? 2 : 1;
-    constexpr int KT = NT / 3;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = lane >> 5, l31 = lane & 31;
-    W4_STAMP(0)
+// Workgroup -> (brick, channel tile, frame parity).  All (virtual) workgroups that read the same V brick (channel tiles, frame
+// parities) take consecutive slots of ONE XCD (workgroup i runs on XCD i % 8).  Which bricks an XCD gets decides what its 4 MB L2
+// can share between them (every brick re-reads a t-halo of 2 / TT and an h-halo of 2 / TH of its rows):
+//   order 0  XCD x owns the flat brick indices x, x + 8, ... (bj fastest, then bh): one w-column and every SECOND bh -- the
+//            h-neighbours of a brick always sit on another XCD;
+//   order 1  XCD x owns whole (sample, w-column) columns x, x + 8, ...; inside a column bh runs fastest, then bt: the ~16
+//            bricks an XCD has in flight form a contiguous (t, h) slab whose inner halos are shared through its L2;
+//   order 2  the same with bt fastest.
+struct W4Brick { int par, ntile, b0, t0, h0, j0; };
 
-    // Workgroup -> (brick, channel tile, frame parity).  All workgroups that read the same V brick (channel tiles, frame
-    // parities) take consecutive dispatch slots of ONE XCD (workgroup i runs on XCD i % 8).  Which bricks an XCD gets decides what
-    // its 4 MB L2 can share between them (every brick re-reads a t-halo of 2 / TT and an h-halo of 2 / TH of its rows):
-    //   order 0  XCD x owns the flat brick indices x, x + 8, ... (bj fastest, then bh): one w-column and every SECOND bh -- the
-    //            h-neighbours of a brick always sit on another XCD;
-    //   order 1  XCD x owns whole (sample, w-column) columns x, x + 8, ...; inside a column bh runs fastest, then bt: the ~16
-    //            bricks an XCD has in flight form a contiguous (t, h) slab whose inner halos are shared through its L2;
-    //   order 2  the same with bt fastest.
+template <int BN>
+__device__ __forceinline__ W4Brick w4_decode(const W4Args& a, int v) {
     const int nNt = a.CoutPad / BN;
     const int npar = a.tdup ? 2 : 1;
     const int per_brick = nNt * npar;
-    const int nbrick = (int)(gridDim.x / per_brick);
+    const int nbrick = a.nvirt / per_brick;
     int par, ntile, b0, bt, bh, bj;
     if ((nbrick & 7) == 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = v & 7, slot = v >> 3;
         const int sub = slot % per_brick, q = slot / per_brick;   // q: this XCD's q-th brick
         par = a.tdup ? sub & 1 : 0;
         ntile = a.tdup ? sub >> 1 : sub;
@@ -412,33 +433,34 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             bt = brick % a.nbT; b0 = brick / a.nbT;
         }
     } else {
-        par = a.tdup ? (int)(blockIdx.x >= (gridDim.x >> 1)) : 0;
-        int brick = a.tdup ? (int)(blockIdx.x % (gridDim.x >> 1)) : (int)blockIdx.x;
+        par = a.tdup ? (int)(v >= (a.nvirt >> 1)) : 0;
+        int brick = a.tdup ? v % (a.nvirt >> 1) : v;
         ntile = brick % nNt; brick /= nNt;
         bj = brick % a.nbJ; brick /= a.nbJ;
         bh = brick % a.nbH; brick /= a.nbH;
         bt = brick % a.nbT; b0 = brick / a.nbT;
     }
-    const int pt = a.tdup ? 1 - par : KT / 2;
+    return W4Brick{par, ntile, b0, bt * a.TT, bh * a.TH, bj * 4};
+}
+
+// index tables of one brick: gposA [1024] (planes 0..3), gposB [1024] (planes 4, 5 in rows 0..511, -1 = zero page behind),
+// tpos [128] (output position of a tile's first column), tres [128][4] (residual rows of the tile's four columns)
+template <int KT>
+__device__ __forceinline__ void w4_tables(const W4Args& a, const W4Brick& k, int* gposA, int tid) {
+    int* gposB = gposA + W4_ROWS_A;
+    int* tpos = gposB + W4_ROWS_A;
+    int* tres = tpos + W4_TILES;
+    const int pt = a.tdup ? 1 - k.par : KT / 2;
     const int HT = a.TT + KT - 1, HH = a.TH + 2;
     const int plane = HT * HH * 4;        // (TJ = 4 tiles along w in every brick of this kernel)
-
-    int* gposA = reinterpret_cast<int*>(smem + a.tofs);   // [1024] planes 0..3
-    int* gposB = gposA + W4_ROWS_A;                       // [1024] planes 4, 5 in rows 0..511, -1 (zero page) behind
-    int* tpos = gposB + W4_ROWS_A;                        // [128] output position of a tile's first column
-    int* tres = tpos + W4_TILES;                          // [128][4] residual rows of the tile's four columns
-
-    const int t0 = bt * a.TT, h0 = bh * a.TH, j0 = bj * 4;
-    const int n0 = ntile * BN;
-
     if (tid < W4_TILES) {
         int m = tid;
         const int ij = m & 3; m >>= 2;       // (no integer divisions in the index tables: they cost a workgroup ~1.5 us)
         const int ih = m & (a.TH - 1); m >>= a.th_shift;
-        const int t = t0 + m, h = h0 + ih, w = 4 * (j0 + ij);
-        const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + par : t;
-        tpos[tid] = ((b0 * To + to) * a.H + h) * a.W + w;
-        const int rbase = ((b0 * (To >> a.rt_shift) + (to >> a.rt_shift)) * (a.H >> a.rs_shift) + (h >> a.rs_shift)) * (a.W >> a.rs_shift);
+        const int t = k.t0 + m, h = k.h0 + ih, w = 4 * (k.j0 + ij);
+        const int To = a.tdup ? 2 * a.T : a.T, to = a.tdup ? 2 * t + k.par : t;
+        tpos[tid] = ((k.b0 * To + to) * a.H + h) * a.W + w;
+        const int rbase = ((k.b0 * (To >> a.rt_shift) + (to >> a.rt_shift)) * (a.H >> a.rs_shift) + (h >> a.rs_shift)) * (a.W >> a.rs_shift);
 #pragma unroll
         for (int c = 0; c < 4; ++c) tres[4 * tid + c] = rbase + ((w + c) >> a.rs_shift);
     }
@@ -450,173 +472,272 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         const int ij = q & 3; q >>= 2;
         const int qh = (int)(((unsigned)q * (unsigned)a.hh_magic) >> 20);   // q / HH
         const int ih = q - qh * HH; q = qh;
-        const int t = t0 + q - pt, h = h0 + ih - 1, j = j0 + ij;
+        const int t = k.t0 + q - pt, h = k.h0 + ih - 1, j = k.j0 + ij;
         const bool ok = x < (pb ? 2 : 4) && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H;
         const int xg = pb ? 4 + x : x;
-        (pb ? gposB : gposA)[rr] = ok ? ((((b0 * a.T + t) * a.nchunk * 6 + xg) * a.H + h) * a.J + j) : -1;  // chunk 0; 64-byte rows
+        (pb ? gposB : gposA)[rr] = ok ? ((((k.b0 * a.T + t) * a.nchunk * 6 + xg) * a.H + h) * a.J + j) : -1;  // chunk 0; 64-byte rows
     }
-    const char* wbase = a.wp + (long)par * a.wset_stride;   // wave-uniform; the lane's 16 bytes are added by the load
+}
+
+constexpr int W4_TABLE_BYTES = (2 * W4_ROWS_A + W4_TILES + 4 * W4_TILES) * 4;   // one table set
+
+// NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time slice (1x3x3: Conv2d).
+// BN: output channels per workgroup.  64: as described above.  32 (layers with 32 output channels): pass A wave = (plane,
+// tile half) with 2 row blocks, pass B wave = (plane, tile quarter) with 1 row block.
+// PIPE: software-pipelined persistent kernel -- one workgroup per CU loops over the virtual workgroups v = blockIdx.x + i *
+// gridDim.x (gridDim.x a multiple of 8: the XCD of a virtual workgroup does not change).  What a brick's workgroup used to do
+// between its loops with the matrix pipe idle (20-33 % of its time) is moved underneath the loops of its neighbours in time:
+//   * the index tables of brick i + 1 are built while brick i's pass B waits for its first weight fragments,
+//   * the first V brick of brick i + 1 travels as two extra LDS-DMA loads per half-request of brick i's pass B into the 64 KB
+//     region that pass B (two 30 KB buffers) does not use; the two regions swap roles from brick to brick (rb0 / rb1),
+//   * the epilogue therefore works in FOUR passes (32-channel half x 64-tile half: E = 6 x 64 x 32 fp32 = 48 KB) inside pass
+//     B's region and leaves the other one alone.
+// LDS (PIPE): [0, 64 K) [64 K, 128 K) the two regions, then two table sets; statistics partials behind E; one dump row.
+template <int NT, int BN, bool PIPE>
+__global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
+    constexpr int WMA = BN == 64 ? 4 : 2, WMB = BN == 64 ? 2 : 1;
+    constexpr int KT = NT / 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = lane >> 5, l31 = lane & 31;
+    const int HH = a.TH + 2;
+    const int plane = (a.TT + KT - 1) * HH * 4;
     const int nblk = a.CoutPad >> 5;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
 
-    // ---- pass A: planes 0..3, wave = (plane, 32-channel half), all 128 tiles   [BN = 32: (plane, tile half)]
-    const int xa = wave & 3, nha = BN == 64 ? wave >> 2 : 0, mha = BN == 64 ? 0 : (wave >> 2) * 64;
-    f32x16 accA[WMA];
-    {
-        int arow[WMA];
-#pragma unroll
-        for (int wm = 0; wm < WMA; ++wm) {
-            int m = mha + wm * 32 + l31;
-            const int ij = m & 3; m >>= 2;
-            const int ih = m & (a.TH - 1); m >>= a.th_shift;
-            arow[wm] = xa * plane + (m * HH + ih) * 4 + ij;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
-        }
-        w4_pass<NT, WMA, 4, false>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid, lane, wave);
-    }
-    W4_STAMP(2)
-    // ---- pass B: planes 4, 5, wave = (plane, 32-channel half, tile half)   [BN = 32: (plane, tile quarter)]
-    const int xb = wave & 1, nhb = BN == 64 ? (wave >> 1) & 1 : 0, mhb = BN == 64 ? (wave >> 2) * 64 : (wave >> 1) * 32;
-    f32x16 accB[WMB];
-    {
-        int arow[WMB];
-#pragma unroll
-        for (int wm = 0; wm < WMB; ++wm) {
-            int m = mhb + wm * 32 + l31;
-            const int ij = m & 3; m >>= 2;
-            const int ih = m & (a.TH - 1); m >>= a.th_shift;
-            arow[wm] = xb * plane + (m * HH + ih) * 4 + ij;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accB[wm][r] = 0.f;
-        }
-        // (chunk 0 of this brick was requested by pass A behind its last chunk and published by its last barrier; pass B's
-        //  own request behind ITS last chunk re-reads its chunk 0 harmlessly)
-        w4_pass<NT, WMB, 2, true>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid, lane, wave);
-    }
-    W4_STAMP(4)
-
-    // ---- epilogue, one 32-channel half at a time: E = [6 planes][128 tiles][32 channels] fp32 (98 KB).  A wave's ds_write_b32
-    // stores the rows m (lanes 0..31) and m + 4 (lanes 32..63) of an accumulator register: 512 bytes apart = the same 32 banks.
-    // Tile m is therefore kept in row m ^ ((m >> 2) & 1), which puts the two halves of the wave on the two halves of the banks.
-    constexpr int NQ = 8, TPI = 64, NIT = 2;
-    float* E = reinterpret_cast<float*>(smem);
-    double* S = reinterpret_cast<double*>(smem + 6 * W4_TILES * 32 * 4);   // [2 halves][8 waves][32 channels][2] behind E
-    const int n4 = tid % NQ;
-    const int e3 = kg * 96, e5 = kg * 160;   // row offsets (in floats) of the wave's upper lanes, see the E writes
-#pragma unroll 1
-    for (int half = 0; half < BN / 32; ++half) {
-        const int n = n0 + half * 32 + 4 * n4;
-        const bool ncol = n < a.Cout;
-        // residual rows first, all of them, so that their latency hides behind the LDS exchange
-        f32x4 rres[NIT][4];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                rres[it][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.res && ncol)
-                    rres[it][c] = *reinterpret_cast<const f32x4*>(a.res + (long)tres[4 * (tid / NQ + TPI * it) + c] * a.Cout + n);
-            }
-        __syncthreads();   // the V bricks / the previous half's E are no longer read
-        if (half == 0) W4_STAMP(8)
-        if (nha == half) {
-#pragma unroll
-            for (int wm = 0; wm < WMA; ++wm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // tile m = c + 4 kg sits in row m ^ ((m >> 2) & 1) = c + (r odd ? 3 : 5) kg: two base addresses + immediates
-                    const int c = mha + wm * 32 + (r & 3) + 8 * (r >> 2);
-                    E[(xa * W4_TILES + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accA[wm][r];
-                }
-        }
-        if (nhb == half) {
-#pragma unroll
-            for (int wm = 0; wm < WMB; ++wm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = mhb + wm * 32 + (r & 3) + 8 * (r >> 2);
-                    E[((4 + xb) * W4_TILES + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accB[wm][r];
-                }
-        }
+    int flip = 0, set = 0;                        // (PIPE) region of pass A's chunk 0 / table set of the current brick
+    int v = (int)blockIdx.x;
+    W4Brick bk = w4_decode<BN>(a, v);
+    int w4_tlv_ = v;   // (timeline builds index their stamps by the virtual workgroup)
+    W4_STAMP(0)
+    w4_tables<KT>(a, bk, reinterpret_cast<int*>(smem + a.tofs), tid);
+    if constexpr (PIPE) {
+        // the first brick of this workgroup: its first V brick is requested here (every later one by the previous brick's pass B)
         __syncthreads();
-        if (half == 0) W4_STAMP(9)
-        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias && ncol) bias = *reinterpret_cast<const float4*>(a.bias + n);
-        const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
-        double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
+        const int* gq = reinterpret_cast<const int*>(smem + a.tofs) + (tid >> 2);
+        const long vpiece = (long)((tid & 3) ^ ((tid >> 4) & 3)) * 16;
+        const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int tile = tid / NQ + TPI * it;
-            float mx[6][4];
+        for (int u = 0; u < 8; ++u) {
+            const int g = gq[128 * u];
+            const char* src = g >= 0 ? a.in + vpiece + (long)g * 64 : a.zeros;
+            unsigned keep_;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep_) : "v"(src), "s"(vdst + (unsigned)(u * 8192)) : "memory");
+        }
+    }
+#pragma unroll 1
+    for (;;) {
+        int* gposA = reinterpret_cast<int*>(smem + a.tofs + (PIPE ? set * W4_TABLE_BYTES : 0));
+        int* gposB = gposA + W4_ROWS_A;
+        const int* tpos = gposB + W4_ROWS_A;
+        const int* tres = tpos + W4_TILES;
+        const int n0 = bk.ntile * BN, b0 = bk.b0;
+        const char* wbase = a.wp + (long)bk.par * a.wset_stride;   // wave-uniform; the lane's 16 bytes are added by the load
+        const int vn = v + (int)gridDim.x;
+        const bool more = PIPE && vn < a.nvirt;
+        const W4Brick bn_ = more ? w4_decode<BN>(a, vn) : bk;
+        int* gposAn = reinterpret_cast<int*>(smem + a.tofs + (set ^ 1) * W4_TABLE_BYTES);
+        // V buffers (LDS rows): pass A alternates between the two 64 KB regions starting at `flip`; pass B's two 32 KB buffers
+        // live in region `flip` (pass A's last chunk -- an odd one -- reads the other region)
+        const int rA0 = PIPE ? flip * 1024 : 0, rA1 = PIPE ? (flip ^ 1) * 1024 : W4_ROWS_A;
+        const int rB0 = rA0, rB1 = rA0 + 512;
+
+        // ---- pass A: planes 0..3, wave = (plane, 32-channel half), all 128 tiles   [BN = 32: (plane, tile half)]
+        const int xa = wave & 3, nha = BN == 64 ? wave >> 2 : 0, mha = BN == 64 ? 0 : (wave >> 2) * 64;
+        f32x16 accA[WMA];
+        {
+            int arow[WMA];
 #pragma unroll
-            for (int x = 0; x < 6; ++x) {
-                const float4 v = *reinterpret_cast<const float4*>(E + (x * W4_TILES + (tile ^ ((tile >> 2) & 1))) * 32 + 4 * n4);
-                mx[x][0] = v.x; mx[x][1] = v.y; mx[x][2] = v.z; mx[x][3] = v.w;
+            for (int wm = 0; wm < WMA; ++wm) {
+                int m = mha + wm * 32 + l31;
+                const int ij = m & 3; m >>= 2;
+                const int ih = m & (a.TH - 1); m >>= a.th_shift;
+                arow[wm] = xa * plane + (m * HH + ih) * 4 + ij;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
             }
+            const W4Next none{gposA, 0u, 0u, 0};
+            w4_pass<NT, WMA, 4, false, PIPE>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid,
+                                             lane, wave, rA0, rA1, none, [] {}, w4_tlv_);
+        }
+        W4_STAMP(2)
+        // ---- pass B: planes 4, 5, wave = (plane, 32-channel half, tile half)   [BN = 32: (plane, tile quarter)]
+        const int xb = wave & 1, nhb = BN == 64 ? (wave >> 1) & 1 : 0, mhb = BN == 64 ? (wave >> 2) * 64 : (wave >> 1) * 32;
+        f32x16 accB[WMB];
+        {
+            int arow[WMB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s12 = mx[1][j] + mx[2][j], d12 = mx[1][j] - mx[2][j];
-                const float s34 = mx[3][j] + mx[4][j], d34 = mx[3][j] - mx[4][j];
-                const float y[4] = {mx[0][j] + s12 + s34, fmaf(2.f, d34, d12), fmaf(4.f, s34, s12), fmaf(8.f, d34, d12) + mx[5][j]};
+            for (int wm = 0; wm < WMB; ++wm) {
+                int m = mhb + wm * 32 + l31;
+                const int ij = m & 3; m >>= 2;
+                const int ih = m & (a.TH - 1); m >>= a.th_shift;
+                arow[wm] = xb * plane + (m * HH + ih) * 4 + ij;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float v = fmaf(y[c], a.oscale, bv[j]) + rres[it][c][j];
-                    if (ncol) {
-                        ssum[j] += (double)v;
-                        ssq[j] = fma((double)v, (double)v, ssq[j]);
+                for (int r = 0; r < 16; ++r) accB[wm][r] = 0.f;
+            }
+            // (chunk 0 of this brick was requested by pass A behind its last chunk and published by its last barrier; pass B's
+            //  own request behind ITS last chunk re-reads its chunk 0 harmlessly)
+            const W4Next nxt{(more ? gposAn : gposA) + (tid >> 2),
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(flip ^ 1) * 65536u + (unsigned)wave * 1024u)),
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)flip * 65536u + 30720u)), more ? 1 : 0};   // dump: rows 480..495 of pass B's first buffer (zero padding, never read)
+            w4_pass<NT, WMB, 2, true, PIPE>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid,
+                                            lane, wave, rB0, rB1, nxt, [&] {
+                                                // (PIPE) the next brick's tables, built while this pass's first weight fragments
+                                                // travel; published by the barrier in front of the loop
+                                                if constexpr (PIPE) { if (more) w4_tables<KT>(a, bn_, gposAn, tid); }
+                                            }, w4_tlv_);
+        }
+        W4_STAMP(4)
+
+        // ---- epilogue: E = [6 planes][tiles][32 channels] fp32.  A wave's ds_write_b32 stores the rows m (lanes 0..31) and m + 4
+        // (lanes 32..63) of an accumulator register: 512 bytes apart = the same 32 banks.  Tile m is therefore kept in row
+        // m ^ ((m >> 2) & 1), which puts the two halves of the wave on the two halves of the banks.
+        // !PIPE: one 32-channel half at a time, all 128 tiles (98 KB over both V regions).  PIPE: (32-channel half, 64-tile half)
+        // quarters of 48 KB inside pass B's region -- the other region holds the next brick's first V brick already.
+        constexpr int NQ = 8, TPI = 64;
+        constexpr int NTH = PIPE ? 2 : 1;             // tile halves per channel half
+        constexpr int ET = W4_TILES / NTH;            // tiles in E
+        constexpr int NIT = ET / TPI;
+        float* E = reinterpret_cast<float*>(smem + (PIPE ? flip * 65536 : 0));
+        double* S = reinterpret_cast<double*>(reinterpret_cast<char*>(E) + 6 * ET * 32 * 4);   // [2 halves][8 waves][32 channels][2] behind E
+        const int n4 = tid % NQ;
+        const int e3 = kg * 96, e5 = kg * 160;   // row offsets (in floats) of the wave's upper lanes, see the E writes
+#pragma unroll 1
+        for (int half = 0; half < BN / 32; ++half) {
+            const int n = n0 + half * 32 + 4 * n4;
+            const bool ncol = n < a.Cout;
+            double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
+            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias && ncol) bias = *reinterpret_cast<const float4*>(a.bias + n);
+            const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll 1
+            for (int th = 0; th < NTH; ++th) {
+                const int tb = th * ET;               // first tile of this E
+                // residual rows first, all of them, so that their latency hides behind the LDS exchange.  (PIPE: requesting both
+                // tile halves' rows in front of the first one costs 16 spilled registers in the 64-channel kernels; per quarter
+                // the loads queue behind the previous quarter's stores, which the exchange's two barriers mostly cover.)
+                f32x4 rres[NIT][4];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        rres[it][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (a.res && ncol)
+                            rres[it][c] = *reinterpret_cast<const f32x4*>(a.res + (long)tres[4 * (tb + tid / NQ + TPI * it) + c] * a.Cout + n);
                     }
-                    if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
-                    rres[it][c][j] = v;
+                __syncthreads();   // the V bricks / the previous E are no longer read
+                if (half == 0 && th == 0) W4_STAMP(8)
+                if (nha == half) {
+#pragma unroll
+                    for (int wm = 0; wm < WMA; ++wm) {
+                        const int m0 = mha + wm * 32 - tb;    // first tile of this row block inside E (wave-uniform)
+                        if (m0 >= 0 && m0 < ET) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                // tile m = c + 4 kg sits in row m ^ ((m >> 2) & 1) = c + (r odd ? 3 : 5) kg: two base addresses + immediates
+                                const int c = m0 + (r & 3) + 8 * (r >> 2);
+                                E[(xa * ET + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accA[wm][r];
+                            }
+                        }
+                    }
                 }
-            }
-        }
-        if (ncol) {
+                if (nhb == half) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const long p = tpos[tid / NQ + TPI * it];
+                    for (int wm = 0; wm < WMB; ++wm) {
+                        const int m0 = mhb + wm * 32 - tb;
+                        if (m0 >= 0 && m0 < ET) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.out + (p + c) * a.Cout + n) = rres[it][c];
-            }
-        }
-        if (half == 0) W4_STAMP(10)
-        if (a.stats) {
-            // lanes of a wave that share (lane % NQ) hold the same four channels -> wavefront shuffles; the eight waves'
-            // partials meet in LDS (behind E) and one wave per channel half issues its 2 x 32 fp64 atomics
+                            for (int r = 0; r < 16; ++r) {
+                                const int c = m0 + (r & 3) + 8 * (r >> 2);
+                                E[((4 + xb) * ET + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accB[wm][r];
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (half == 0 && th == 0) W4_STAMP(9)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (NQ <= 8) { ssum[j] = wave_xor_add_f64<8>(ssum[j]); ssq[j] = wave_xor_add_f64<8>(ssq[j]); }
-                ssum[j] = wave_xor_add_f64<16>(ssum[j]); ssq[j] = wave_xor_add_f64<16>(ssq[j]);
-                ssum[j] = wave_xor_add_f64<32>(ssum[j]); ssq[j] = wave_xor_add_f64<32>(ssq[j]);
+                for (int it = 0; it < NIT; ++it) {
+                    const int tile = tid / NQ + TPI * it;
+                    float mx[6][4];
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) {
+                        const float4 vv = *reinterpret_cast<const float4*>(E + (x * ET + (tile ^ ((tile >> 2) & 1))) * 32 + 4 * n4);
+                        mx[x][0] = vv.x; mx[x][1] = vv.y; mx[x][2] = vv.z; mx[x][3] = vv.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float s12 = mx[1][j] + mx[2][j], d12 = mx[1][j] - mx[2][j];
+                        const float s34 = mx[3][j] + mx[4][j], d34 = mx[3][j] - mx[4][j];
+                        const float y[4] = {mx[0][j] + s12 + s34, fmaf(2.f, d34, d12), fmaf(4.f, s34, s12), fmaf(8.f, d34, d12) + mx[5][j]};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float vv = fmaf(y[c], a.oscale, bv[j]) + rres[it][c][j];
+                            if (ncol) {
+                                ssum[j] += (double)vv;
+                                ssq[j] = fma((double)vv, (double)vv, ssq[j]);
+                            }
+                            if (a.epi & EPI_LRELU) vv = vv >= 0.f ? vv : 0.2f * vv;
+                            rres[it][c][j] = vv;
+                        }
+                    }
+                }
+                if (ncol) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const long p = tpos[tb + tid / NQ + TPI * it];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.out + (p + c) * a.Cout + n) = rres[it][c];
+                    }
+                }
+                if (half == 0 && th == 0) W4_STAMP(10)
             }
-            // (each half has its own 4 KB of S: the cross-wave sums and the atomics of both halves wait until after the loop,
-            //  one barrier and two waves instead of a barrier and a serial section of wave 0 per half)
-            double* Sh = S + half * (8 * 32 * 2);
-            if (lane < NQ) {
+            if (a.stats) {
+                // lanes of a wave that share (lane % NQ) hold the same four channels -> wavefront shuffles; the eight waves'
+                // partials meet in LDS (behind E) and one wave per channel half issues its 2 x 32 fp64 atomics
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    Sh[(wave * 32 + 4 * lane + j) * 2] = ssum[j];
-                    Sh[(wave * 32 + 4 * lane + j) * 2 + 1] = ssq[j];
+                    if constexpr (NQ <= 8) { ssum[j] = wave_xor_add_f64<8>(ssum[j]); ssq[j] = wave_xor_add_f64<8>(ssq[j]); }
+                    ssum[j] = wave_xor_add_f64<16>(ssum[j]); ssq[j] = wave_xor_add_f64<16>(ssq[j]);
+                    ssum[j] = wave_xor_add_f64<32>(ssum[j]); ssq[j] = wave_xor_add_f64<32>(ssq[j]);
+                }
+                // (each half has its own 4 KB of S: the cross-wave sums and the atomics of both halves wait until after the loop,
+                //  one barrier and two waves instead of a barrier and a serial section of wave 0 per half)
+                double* Sh = S + half * (8 * 32 * 2);
+                if (lane < NQ) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Sh[(wave * 32 + 4 * lane + j) * 2] = ssum[j];
+                        Sh[(wave * 32 + 4 * lane + j) * 2 + 1] = ssq[j];
+                    }
                 }
             }
+            W4_STAMP(5 + half)
         }
-        W4_STAMP(5 + half)
-    }
-    if (a.stats) {
-        __syncthreads();
-        if (wave < BN / 32 && lane < 32 && n0 + wave * 32 + lane < a.Cout) {   // wave h sums channel half h
-            const double* Sh = S + wave * (8 * 32 * 2);
-            double s0 = 0.0, s1 = 0.0;
+        if (a.stats) {
+            __syncthreads();
+            if (wave < BN / 32 && lane < 32 && n0 + wave * 32 + lane < a.Cout) {   // wave h sums channel half h
+                const double* Sh = S + wave * (8 * 32 * 2);
+                double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                s0 += Sh[(w * 32 + lane) * 2];
-                s1 += Sh[(w * 32 + lane) * 2 + 1];
+                for (int w = 0; w < 8; ++w) {
+                    s0 += Sh[(w * 32 + lane) * 2];
+                    s1 += Sh[(w * 32 + lane) * 2 + 1];
+                }
+                double* dst = a.stats + ((long)b0 * a.Cout + n0 + wave * 32 + lane) * 2;
+                atomicAdd(dst, s0);
+                atomicAdd(dst + 1, s1);
             }
-            double* dst = a.stats + ((long)b0 * a.Cout + n0 + wave * 32 + lane) * 2;
-            atomicAdd(dst, s0);
-            atomicAdd(dst + 1, s1);
         }
+        W4_STAMP(7)
+        if (!more) break;
+        v = vn; bk = bn_; flip ^= 1; set ^= 1;
+        w4_tlv_ = v;
+        W4_STAMP(0)
     }
-    W4_STAMP(7)
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -712,14 +833,53 @@ int Wino4Weights::pack_tdup(const float* w_src, const float* bias_src, int cout,
     return I2V_OK;
 }
 
-template <int NT, int BN>
-static int launch_wino4(const W4Args& a, unsigned nblk, size_t lds, hipStream_t st) {
-    auto kern = conv_wino4_f16x3_kernel<NT, BN>;
+template <int NT, int BN, bool PIPE>
+static int launch_wino4_(const W4Args& a, unsigned grid, size_t lds, hipStream_t st) {
+    auto kern = conv_wino4_f16x3_kernel<NT, BN, PIPE>;
     static bool attr_set[I2V_MAX_DEV] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
+}
+
+// compute units of the current device (one persistent workgroup each)
+static int device_cus() {
+    static int cus[I2V_MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= I2V_MAX_DEV) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+template <int NT, int BN>
+static int launch_wino4(W4Args& a, unsigned nblk, hipStream_t st) {
+    a.nvirt = (int)(a.tdup ? 2 * nblk : nblk);
+    static const int env_pipe = getenv("I2V_W4_PIPE") ? atoi(getenv("I2V_W4_PIPE")) : W4_DEFAULT_PIPE;
+    const int body = 2 * W4_ROWS_A * 64;   // two V regions (pass B and the epilogue's exchange buffer reuse them)
+    a.tofs = body;
+#ifdef W4_TAPTIME
+    const bool pipe = false;
+#else
+    const bool pipe = env_pipe != 0;
+#endif
+    if (pipe) {
+        // one workgroup per CU, a multiple of 8 so that a virtual workgroup keeps its XCD
+        int grid = std::min(a.nvirt, device_cus());
+        if (grid >= 8) grid &= ~7;
+        const size_t lds = (size_t)body + 2 * (size_t)W4_TABLE_BYTES;
+        return launch_wino4_<NT, BN, true>(a, (unsigned)grid, lds, st);
+    }
+#ifdef W4_TAPTIME
+    const size_t lds = 160 * 1024;
+#else
+    const size_t lds = (size_t)body + (size_t)W4_TABLE_BYTES;
+#endif
+    return launch_wino4_<NT, BN, false>(a, (unsigned)a.nvirt, lds, st);
 }
 
 int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T, int H,
@@ -752,14 +912,7 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     while ((1 << a.th_shift) < TH) ++a.th_shift;
     I2V_REQUIRE((1 << a.th_shift) == TH, I2V_E_INVALID, "wino4: brick height %d is not a power of two", TH);
     a.hh_magic = ((1 << 20) + TH + 1) / (TH + 2);
-    const int body = 2 * W4_ROWS_A * 64;   // two V bricks of pass A (pass B and the epilogue's exchange buffer reuse them)
-    a.tofs = body;
-#ifdef W4_TAPTIME
-    const size_t lds = 160 * 1024;
-#else
-    const size_t lds = (size_t)body + (size_t)(2 * W4_ROWS_A) * 4 + W4_TILES * 4 + W4_TILES * 16;
-#endif
-    I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "wino4: LDS %zu bytes", lds);
+    I2V_REQUIRE(2 * 4 * (TT + wts.KT - 1) * (TH + 2) + 16 <= W4_ROWS_A / 2, I2V_E_INVALID, "wino4: pass B's brick leaves no padding rows");
     I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
     int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
     static const int env_bn = getenv("I2V_W4_BN") ? atoi(getenv("I2V_W4_BN")) : 0;        // measurement switches
@@ -772,18 +925,18 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     I2V_REQUIRE((long)B * T * a.nchunk * 6 * H * a.J < (1L << 31) && (long)B * (wts.tdup ? 2 * T : T) * H * W < (1L << 31), I2V_E_INVALID,
                 "wino4: batch %d too large for the 32-bit row indices of this kernel ([%d,%d,%d] x %d chunks)", B, T, H, W, a.nchunk);
     if (getenv("I2V_W4_TRACE")) {
-        fprintf(stderr, "wino4: B %d T %d H %d W %d Cin %d Cout %d pad %d KT %d tdup %d TT %d TH %d res %p rt %d rs %d stats %p epi %d nblk %ld lds %zu\n", B, T, H, W,
-                a.Cin, a.Cout, a.CoutPad, wts.KT, a.tdup, TT, TH, (const void*)res, a.rt, a.rs, (void*)stats, epi, nblk, lds);
+        fprintf(stderr, "wino4: B %d T %d H %d W %d Cin %d Cout %d pad %d KT %d tdup %d TT %d TH %d res %p rt %d rs %d stats %p epi %d nblk %ld\n", B, T, H, W,
+                a.Cin, a.Cout, a.CoutPad, wts.KT, a.tdup, TT, TH, (const void*)res, a.rt, a.rs, (void*)stats, epi, nblk);
         (void)hipDeviceSynchronize();
     }
     if (BN == 64) {
-        if (wts.KT == 3) return launch_wino4<9, 64>(a, (unsigned)nblk, lds, st);
-        if (wts.KT == 2) return launch_wino4<6, 64>(a, (unsigned)nblk, lds, st);
-        return launch_wino4<3, 64>(a, (unsigned)nblk, lds, st);   // one time slice: SPADE's 2-D convs
+        if (wts.KT == 3) return launch_wino4<9, 64>(a, (unsigned)nblk, st);
+        if (wts.KT == 2) return launch_wino4<6, 64>(a, (unsigned)nblk, st);
+        return launch_wino4<3, 64>(a, (unsigned)nblk, st);   // one time slice: SPADE's 2-D convs
     }
     I2V_REQUIRE(wts.KT != 1, I2V_E_INVALID, "wino4: the 1x3x3 variant exists for 64-channel tiles only");
-    if (wts.KT == 3) return launch_wino4<9, 32>(a, (unsigned)nblk, lds, st);
-    return launch_wino4<6, 32>(a, (unsigned)nblk, lds, st);
+    if (wts.KT == 3) return launch_wino4<9, 32>(a, (unsigned)nblk, st);
+    return launch_wino4<6, 32>(a, (unsigned)nblk, st);
 }
 
 #ifdef W4_TAPTIME

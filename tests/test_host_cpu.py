@@ -327,16 +327,19 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     text = asm.read_text()
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import check_asm_waits as caw
-    kernels = re.findall(r"^(_ZN3i2v23conv_wino4_f16x3_kernelILi(\d)ELi(\d+)EEEvNS_6W4ArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+    kernels = re.findall(r"^(_ZN3i2v23conv_wino4_f16x3_kernelILi(\d)ELi(\d+)ELb(\d)EEEvNS_6W4ArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
                          flags=re.S | re.M)
-    assert len(kernels) == 5, [k[0] for k in kernels]     # <9,64> <6,64> <3,64> (SPADE's 2-D convs) <9,32> <6,32>
-    for name, nt, bn, whole in kernels:
+    # <9,64> <6,64> <3,64> (SPADE's 2-D convs) <9,32> <6,32>, each as the software-pipelined persistent kernel (PIPE = 1) and as
+    # round 3's one-workgroup-per-brick kernel (PIPE = 0)
+    assert len(kernels) == 10, [k[0] for k in kernels]
+    for name, nt, bn, pipe, whole in kernels:
         nt = int(nt)
         assert "scratch_" not in whole and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", whole), name
         loops = [mm.group(2) for mm in re.finditer(r"^(\.LBB\d+_\d+):[^\n]*\n((?:(?!^\.LBB).)*?)s_cbranch_\w+ \1\n", whole, flags=re.S | re.M)
                  if "v_mfma" in mm.group(2)]
         assert len(loops) == 2, (name, len(loops))
-        for loop, wm, vh in zip(loops, (4, 2) if bn == "64" else (2, 1), (4, 2)):
+        # PIPE: pass B's half-requests carry two extra loads (the next brick's first V brick)
+        for loop, wm, vh in zip(loops, (4, 2) if bn == "64" else (2, 1), (4, 4) if pipe == "1" else (4, 2)):
             taps = 2 * nt
             assert loop.count("v_mfma_f32_32x32x16_f16") == taps * 3 * wm, name
             assert loop.count("global_load_lds_dwordx4") == 2 * 2 * vh, name                 # two half-requests per chunk
