@@ -268,12 +268,11 @@ def main():
     # steady state: >= 10 s of back-to-back steps (a fresh box clocks higher for the first seconds than under sustained load)
     sustained = None
     if not args.no_extras and args.sustain > 0:
-        n_s = max(int(args.sustain / max(dt / args.steps, 1e-4)) + 1, args.steps)
+        n_c = max(int(args.sustain / 5 / max(dt / args.steps, 1e-4)), 1)   # steps per chunk: about a fifth of the span
         chunks, done_s = [], 0
         barrier()
         ts0 = time.perf_counter()
-        while done_s < n_s:
-            n_c = min(max(n_s // 5, 1), n_s - done_s)
+        while time.perf_counter() - ts0 < args.sustain + 0.05:             # time-based: at least `sustain` seconds
             tc = time.perf_counter()
             run_steps(n_c)
             collator.result()
@@ -282,8 +281,8 @@ def main():
             done_s += n_c
         tot_s = time.perf_counter() - ts0
         sustained = {"seconds": tot_s, "steps": done_s, "ms_per_step": tot_s / done_s * 1e3,
-                     "ms_per_step_by_fifth": chunks, "frames_per_s": frames_per_step * done_s / tot_s,
-                     "note": "back-to-back pipelined steps after the timed region, same code path; fifths in time order"}
+                     "ms_per_step_by_chunk": chunks, "frames_per_s": frames_per_step * done_s / tot_s,
+                     "note": "back-to-back pipelined steps after the timed region, same code path; chunks in time order"}
         bad = [k for k, v in enumerate(step_sums[-done_s:]) if int(v.item()) != ref_sum] if done_s <= 4096 else []
         if bad:
             raise SystemExit(f"bench.py: sustained-load steps {bad[:8]} differ from the serial reference")

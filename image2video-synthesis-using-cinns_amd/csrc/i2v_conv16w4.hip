@@ -77,7 +77,7 @@ __device__ unsigned long long w4_tt[2 * 8 * 18 * 2];   // [pass][wave][tap slot]
 #define W4_TT(U)
 #endif
 constexpr int W4_DEFAULT_PIPE = 1;    // 1: software-pipelined persistent kernel (I2V_W4_PIPE=0: one workgroup per brick, round 3's structure)
-constexpr int W4_DEFAULT_ORDER = 0;   // brick -> XCD order (kernel comment); I2V_W4_ORDER overrides for A/B runs
+constexpr int W4_DEFAULT_ORDER = 2;   // brick -> XCD order (kernel comment); I2V_W4_ORDER overrides for A/B runs
 constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
 constexpr int W4_KC = 16;       // input channels per K chunk
 constexpr int W4_ROWS_A = 1024; // staged V rows per buffer, pass A (4 planes); pass B stages 512 (2 planes)
@@ -917,7 +917,11 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
     static const int env_bn = getenv("I2V_W4_BN") ? atoi(getenv("I2V_W4_BN")) : 0;        // measurement switches
     static const int env_order = getenv("I2V_W4_ORDER") ? atoi(getenv("I2V_W4_ORDER")) : W4_DEFAULT_ORDER;
+    // 64-channel workgroups that would leave CUs idle (16x16 maps at small batches) become twice as many 32-channel ones: the
+    // accumulation order of every output does not depend on the tile width, so the bits are the same
+    if (BN == 64 && wts.KT != 1 && (long)B * (T / TT) * (H / TH) * (a.J / 4) * (a.CoutPad / 64) * (wts.tdup ? 2 : 1) < device_cus()) BN = 32;
     if (env_bn == 32 && wts.KT != 1) BN = 32;
+    if (env_bn == 64 && a.CoutPad % 64 == 0) BN = 64;
     a.order = env_order;
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);

@@ -813,9 +813,11 @@ bool want_wino0(const i2v_dec* d, const Block& b, const Level& l) {
 bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
     return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
 }
-// F(4,3): its bricks hold 512 output positions x 64 channels -- only where one SAMPLE already gives >= 32 workgroups (the
-// per-GPU batch of the 8-GPU jobs is 8), i.e. from the 32x32 level on; 16x16 maps stay on the F(2,3) kernel
-bool w4_fills(const Level& l, int cout) { return (long)l.T * l.H * l.W / 512 * std::max(cout / 64, 1) >= 32; }
+// F(4,3): its bricks hold 512 output positions x 64 or 32 channels (the launcher picks 32-channel workgroups when 64-channel ones
+// would not fill the chip; both give the same bits) -- wherever one SAMPLE gives >= 16 workgroups of 32 channels, i.e. from the
+// 16x16 level on (round 3 stopped at 32x32: g_1 ran F(2,3); measured at B = 64: g_1.conv_0 1.94 -> 1.49 ms, conv_1 1.47 -> 1.13,
+// at B = 8 equal).  The rule depends on the layer only, never on the batch: shards reproduce the full batch bit for bit.
+bool w4_fills(const Level& l, int cout) { return (long)l.T * l.H * l.W / 512 * std::max(cout / 32, 1) >= 16; }
 bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l) {
     const bool tdup = l.ut == 2;
     return d->cfg.mma == 1 && d->wino && d->wino4 && (d->wino4 == 2 || w4_fills(l, b.n_mid)) &&

@@ -529,7 +529,7 @@ int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
     std::vector<int> sf((size_t)nf * 64), sb((size_t)nf * 64);
     f->an_logdet.assign(nf, 0.f);
     f->step_cond.assign(S, 0);
-    size_t pbytes = 0;
+    size_t pbytes = 0, wfloats = 0;
     for (int fl = 0; fl < nf; ++fl) {
         const std::string p = "sub_layers." + std::to_string(fl) + ".";
         const bool cond = f->cfg.control == 2 || (f->cfg.control == 1 && fl % 4 != 0);  // flow_blocks.py:24
@@ -590,6 +590,7 @@ int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
                     b3[(size_t)step * 64 + net * 32 + c] = bb3[c];
                 }
                 pbytes += ((size_t)H * dim + H + (size_t)D * ((size_t)H * H + H) + (size_t)32 * H + 32) * 4;
+                wfloats += (size_t)H * dim + (size_t)D * H * H + (size_t)32 * H;   // the weight matrices alone
             }
         }
     }
@@ -618,8 +619,13 @@ int i2v_flow_load(i2v_flow* f, const i2v_tensor* tensors, int32_t n_tensors) {
     if ((rc = f->shuf_f.upload(sf.data(), sf.size() * 4))) return rc;
     if ((rc = f->shuf_b.upload(sb.data(), sb.size() * 4))) return rc;
     f->tile.ok = false;
+    I2V_REQUIRE(!f->cfg.linear_f16 || (f->tile_wanted && flow_tile_geometry_ok(f->cfg.in_channels, H, D, E)), I2V_E_INVALID,
+                "i2v_flow_load: linear_f16 needs the matrix-core tile chain (64 channels, hidden 128..512 in steps of 128, depth >= 1, E <= 128)");
     if (f->tile_wanted && flow_tile_geometry_ok(f->cfg.in_channels, H, D, E)) {
-        if ((rc = flow_tile_pack(f->tile, S, H, D, E, W0.data(), Wmid.data(), W3T.data()))) return rc;
+        if ((rc = flow_tile_pack(f->tile, S, H, D, E, W0.data(), Wmid.data(), W3T.data(), f->cfg.linear_f16 != 0))) return rc;
+    }
+    if (f->cfg.linear_f16) {   // the weight matrices stream as fp16 (biases, ActNorm, Shuffle stay 4-byte)
+        pbytes -= wfloats * 2;
     }
     f->param_bytes = pbytes;
     f->loaded = true;

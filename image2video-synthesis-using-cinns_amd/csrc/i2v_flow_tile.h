@@ -28,6 +28,11 @@ struct FlowTilePack {
     DevBuf io;   // one FlowIo
     FlowIo io_host{};  // what the device copy holds
     bool ok = false;
+    // fp16-operand mode (BASELINE configs[4] "fp16 MFMA conditioning GEMM"; i2v_flow_cfg.linear_f16): every Linear of the s- / t-nets
+    // runs v_mfma_f32_16x16x16_f16 -- weights rounded to fp16 once at load (the same fragments with 8 instead of 16 bytes per lane:
+    // half the streamed parameter bytes), activations rounded to fp16 per layer in registers, fp32 accumulation, bias / LeakyReLU /
+    // coupling / log-det in fp32.  One MFMA per 16 x 16 x 16 block instead of four.
+    bool f16 = false;
 };
 
 // geometry the tile chain covers (every shipped config: 64 channels, hidden 512, depth 2); anything else runs the generic
@@ -37,7 +42,7 @@ inline bool flow_tile_geometry_ok(int in_channels, int H, int depth, int E) {
 }
 
 // host weights in the layouts i2v_flow_load builds: W0 [S][2H][32 + E], Wmid [S][depth][2H][H], W3T [S][H][64]
-int flow_tile_pack(FlowTilePack& p, int S, int H, int depth, int E, const float* W0, const float* Wmid, const float* W3T);
+int flow_tile_pack(FlowTilePack& p, int S, int H, int depth, int E, const float* W0, const float* Wmid, const float* W3T, bool f16 = false);
 
 struct FlowTileWs {
     size_t x, x2, logdet, pre, hA, hB, P, total;

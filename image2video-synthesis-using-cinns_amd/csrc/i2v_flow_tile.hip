@@ -31,6 +31,7 @@
 namespace i2v {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #ifdef FLOW_TIMELINE   // measurement build (tools/flow_timeline.py): wall-clock stamps (100 MHz) per launch and workgroup phase
 constexpr int FTL_LAUNCHES = 512, FTL_WGS = 64, FTL_ST = 8;
@@ -51,6 +52,28 @@ namespace {
 
 __device__ __forceinline__ v4f ld4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
 __device__ __forceinline__ void st4(float* p, v4f v) { *reinterpret_cast<v4f*>(p) = v; }
+// One 16 x 16 x 16 block D += A . B with A = a weight fragment (fp32: 16 bytes per lane, four v_mfma_f32_16x16x4_f32 steps; F16: 8 bytes
+// per lane, ONE v_mfma_f32_16x16x16_f16 -- lane (q, m) holds A[m][4q .. 4q+3] in both) and B = an activation tile in the
+// accumulator-fragment layout (fp32; F16: rounded to fp16 here, round-to-nearest-even).
+template <bool F16> struct WFrag { typedef v4f T; };
+template <> struct WFrag<true> { typedef h4 T; };
+template <bool F16>
+__device__ __forceinline__ typename WFrag<F16>::T ldw(const void* base, size_t frag, int lane) {
+    if constexpr (F16) return *reinterpret_cast<const h4*>(static_cast<const char*>(base) + frag * 512 + lane * 8);
+    else return *reinterpret_cast<const v4f*>(static_cast<const char*>(base) + frag * 1024 + lane * 16);
+}
+template <bool F16>
+__device__ __forceinline__ v4f mma16(typename WFrag<F16>::T a, v4f b, v4f d) {
+    if constexpr (F16) {
+        const h4 bh = {(_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, bh, d, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], d, 0, 0, 0);
+        return d;
+    }
+}
+
 __device__ __forceinline__ v4f lrelu4(v4f v, float slope) {
     v4f o;
 #pragma unroll
@@ -74,6 +97,7 @@ constexpr int PRE_LD = 128 + 4;  // LDS row stride (floats): 16-byte aligned row
 
 // workgroup = 8 row tiles (one per wave) x PRE_SC sample tiles; the embeddings of the 64 samples are staged in LDS with
 // coalesced loads (rows of E floats) and read back as B fragments (lane (q, n), j -> embed[n][16 i + 4 q + j])
+template <bool F16>
 __global__ __launch_bounds__(512) void flow_pre_tile_kernel(PreTileArgs a) {
     __shared__ __attribute__((aligned(16))) float es[PRE_SC * 16][PRE_LD];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -84,10 +108,9 @@ __global__ __launch_bounds__(512) void flow_pre_tile_kernel(PreTileArgs a) {
     const bool rok = R < a.Rtiles;
     const int Rc = rok ? R : 0;
     const int step = Rc / a.NRT, rt = Rc - step * a.NRT;
-    const float* wp = a.W0E + ((size_t)Rc * a.KE16) * 256 + lane * 4;
-    v4f A[8];
+    typename WFrag<F16>::T A[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) A[i] = i < a.KE16 ? ld4(wp + i * 256) : v4f{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 8; ++i) A[i] = ldw<F16>(a.W0E, (size_t)Rc * a.KE16 + (i < a.KE16 ? i : 0), lane);
     const v4f bias = ld4(a.b0 + (size_t)Rc * 16 + q * 4);
     const float* emb = a.io->embed;
     const int b0 = sc * PRE_SC * 16, K = a.KE16 * 16;
@@ -105,9 +128,7 @@ __global__ __launch_bounds__(512) void flow_pre_tile_kernel(PreTileArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (i < a.KE16) {
-                const v4f bx = ld4(&es[t * 16 + n][16 * i + 4 * q]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][j], bx[j], D, 0, 0, 0);
+                D = mma16<F16>(A[i], ld4(&es[t * 16 + n][16 * i + 4 * q]), D);
             }
         st4(a.pre + (((size_t)step * a.NST + st) * a.NRT + rt) * 256 + lane * 4, D);
     }
@@ -127,8 +148,12 @@ struct HidTileArgs {
     int seq;
 };
 
-template <int KPW, int NS>
-__global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
+// (flat parameters, 15 dwords: with -mllvm -amdgpu-kernarg-preload-count=16 they arrive in SGPRs with the wave instead of
+//  through a scalar load at the head of every one of the pass's 80 dependent hidden-layer launches)
+template <int KPW, int NS, bool F16>
+__global__ __launch_bounds__(512) void flow_hid_tile_kernel(const float* WT_, const float* in_, const float* bias_, float* out_,
+                                                            const float* W3P_, float* P_, int NRT_, int NST_, int seq_) {
+    const HidTileArgs a{WT_, bias_, in_, out_, W3P_, P_, NRT_, NST_, seq_};
     __shared__ v4f red[8][NS][64];
     constexpr int HB = 8 * KPW;
     FTL_BEGIN(a.seq)
@@ -140,10 +165,10 @@ __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
     const int sg = slot / (HB / 4), rt = net * HB + (xcd & 3) + 4 * (slot - sg * (HB / 4)), st0 = sg * NS;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // operand requests: this wave's K slice (k16 blocks w*KPW ...) of the weight tile row and of NS activation tiles
-    v4f A[KPW], Bv[NS][KPW];
-    const float* wp = a.WT + ((size_t)rt * HB + w * KPW) * 256 + lane * 4;
+    typename WFrag<F16>::T A[KPW];
+    v4f Bv[NS][KPW];
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) A[i] = ld4(wp + i * 256);
+    for (int i = 0; i < KPW; ++i) A[i] = ldw<F16>(a.WT, (size_t)rt * HB + w * KPW + i, lane);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int st = st0 + s < a.NST ? st0 + s : a.NST - 1;
@@ -154,10 +179,11 @@ __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
     // epilogue operands of the waves that finish a tile: (sample tile es, column block cb of the final Linear)
     const int es = w >> 1, cb = w & 1;
     const bool epi = w < 2 * NS;
-    v4f bias4 = {0.f, 0.f, 0.f, 0.f}, A3 = {0.f, 0.f, 0.f, 0.f};
+    v4f bias4 = {0.f, 0.f, 0.f, 0.f};
+    typename WFrag<F16>::T A3 = {};
     if (epi) {
         bias4 = ld4(a.bias + rt * 16 + (lane >> 4) * 4);
-        if (a.W3P) A3 = ld4(a.W3P + ((size_t)rt * 2 + cb) * 256 + lane * 4);
+        if (a.W3P) A3 = ldw<F16>(a.W3P, (size_t)rt * 2 + cb, lane);
     }
     v4f D[NS];
 #pragma unroll
@@ -165,12 +191,19 @@ __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
     FTL_STAMP(a.seq, 1)   // requests issued
     FTL_LANDED()
     FTL_STAMP(a.seq, 2)   // operands landed
+    if constexpr (F16) {
 #pragma unroll
-    for (int i = 0; i < KPW; ++i)
+        for (int i = 0; i < KPW; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int s = 0; s < NS; ++s) D[s] = mma16<true>(A[i], Bv[s][i], D[s]);
+    } else {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) D[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][j], Bv[s][i][j], D[s], 0, 0, 0);
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) D[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][j], Bv[s][i][j], D[s], 0, 0, 0);
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) red[w][s][lane] = D[s];
     FTL_STAMP(a.seq, 3)   // MFMAs done, partial tiles parked
@@ -186,9 +219,7 @@ __global__ __launch_bounds__(512) void flow_hid_tile_kernel(HidTileArgs a) {
     if (a.out && cb == 0) st4(a.out + ((size_t)st * a.NRT + rt) * 256 + lane * 4, h);
     if (a.W3P) {
         // this tile's share of the final Linear: the accumulator fragment h IS the B operand (k = 16 rt + 4 q + j)
-        v4f d3 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[j], h[j], d3, 0, 0, 0);
+        const v4f d3 = mma16<F16>(A3, h, v4f{0.f, 0.f, 0.f, 0.f});
         st4(a.P + (((size_t)st * a.NRT + rt) * 2 + cb) * 256 + lane * 4, d3);
     }
     FTL_STAMP(a.seq, 5)   // reduce + epilogue MFMA + stores issued
@@ -221,7 +252,20 @@ struct TailTileArgs {
     int seq;
 };
 
-__global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
+// (flat parameters ordered by first use: the 16 dwords that the kernel's first vector loads need -- partial tiles, state, first-layer
+//  weights and biases, geometry, flags, the caller's pointer block -- are preloaded into SGPRs (-mllvm -amdgpu-kernarg-preload-count=16);
+//  what the later phases need arrives by scalar load underneath those vector loads)
+template <bool F16>
+__global__ __launch_bounds__(512) void flow_tail_tile_kernel(const float* P_, const float* x_, const float* W0T_, const float* pre_,
+                                                             const float* b3_, int NST_, int NRT_, int HB2_, int flags_, const FlowIo* io_,
+                                                             float* xo_, float* logdet_, const int* shuf_, const float* an_loc_,
+                                                             const float* an_scale_, float an_logdet_, float* h0_, int B_, int seq_) {
+    TailTileArgs a{};
+    a.P = P_; a.x = x_; a.W0T = W0T_; a.pre = pre_; a.b3 = b3_; a.NST = NST_; a.NRT = NRT_; a.HB2 = HB2_; a.io = io_;
+    a.io_in = flags_ & 1; a.io_out = (flags_ >> 1) & 1; a.ld_init = (flags_ >> 2) & 1; a.reverse = (flags_ >> 3) & 1;
+    a.do_lrelu = (flags_ >> 4) & 1; a.do_swap = (flags_ >> 5) & 1; a.l1 = (flags_ >> 6) & 3;
+    a.xo = xo_; a.logdet = logdet_; a.shuf = shuf_; a.an_loc = an_loc_; a.an_scale = an_scale_; a.an_logdet = an_logdet_; a.h0 = h0_;
+    a.B = B_; a.seq = seq_;
     __shared__ v4f ps[8][64];
     __shared__ __attribute__((aligned(16))) float xs[16][68];
     __shared__ __attribute__((aligned(16))) float xs2[16][68];
@@ -248,11 +292,12 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
     const int rpg = a.NRT >> 3;  // row tiles of the next first layer per row group
     const bool l0 = a.l1 != 0 && w < rpg;
     const int rt = rq * rpg + w;
-    v4f A0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, D = {0.f, 0.f, 0.f, 0.f};
+    typename WFrag<F16>::T A0[2] = {};
+    v4f D = {0.f, 0.f, 0.f, 0.f};
     if (l0) {
         if (a.l1 == 1) {
-            A0[0] = ld4(a.W0T + ((size_t)rt * 2) * 256 + lane * 4);
-            A0[1] = ld4(a.W0T + ((size_t)rt * 2 + 1) * 256 + lane * 4);
+            A0[0] = ldw<F16>(a.W0T, (size_t)rt * 2, lane);
+            A0[1] = ldw<F16>(a.W0T, (size_t)rt * 2 + 1, lane);
         }
         D = ld4(a.pre + ((size_t)st * a.NRT + rt) * 256 + lane * 4);
     }
@@ -341,11 +386,7 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
     if (l0) {
         if (a.l1 == 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const v4f bx = ld4(&xs2[n][16 * i + 4 * q]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) D = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[i][j], bx[j], D, 0, 0, 0);
-            }
+            for (int i = 0; i < 2; ++i) D = mma16<F16>(A0[i], ld4(&xs2[n][16 * i + 4 * q]), D);
         }
         st4(a.h0 + ((size_t)st * a.NRT + rt) * 256 + lane * 4, lrelu4(D, 0.01f));
     }
@@ -355,12 +396,12 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(TailTileArgs a) {
 
 __global__ void flow_set_io_kernel(FlowIo* dst, FlowIo v) { *dst = v; }
 
-template <int KPW>
+template <int KPW, bool F16>
 void launch_hid(const HidTileArgs& a, int ns, int groups, hipStream_t st) {
     const dim3 grid(a.NRT * groups), block(512);
-    if (ns == 1) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 1>), grid, block, 0, st, a);
-    else if (ns == 2) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 4>), grid, block, 0, st, a);
+    if (ns == 1) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 1, F16>), grid, block, 0, st, a.WT, a.in, a.bias, a.out, a.W3P, a.P, a.NRT, a.NST, a.seq);
+    else if (ns == 2) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 2, F16>), grid, block, 0, st, a.WT, a.in, a.bias, a.out, a.W3P, a.P, a.NRT, a.NST, a.seq);
+    else hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 4, F16>), grid, block, 0, st, a.WT, a.in, a.bias, a.out, a.W3P, a.P, a.NRT, a.NST, a.seq);
 }
 
 int env_int(const char* name, int dflt) {
@@ -370,8 +411,16 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-int flow_tile_pack(FlowTilePack& p, int S, int H, int depth, int E, const float* W0, const float* Wmid, const float* W3T) {
+static int upload_frags(DevBuf& dst, const std::vector<float>& w, bool f16) {
+    if (!f16) return dst.upload(w.data(), w.size() * 4);
+    std::vector<_Float16> h(w.size());
+    for (size_t i = 0; i < w.size(); ++i) h[i] = (_Float16)w[i];   // round to nearest even, once, at load
+    return dst.upload(h.data(), h.size() * 2);
+}
+
+int flow_tile_pack(FlowTilePack& p, int S, int H, int depth, int E, const float* W0, const float* Wmid, const float* W3T, bool f16) {
     p.ok = false;
+    p.f16 = f16;
     p.S = S; p.H = H; p.depth = depth; p.E = E;
     p.HB = H / 16; p.NRT = 2 * p.HB; p.KE16 = (E + 15) / 16;
     const int HB = p.HB, NRT = p.NRT, KE16 = p.KE16, N2 = 2 * H, ld0 = 32 + E;
@@ -410,10 +459,10 @@ int flow_tile_pack(FlowTilePack& p, int S, int H, int depth, int E, const float*
             }
         }
     int rc;
-    if ((rc = p.WT.upload(wt.data(), wt.size() * 4))) return rc;
-    if ((rc = p.W3P.upload(w3.data(), w3.size() * 4))) return rc;
-    if ((rc = p.W0T.upload(w0t.data(), w0t.size() * 4))) return rc;
-    if ((rc = p.W0E.upload(w0e.data(), w0e.size() * 4))) return rc;
+    if ((rc = upload_frags(p.WT, wt, f16))) return rc;
+    if ((rc = upload_frags(p.W3P, w3, f16))) return rc;
+    if ((rc = upload_frags(p.W0T, w0t, f16))) return rc;
+    if ((rc = upload_frags(p.W0E, w0e, f16))) return rc;
     FlowIo zero{};
     if ((rc = p.io.upload(&zero, sizeof(zero)))) return rc;
     p.io_host = zero;
@@ -462,13 +511,15 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     if (const int e = env_int("I2V_FLOW_NS", 0)) ns = e >= 4 ? 4 : e >= 2 ? 2 : 1;
     const int groups = (NST + ns - 1) / ns;
     int seq = 0;   // launch number inside the pass
+    const size_t fb = p.f16 ? 512 : 1024;   // bytes per weight fragment
 
     {   // embedding part of every first layer of the pass
         PreTileArgs a{};
         a.seq = seq++;
         a.W0E = p.W0E.as<float>(); a.b0 = c.b0; a.io = io; a.pre = pre;
         a.NRT = NRT; a.NST = NST; a.KE16 = p.KE16; a.E = p.E; a.B = B; a.Rtiles = S * NRT; a.nblk = (a.Rtiles + 7) / 8;
-        hipLaunchKernelGGL(flow_pre_tile_kernel, dim3(a.nblk * ((NST + PRE_SC - 1) / PRE_SC)), dim3(512), 0, st, a);
+        if (p.f16) hipLaunchKernelGGL(flow_pre_tile_kernel<true>, dim3(a.nblk * ((NST + PRE_SC - 1) / PRE_SC)), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(flow_pre_tile_kernel<false>, dim3(a.nblk * ((NST + PRE_SC - 1) / PRE_SC)), dim3(512), 0, st, a);
         I2V_HIP_CHECK(hipGetLastError());
     }
     auto step_of = [&](int it) {  // forward visits (fl, i) = (0,0),(0,1),(1,0)...; reverse visits (nf-1,1),(nf-1,0),(nf-2,1)...
@@ -493,11 +544,14 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
         t.do_lrelu = lrelu ? 1 : 0; t.do_swap = swap ? 1 : 0;
         if (next_step >= 0) {
             t.l1 = c.step_cond[next_step] ? 2 : 1;
-            t.W0T = p.W0T.as<float>() + (size_t)next_step * NRT * 512;
+            t.W0T = reinterpret_cast<const float*>(p.W0T.as<char>() + (size_t)next_step * NRT * 2 * fb);
             t.pre = pre + (size_t)next_step * NST * NRT * 256;
             t.h0 = hA;
         }
-        hipLaunchKernelGGL(flow_tail_tile_kernel, dim3((NST + 7) / 8 * 64), dim3(512), 0, st, t);
+        const int flags = t.io_in | t.io_out << 1 | t.ld_init << 2 | t.reverse << 3 | t.do_lrelu << 4 | t.do_swap << 5 | t.l1 << 6;
+        auto tk = p.f16 ? flow_tail_tile_kernel<true> : flow_tail_tile_kernel<false>;
+        hipLaunchKernelGGL(tk, dim3((NST + 7) / 8 * 64), dim3(512), 0, st, t.P, t.x, t.W0T, t.pre, t.b3, t.NST, t.NRT, t.HB2,
+                           flags, t.io, t.xo, t.logdet, t.shuf, t.an_loc, t.an_scale, t.an_logdet, t.h0, t.B, t.seq);
         I2V_HIP_CHECK(hipGetLastError());
         return I2V_OK;
     };
@@ -516,18 +570,27 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
         for (int d = 0; d < D; ++d) {
             HidTileArgs m{};
             m.seq = seq++;
-            m.WT = p.WT.as<float>() + ((size_t)step * D + d) * NRT * HB * 256;
+            m.WT = reinterpret_cast<const float*>(p.WT.as<char>() + ((size_t)step * D + d) * NRT * HB * fb);
             m.bias = c.bmid + ((size_t)step * D + d) * N2;
             m.in = cur;
             m.out = d == D - 1 ? nullptr : nxt;
-            m.W3P = d == D - 1 ? p.W3P.as<float>() + (size_t)step * NRT * 512 : nullptr;
+            m.W3P = d == D - 1 ? reinterpret_cast<const float*>(p.W3P.as<char>() + (size_t)step * NRT * 2 * fb) : nullptr;
             m.P = P;
             m.NRT = NRT; m.NST = NST;
-            switch (HB / 8) {
-                case 1: launch_hid<1>(m, ns, groups, st); break;
-                case 2: launch_hid<2>(m, ns, groups, st); break;
-                case 3: launch_hid<3>(m, ns, groups, st); break;
-                default: launch_hid<4>(m, ns, groups, st); break;
+            if (p.f16) {
+                switch (HB / 8) {
+                    case 1: launch_hid<1, true>(m, ns, groups, st); break;
+                    case 2: launch_hid<2, true>(m, ns, groups, st); break;
+                    case 3: launch_hid<3, true>(m, ns, groups, st); break;
+                    default: launch_hid<4, true>(m, ns, groups, st); break;
+                }
+            } else {
+                switch (HB / 8) {
+                    case 1: launch_hid<1, false>(m, ns, groups, st); break;
+                    case 2: launch_hid<2, false>(m, ns, groups, st); break;
+                    case 3: launch_hid<3, false>(m, ns, groups, st); break;
+                    default: launch_hid<4, false>(m, ns, groups, st); break;
+                }
             }
             I2V_HIP_CHECK(hipGetLastError());
             std::swap(cur, nxt);

@@ -30,7 +30,7 @@ class _Tensor(ctypes.Structure):
 
 class FlowCfg(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in ("in_channels", "embedding_dim", "hidden_dim", "hidden_depth", "n_flows",
-                                      "control", "activation", "skip_actnorm", "skip_shuffle", "use_graph")]
+                                      "control", "activation", "skip_actnorm", "skip_shuffle", "use_graph", "linear_f16")]
 
 
 class DecCfg(ctypes.Structure):
@@ -227,9 +227,10 @@ class NativeFlow(_Handle):
     """Handle for ``i2v_flow_*`` (ConditionalFlow, flow_blocks.py:8-60)."""
 
     def __init__(self, in_channels, embedding_dim, hidden_dim, hidden_depth, n_flows, control=False,
-                 activation="lrelu", skip_actnorm=False, skip_shuffle=False, use_graph=True, device=None):
+                 activation="lrelu", skip_actnorm=False, skip_shuffle=False, use_graph=True, device=None, linear_f16=None):
+        self.linear_f16 = default_flow_f16() if linear_f16 is None else int(bool(linear_f16))
         cfg = FlowCfg(in_channels, embedding_dim, hidden_dim, hidden_depth, n_flows, int(control),
-                      1 if activation == "lrelu" else 0, int(skip_actnorm), int(skip_shuffle), int(use_graph))
+                      1 if activation == "lrelu" else 0, int(skip_actnorm), int(skip_shuffle), int(use_graph), self.linear_f16)
         h = c_void_p()
         with self._bind(device):
             _check(lib().i2v_flow_create(ctypes.byref(cfg), ctypes.byref(h)), "i2v_flow_create")
@@ -475,6 +476,12 @@ def channel_mean_std(flat):
     with torch.cuda.device(flat.device):
         _check(lib().i2v_row_mean_std(flat.data_ptr(), C, N, mean.data_ptr(), std.data_ptr(), _stream()), "i2v_row_mean_std")
     return mean, std
+
+
+def default_flow_f16():
+    """Operand precision of the cINN's Linear layers: 0 = exact fp32 matrix cores (default), 1 = fp16 operands with fp32
+    accumulation (BASELINE configs[4]; i2v_flow_cfg.linear_f16); env I2V_FLOW_F16."""
+    return int(os.environ.get("I2V_FLOW_F16", "0"))
 
 
 def default_mma():

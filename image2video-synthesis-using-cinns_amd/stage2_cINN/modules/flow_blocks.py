@@ -46,10 +46,15 @@ class ConditionalFlow(NativeBacked):
         # opt-in: set ``record_intermediates = True`` (the lists stay empty otherwise)
         self.record_intermediates = False
         self._init_checked = False
+        # Not a reference argument: operand precision of the s- / t-net Linear layers.  None = env I2V_FLOW_F16 (default 0: exact
+        # fp32 matrix cores); 1 = fp16 operands, fp32 accumulation (BASELINE configs[4]'s "fp16 MFMA conditioning GEMM"; outside
+        # the 1e-4 fp32 gate).  Set it before the first call (or call refresh_native()).
+        self.linear_f16 = None
 
     def _build_native(self):
         h = native.NativeFlow(self.in_channels, self.cond_channels, self.mid_channels, self.num_blocks, self.n_flows,
-                              control=1 if self.control else 0, activation=self.activation, device=self.module_device())
+                              control=1 if self.control else 0, activation=self.activation, device=self.module_device(),
+                              linear_f16=self.linear_f16)
         h.load(self.state_dict())
         return h
 

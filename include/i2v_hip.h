@@ -69,6 +69,10 @@ typedef struct {
     int32_t skip_actnorm;  /* 1: no ActNorm  (used to expose the bare coupling block, :63-105) */
     int32_t skip_shuffle;  /* 1: no Shuffle */
     int32_t use_graph;     /* 1: replay the launch chain from a captured hipGraph */
+    int32_t linear_f16;    /* 1: fp16-operand mode of the s- / t-net Linear layers (BASELINE configs[4]: "fp16 MFMA conditioning
+                            * GEMM"): weights rounded to fp16 once at load, activations per layer, v_mfma_f32_16x16x16_f16 with fp32
+                            * accumulation; bias, LeakyReLU, coupling and log-det stay fp32.  NOT within the 1e-4 fp32 gate (z rel-L2
+                            * ~1e-3); 0 (default): exact fp32 matrix cores.  Needs the tile-chain geometry. */
 } i2v_flow_cfg;
 
 int i2v_flow_create(const i2v_flow_cfg* cfg, i2v_flow** out);

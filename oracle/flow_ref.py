@@ -11,8 +11,25 @@ Parity pin: checked against golden vectors produced by the reference's own modul
 Every function cites the reference lines (relative to /root/reference) it restates.
 ``sd`` is a ``ConditionalFlow.state_dict()``-shaped mapping {key: torch.Tensor}.
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
+
+# Emulation of the HIP path's optional fp16-operand mode (i2v_flow_cfg.linear_f16, BASELINE configs[4]): the operands of every
+# Linear of the s- / t-nets are rounded to fp16 (round-to-nearest-even), products and sums stay fp32 -- NOT what the reference
+# computes; used by the tests to pin that mode tightly, next to the looser comparison with the fp32 path.
+_LINEAR_F16 = False
+
+
+@contextlib.contextmanager
+def linear_f16_emulation(on=True):
+    global _LINEAR_F16
+    old, _LINEAR_F16 = _LINEAR_F16, bool(on)
+    try:
+        yield
+    finally:
+        _LINEAR_F16 = old
 
 
 def mlp(sd, prefix, x, depth=2):
@@ -20,7 +37,10 @@ def mlp(sd, prefix, x, depth=2):
     Linear -> LeakyReLU() [slope 0.01, modules.py:17,22] x (depth+1), final Linear."""
     h = x
     for li in range(depth + 2):
-        h = F.linear(h, sd[f"{prefix}main.{2 * li}.weight"], sd[f"{prefix}main.{2 * li}.bias"])
+        w = sd[f"{prefix}main.{2 * li}.weight"]
+        if _LINEAR_F16:
+            h, w = h.half().float(), w.half().float()
+        h = F.linear(h, w, sd[f"{prefix}main.{2 * li}.bias"])
         if li < depth + 1:
             h = F.leaky_relu(h, 0.01)
     return h
