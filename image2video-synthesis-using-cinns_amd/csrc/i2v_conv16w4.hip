@@ -76,7 +76,12 @@ __device__ unsigned long long w4_tt[2 * 8 * 18 * 2];   // [pass][wave][tap slot]
 #else
 #define W4_TT(U)
 #endif
-constexpr int W4_DEFAULT_PIPE = 1;    // 1: software-pipelined persistent kernel (I2V_W4_PIPE=0: one workgroup per brick, round 3's structure)
+// 0: one workgroup per brick (round 3's structure, the default); 1 (I2V_W4_PIPE=1): the software-pipelined persistent kernel.
+// Measured (profiles/r04_b_*): correct on every shape and in the whole GPU suite, but not faster -- per workgroup of the
+// 128 -> 128 layer it removes 1.9 us of prologue and 1.0 us of pass A and pays 0.7 us (tables under pass B's prologue), 1.5 us (pass B
+// with the extra loads) and 1.4 us (four-quarter epilogue): 81.9 -> 82.7 us; thin layers +2..4 %, wide ones -2..4 %; B = 64 BAIR step
+// 36.4 -> 37.2 ms, Landscape 12.10 -> 12.23 ms.  Kept selectable (and statically checked) as the base of further work.
+constexpr int W4_DEFAULT_PIPE = 0;
 constexpr int W4_DEFAULT_ORDER = 2;   // brick -> XCD order (kernel comment); I2V_W4_ORDER overrides for A/B runs
 constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
 constexpr int W4_KC = 16;       // input channels per K chunk
@@ -859,7 +864,8 @@ static int device_cus() {
 template <int NT, int BN>
 static int launch_wino4(W4Args& a, unsigned nblk, hipStream_t st) {
     a.nvirt = (int)(a.tdup ? 2 * nblk : nblk);
-    static const int env_pipe = getenv("I2V_W4_PIPE") ? atoi(getenv("I2V_W4_PIPE")) : W4_DEFAULT_PIPE;
+    const char* ep_ = getenv("I2V_W4_PIPE");   // (read per launch: tests and A/B runs switch it inside one process)
+    const int env_pipe = ep_ ? atoi(ep_) : W4_DEFAULT_PIPE;
     const int body = 2 * W4_ROWS_A * 64;   // two V regions (pass B and the epilogue's exchange buffer reuse them)
     a.tofs = body;
 #ifdef W4_TAPTIME
@@ -915,8 +921,9 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     I2V_REQUIRE(2 * 4 * (TT + wts.KT - 1) * (TH + 2) + 16 <= W4_ROWS_A / 2, I2V_E_INVALID, "wino4: pass B's brick leaves no padding rows");
     I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
     int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
-    static const int env_bn = getenv("I2V_W4_BN") ? atoi(getenv("I2V_W4_BN")) : 0;        // measurement switches
-    static const int env_order = getenv("I2V_W4_ORDER") ? atoi(getenv("I2V_W4_ORDER")) : W4_DEFAULT_ORDER;
+    const char* eb_ = getenv("I2V_W4_BN");        // measurement switches (read per launch)
+    const char* eo_ = getenv("I2V_W4_ORDER");
+    const int env_bn = eb_ ? atoi(eb_) : 0, env_order = eo_ ? atoi(eo_) : W4_DEFAULT_ORDER;
     // 64-channel workgroups that would leave CUs idle (16x16 maps at small batches) become twice as many 32-channel ones: the
     // accumulation order of every output does not depend on the tile width, so the bits are the same
     if (BN == 64 && wts.KT != 1 && (long)B * (T / TT) * (H / TH) * (a.J / 4) * (a.CoutPad / 64) * (wts.tdup ? 2 : 1) < device_cus()) BN = 32;

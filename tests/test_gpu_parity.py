@@ -291,6 +291,29 @@ def test_decoder_alternative_kernel_paths(env, monkeypatch):
     assert rel_l2(alt.cpu(), ref.cpu()) < 1e-5 and not torch.equal(alt, ref)   # a different kernel really ran
 
 
+@pytest.mark.parametrize("golden", ["dec_nf64_bair", "dec_nf32_128"])
+def test_f43_structure_switches_keep_the_bits(golden, monkeypatch):
+    """The F(4,3) kernel's measurement switches change WHERE and WHEN a brick is computed, never the arithmetic of an output:
+    the software-pipelined persistent kernel (I2V_W4_PIPE=1: next brick's tables and first V brick fetched under the current
+    brick's pass B, four-quarter epilogue), the brick -> XCD orders and 32-channel workgroups must reproduce the default
+    kernel's frames bit for bit, on the 64-channel (BAIR nf = 64) and the 32-channel (128x128 nf = 32) instantiations."""
+    g, meta = load_golden(golden)
+    x0, z, _ = synth.bench_inputs(3, g["img"].shape[-1], 64)     # 3 samples: grids that are not a multiple of the CU count
+    x0[1], z[1] = torch.from_numpy(g["img"][0]), torch.from_numpy(g["z"][0])
+    x0, z = x0.cuda(), z.cuda()
+    ref = _gen(meta)(x0, z)
+    assert rel_l2(ref[1:2, ..., ::2, ::2].cpu(), g["out_s2"]) < TOL
+    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32")):
+        monkeypatch.setenv(env, val)
+        alt = _gen(meta)(x0, z)
+        monkeypatch.delenv(env)
+        assert torch.equal(alt, ref), (env, val, float((alt - ref).abs().max()))
+    monkeypatch.setenv("I2V_W4_PIPE", "1")
+    gen = _gen(meta)
+    big = gen(x0.repeat(6, 1, 1, 1), z.repeat(6, 1))              # 18 samples: several bricks per persistent workgroup
+    assert torch.equal(big[:3], ref) and torch.equal(big[15:], ref)
+
+
 def _write_checkpoints(tmp_path, meta, with_embedder=False, with_encoder=False):
     """Checkpoint tree as get_model.Model expects it (get_model.py:15-43): <stage2>/config_stage2.yaml + cINN.pth,
     <stage1>/config_stage1.yaml + best_PFVD_GEN.pth."""

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Measurement builds (run in the build container; the .so / binaries travel to the GPU box with gpurun):
+#   tools/_tl/libi2v_hip_nopreload.so the library without -amdgpu-kernarg-preload-count
 #   tools/_tl/libi2v_hip_flowtl.so   the library with -DFLOW_TIMELINE (per-launch / per-phase stamps of the cINN tile chain,
 #                                    read by tools/flow_timeline.py)
 #   tools/conv16w_check[_tl|_tt]     the conv check tool: plain, -DW4_TIMELINE, -DW4_TAPTIME
@@ -8,7 +9,10 @@ cd "$(dirname "$0")/.."
 CS=image2video-synthesis-using-cinns_amd/csrc
 mkdir -p tools/_tl
 if [ "$1" != "conv" ]; then
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DFLOW_TIMELINE -Wno-unused-function -shared -I$CS -Iinclude \
+  ALL="$CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip"
+  # the shipped library WITHOUT kernarg preload (A/B of that flag: FLOWTIME_LIB=tools/_tl/libi2v_hip_nopreload.so python tools/flowtime.py)
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -shared -I$CS -Iinclude $ALL -o tools/_tl/libi2v_hip_nopreload.so &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DFLOW_TIMELINE -mllvm -amdgpu-kernarg-preload-count=16 -Wno-unused-function -shared -I$CS -Iinclude \
     $CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip \
     $CS/i2v_conv16w4.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip -o tools/_tl/libi2v_hip_flowtl.so &
 fi
