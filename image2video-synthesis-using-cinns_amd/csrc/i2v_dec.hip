@@ -595,6 +595,7 @@ struct i2v_dec {
     int img16 = 2;  // split-fp16 mode: 2 fused matrix-core kernel (i2v_convimg.hip), 1 round 2's 81-plane GEMM + gather at nf >= 64, 0 vector-ALU kernel (env I2V_DEC_IMG16)
     int wino4 = 1; // 1: F(4,3) Winograd kernel where the shape allows and one sample gives >= 32 workgroups (env I2V_DEC_WINO4=0: F(2,3); 2: wherever the shape allows)
     int spw = 1;   // 1: SPADE's gamma|beta conv uses the Winograd kernel where the shape allows (env I2V_DEC_SPW=0: direct kernel)
+    int sub = 0;   // samples per sub-batch of the last two levels (env I2V_DEC_SUB; 0: the whole batch per launch)
     int pw16 = 1;  // 1: split-fp16 mode runs the shortcut convs on split-fp16 operands too (env I2V_DEC_PW16=0: exact-fp32 MFMA)
     int device = 0;             // the device the packed weights live on
     int* status_dev = nullptr;  // sticky range flag of the hl16 producers (device) ...
@@ -621,7 +622,7 @@ struct i2v_dec {
 namespace {
 
 struct DecWs {
-    size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, coef, splitk, splitk_floats, y1v, total;
+    size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, sums3, coef, splitk, splitk_floats, y1v, total;
     bool has_y1v = false;
 };
 
@@ -669,6 +670,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
     L.has_y1v = mx_yv > 0;
     L.zl = take((size_t)B * d->Nz);
     L.sums1 = take((size_t)B * cmax * 4); L.sums2 = take((size_t)B * cmax * 4);  // doubles: 2 per channel
+    L.sums3 = take((size_t)B * cmax * 4);   // block output statistics (sums1 / sums3 alternate as a block's input / output statistics)
     L.coef = take((size_t)B * cmax * 2);
     {   // split-K scratch of the direct conv kernel (the tiny feature maps of head_0 / g_0): its partial copies of the output
         size_t mx = 0;
@@ -853,7 +855,8 @@ namespace {
 
 struct BlockBufs {
     float *a, *dx, *xs_in, *xs_low, *y0, *y1, *gb, *coef;
-    double *sums1, *sums2;
+    double *sums1, *sums2;        // sums1: statistics of the block INPUT (filled by the previous block's conv_1 epilogue or by run_stats)
+    double* sums_out = nullptr;   // where conv_1's epilogue accumulates the statistics of the block OUTPUT (null: into sums1)
     float* splitk = nullptr;      // split-K scratch of conv16_forward (optional)
     size_t splitk_floats = 0;
     float* y1v = nullptr;         // Winograd operand of SPADE's 128-channel activation (2 x the size of y1; optional)
@@ -865,6 +868,7 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
                   const float* zl, int zstride, int B, const BlockBufs& w, bool& x_stats_ready, bool last, hipStream_t st) {
     float *a = w.a, *dx = w.dx, *xs_in = w.xs_in, *xs_low = w.xs_low, *y0 = w.y0, *y1 = w.y1, *gb = w.gb, *coef = w.coef;
     double *sums1 = w.sums1, *sums2 = w.sums2;
+    double* sums_out = w.sums_out ? w.sums_out : w.sums1;
     int rc;
     auto tap = [&](int k_, int which, const float* src, size_t count) -> int {
         if (d->tap_dst && d->tap_block == k_ && d->tap_which == which)
@@ -953,9 +957,9 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     const bool fuse_out = f16 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
     d->prof_cur_layer = 2 * k + 1;
     d->prof_cur_kernel = q1 ? 3 : w1 ? 2 : (f16 ? 1 : 0);
-    if (q1) rc = conv3_w4(d, b.conv1_w4, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
-    else if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr);
-    else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums1 : nullptr,
+    if (q1) rc = conv3_w4(d, b.conv1_w4, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
+    else if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
+    else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr,
                                 w.splitk, w.splitk_floats);
     else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
     if (rc) return rc;
@@ -1079,6 +1083,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     if (const char* e = std::getenv("I2V_DEC_PW16")) d->pw16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_SUB")) d->sub = std::max(0, std::atoi(e));
     if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
     const char* names[6] = {"head_0", "g_0", "g_1", "g_2", "g_3", "g_4"};
@@ -1325,10 +1330,30 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     float* x = xA;
     float* xn = xB;
     bool x_stats_ready = false;
-    BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, sums1, sums2, F(L.splitk), L.splitk_floats, L.has_y1v ? F(L.y1v) : nullptr};
+    double* sums3 = reinterpret_cast<double*>(ws + L.sums3);
     for (int k = 0; k < 6; ++k) {
-        if ((rc = block_forward(d, k, d->blk[k], d->lvl[k], x, xn, img, img_h, img_w, zl, d->Nz, B, bufs, x_stats_ready, k == 5, st)))
-            return rc;
+        const Block& b = d->blk[k];
+        const Level& l = d->lvl[k];
+        double* s_in = (k & 1) ? sums3 : sums1;
+        double* s_out = (k & 1) ? sums1 : sums3;
+        // Sub-batches (I2V_DEC_SUB = samples per sub-batch, levels whose one sample already fills the chip): the block's launch
+        // sequence runs once per sub-batch, so that what one launch writes (dx, the V operands: ~100 MB per sample at the last
+        // two levels) is still in the 256 MB Infinity Cache when the next launch reads it.  Every op is per sample: same bits.
+        int nsub = B;
+        if (d->sub > 0 && k >= 4 && (long)l.T * l.H * l.W >= 65536) nsub = std::min(B, d->sub);
+        const long Pl = (long)(l.T / l.ut) * (l.H / l.us) * (l.W / l.us), P = (long)l.T * l.H * l.W;
+        bool ready_out = x_stats_ready;
+        for (int s0 = 0; s0 < B; s0 += nsub) {
+            const int n = std::min(nsub, B - s0);
+            BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, s_in + (size_t)s0 * b.n_in * 2, sums2, s_out + (size_t)s0 * b.n_out * 2,
+                           F(L.splitk), L.splitk_floats, L.has_y1v ? F(L.y1v) : nullptr};
+            bool ready = x_stats_ready;
+            if ((rc = block_forward(d, k, d->blk[k], l, x + (size_t)s0 * Pl * b.n_in, xn + (size_t)s0 * P * b.n_out,
+                                    img + (size_t)s0 * 3 * img_h * img_w, img_h, img_w, zl + (size_t)s0 * d->Nz, d->Nz, n, bufs, ready, k == 5, st)))
+                return rc;
+            ready_out = ready;
+        }
+        x_stats_ready = ready_out;
         std::swap(x, xn);
     }
     {
