@@ -296,14 +296,15 @@ def test_f43_structure_switches_keep_the_bits(golden, monkeypatch):
     """The F(4,3) kernel's measurement switches change WHERE and WHEN a brick is computed, never the arithmetic of an output:
     the software-pipelined persistent kernel (I2V_W4_PIPE=1: next brick's tables and first V brick fetched under the current
     brick's pass B, four-quarter epilogue), the brick -> XCD orders and 32-channel workgroups must reproduce the default
-    kernel's frames bit for bit, on the 64-channel (BAIR nf = 64) and the 32-channel (128x128 nf = 32) instantiations."""
+    kernel's frames bit for bit, on the 64-channel (BAIR nf = 64) and the 32-channel (128x128 nf = 32) instantiations; so must
+    the decoder's sub-batching of its last two levels (I2V_DEC_SUB)."""
     g, meta = load_golden(golden)
     x0, z, _ = synth.bench_inputs(3, g["img"].shape[-1], 64)     # 3 samples: grids that are not a multiple of the CU count
     x0[1], z[1] = torch.from_numpy(g["img"][0]), torch.from_numpy(g["z"][0])
     x0, z = x0.cuda(), z.cuda()
     ref = _gen(meta)(x0, z)
     assert rel_l2(ref[1:2, ..., ::2, ::2].cpu(), g["out_s2"]) < TOL
-    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32")):
+    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"), ("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2")):
         monkeypatch.setenv(env, val)
         alt = _gen(meta)(x0, z)
         monkeypatch.delenv(env)
