@@ -86,6 +86,10 @@ def main():
                          "under rocprofv3 so that the kernel trace holds the timed steps only")
     ap.add_argument("--sustain", type=float, default=10.0, help="seconds of back-to-back steps after the timed region (0: skip)")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 (mma = 0) leg")
+    ap.add_argument("--live-traffic", action="store_true",
+                    help="after the timing, measure the HBM bytes per launch of the dominant kernel and per cINN pass NOW (two child runs of this "
+                         "workload under `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace`, tools/pmc_hbm_traffic.py; ~2 min) instead of "
+                         "quoting the newest committed profiles/r*_pmc_hbm_traffic.json")
     ap.add_argument("--per-layer", type=str, help="write the per-layer table of the 3x3x3 conv launches (CSV) here")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="1 (default): the cINN pass of step k+1 runs on a side stream underneath the decoder of step k "
@@ -388,6 +392,8 @@ def main():
             result["encoder"] = encoder_latency(cfg, x0_d)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+        if args.live_traffic and world == 1:
+            live_traffic(result, args)
         if args.per_layer:
             write_per_layer(args.per_layer, layers, args.steps, gen.mma)
         validate_line(result, full=world == 1 and gen.mma == 1 and not (args.no_extras or args.no_cpu_baseline or args.no_exact or args.sustain < 10))
@@ -506,6 +512,36 @@ def dry_run(args):
         dist.barrier()
         dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def live_traffic(result, args):
+    """--live-traffic: run tools/pmc_hbm_traffic.py (separate FETCH_SIZE / WRITE_SIZE passes of one step of THIS workload under
+    rocprofv3, the guide's gfx950 correction) in a child process while this process idles, and replace the static figures."""
+    import subprocess
+    import tempfile
+    out = os.environ.get("I2V_PMC_OUT") or tempfile.mkdtemp(prefix="i2v_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))   # (I2V_PMC_OUT: keep the summary)
+    cmd = [sys.executable, os.path.join(REPO, "tools", "pmc_hbm_traffic.py"), out, "--config", args.config, "--scaling", args.scaling]
+    if args.batch:
+        cmd += ["--batch", str(args.batch)]
+    try:
+        subprocess.run(cmd, check=True, cwd=REPO, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        with open(os.path.join(out, "hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+        result["roofline"]["traffic_live_error"] = repr(e)[:200]
+        return
+    r = result["roofline"]
+    name = next((n for n in k if r["kernel_name"] in n and "3x3x3" in n), None)
+    if name:
+        r["traffic"] = k[name]["hbm_bytes_per_launch"]
+        r["traffic_read_write"] = [k[name]["read_bytes"] / k[name]["launches"], k[name]["write_bytes"] / k[name]["launches"]]
+        r["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two child passes of one step of this workload, "
+                               f"tools/pmc_hbm_traffic.py), mean over the {k[name]['launches']} launches of {name}")
+    flow = {n: v for n, v in k.items() if "flow_" in n}
+    passes = next((v["launches"] for n, v in flow.items() if "flow_pre" in n), 0)
+    if passes and "roofline_cinn" in result:
+        result["roofline_cinn"]["measured_hbm_bytes_per_pass"] = sum(v["read_bytes"] + v["write_bytes"] for v in flow.values()) / passes
+        result["roofline_cinn"]["measured_hbm_bytes_source"] = "measured by this run (same child passes)"
 
 
 def _latest_traffic_file():

@@ -3,32 +3,29 @@
 export TMPDIR=/tmp
 out=${1:-gpurun_out/evidence}
 mkdir -p $out
-timeout 400 python bench.py --per-layer $out/conv16_per_layer_bair64.csv 2>$out/bench_bair64.err | tail -1 > $out/bench_bair64.json
-timeout 300 python bench.py --config land128 --steps 10 --warmup 3 --no-cpu-baseline --per-layer $out/conv16_per_layer_land128.csv 2>/dev/null | tail -1 > $out/bench_land128_b32.json
-for b in 4 8 16; do timeout 200 python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_bair64_b$b.json; done
-timeout 300 python bench.py --config dtdb128 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_dtdb128_strong_b256.json
-timeout 300 python bench.py --config iper128_t32 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_iper128_t32_strong_b128.json
+# the default line (BASELINE configs[1]) with every key, HBM traffic measured by the run itself (two rocprofv3 --pmc child passes)
+I2V_PMC_OUT=$out/pmc_traffic timeout 900 python bench.py --live-traffic --per-layer $out/conv16_per_layer_bair64.csv 2>$out/bench_bair64.err | tail -1 > $out/bench_bair64.json
+rm -rf $out/pmc_traffic/fetch_size $out/pmc_traffic/write_size
+I2V_PMC_OUT=$out/pmc_traffic_land timeout 900 python bench.py --config land128 --steps 10 --warmup 3 --no-cpu-baseline --live-traffic --per-layer $out/conv16_per_layer_land128.csv 2>/dev/null | tail -1 > $out/bench_land128_b32.json
+rm -rf $out/pmc_traffic_land/fetch_size $out/pmc_traffic_land/write_size
+for b in 4 8 16; do timeout 200 python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_bair64_b$b.json; done
+timeout 300 python bench.py --config dtdb128 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_dtdb128_strong_b256.json
+timeout 300 python bench.py --config iper128_t32 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_iper128_t32_strong_b128.json
 timeout 300 python bench.py --config dtdb128 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $out/bench_dtdb128_b32.json
 timeout 300 python bench.py --config iper128_t32 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $out/bench_iper128_t32_b16.json
 # kernel traces of the timed steps only (--no-extras: no post-timing measurement loops in the trace)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bair -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/prof_bair.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_land -o bench -- python bench.py --config land128 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/prof_land.log 2>&1
 rm -f $out/prof_*/bench_kernel_trace.csv
-timeout 400 python tools/pmc_hbm_traffic.py $out/pmc_traffic > $out/pmc_traffic.log 2>&1
-rm -rf $out/pmc_traffic/fetch_size $out/pmc_traffic/write_size
-# round 3 additions: cINN latencies / per-kernel stats, FETCH_SIZE calibration, SQ counters of the F(4,3) kernel on the
-# g_3.conv_1 shape (pass A and pass B are one kernel; MFMA-busy normalised by GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs)
-if [ -z "$EVIDENCE_SKIP_FLOW" ]; then   # (cINN chain and counter calibration: unchanged code -> EVIDENCE_SKIP_FLOW=1 keeps the older files)
-timeout 300 python tools/flowtime.py > $out/flowtime.txt 2>&1
+# cINN chain: latencies (fp32 and fp16-operand mode), per-kernel stats
+timeout 300 python tools/flowtime.py 2>&1 | grep -v amdgpu.ids > $out/flowtime.txt
+FLOWTIME_F16=1 timeout 300 python tools/flowtime.py 2>&1 | grep -v amdgpu.ids >> $out/flowtime.txt
 FLOWTIME_B=64 timeout 300 bash tools/flow_prof.sh evidence_b64 > /dev/null 2>&1; cp gpurun_out/flowprof_evidence_b64.csv $out/kernel_stats_flow_b64.csv 2>/dev/null
-timeout 300 python tools/pmc_hbm_traffic.py $out/pmc_traffic --calibrate > $out/fetch_calibration.log 2>&1
-rm -rf $out/pmc_traffic/fetch_calib
-fi
+# SQ counters of the F(4,3) kernel on the g_3.conv_1 shape (pass A and pass B are one kernel; MFMA-busy normalised by GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs)
 timeout 400 bash tools/pmc_sq.sh $out/pmc_sq_f43 tools/conv16w_check 8 16 64 64 128 128 0 1 > $out/pmc_sq_f43_g3conv1.txt 2>&1
 rm -rf $out/pmc_sq_f43
-# per-workgroup phase timeline and per-tap timing of the F(4,3) kernel (instrumented builds of the check tool:
-#   hipcc -O3 --offload-arch=gfx950 -DW4_TIMELINE | -DW4_TAPTIME -I<csrc> tools/conv16w_check.hip <csrc>/i2v_conv16w.hip <csrc>/i2v_conv16w4.hip <csrc>/i2v_conv16.hip <csrc>/i2v_common.hip)
-for s in "8 16 64 64 128 128 0 1" "8 16 64 64 256 128 1 0" "8 16 64 64 64 64 0 1"; do
+# per-workgroup phase timeline and per-tap timing of the F(4,3) kernel (instrumented builds: tools/build_measurement_libs.sh conv)
+for s in "8 16 64 64 128 128 0 1" "8 16 64 64 256 128 1 0" "8 16 64 64 64 64 0 1" "4 16 128 128 32 32 0 1" "8 4 16 16 512 512 0 1"; do
   [ -x tools/conv16w_check_tl ] && timeout 100 tools/conv16w_check_tl $s 2>&1 | grep -v "^$" >> $out/f43_timeline.txt
   [ -x tools/conv16w_check_tt ] && timeout 100 tools/conv16w_check_tt $s 2>&1 | grep -v "^$" >> $out/f43_taptime.txt
 done

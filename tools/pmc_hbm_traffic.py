@@ -25,11 +25,14 @@ def one_pass(outdir, counter, extra, parse_only):
             subprocess.run(cmd, check=True, stdout=log, stderr=subprocess.STDOUT, env=env)
     per = collections.defaultdict(lambda: [0, 0.0])
     conv16 = []
+    n_dec = 0   # decoder passes in the run (one conv_img launch each): bench.py also decodes a serial reference call after the timed step
     with open(os.path.join(d, "pmc_counter_collection.csv")) as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
             k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+            if "conv_img" in k:
+                n_dec += 1
             if "conv_mfma_f16x3_kernel" in k:
                 conv16.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                 continue
@@ -48,7 +51,9 @@ def one_pass(outdir, counter, extra, parse_only):
     # The first two blocks (head_0, g_0: 4x4 and 8x8 maps) run all four of their convs on the direct kernel (SPADE input conv,
     # SPADE gamma|beta conv, conv_0, conv_1); every later block only its SPADE input conv (3 -> 128) and, where the 1x3x3
     # Winograd variant does not apply (maps below 32x32), its gamma|beta conv.  Count from the front: 4 + 4, the rest SPADE.
-    for i, (_, v) in enumerate(conv16):
+    per_pass = len(conv16) // max(n_dec, 1) if n_dec and len(conv16) % max(n_dec, 1) == 0 else len(conv16)
+    for i0, (_, v) in enumerate(conv16):
+        i = i0 % per_pass
         name = "i2v::conv_mfma_f16x3_kernel [3x3x3 Conv3d, direct]" if i < 8 and i % 4 >= 2 else "i2v::conv_mfma_f16x3_kernel [SPADE 3x3 Conv2d]"
         per[name][0] += 1
         per[name][1] += v
