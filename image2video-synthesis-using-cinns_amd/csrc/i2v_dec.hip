@@ -365,6 +365,45 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
 //   V3 = -2 d1 - d2 + 2 d3 + d4   V4 = 2 d1 - d2 - 2 d3 + d4   V5 = 4 d1 - 5 d3 + d5
 // Same thread mapping as modulate_wino_kernel: one thread = one 16-byte piece of the V rows of one (h, tile) column; it
 // evaluates its OWN four positions (d1..d4), gets d0 / d5 from the neighbouring tiles by lane shuffle and loops over the frames.
+// GB: SPADE's gamma' / beta are present -- every position then has its own affine (a, b)[8], kept in registers over the frame
+// loop (5 x 16 registers); without them (the ADAIN operand of conv_1, SPADE's own activation) all positions share the sample's
+// (ca, cb) and the kernel fits three waves per SIMD instead of two (round 3's single kernel: 215 VGPRs + 44 bytes of scratch).
+template <bool GB>
+struct ModPos4 {
+    float a[GB ? 8 : 1], b[GB ? 8 : 1];
+    const float* xp;
+};
+
+template <bool GB>
+__device__ __forceinline__ void mod_pos4_init(ModPos4<GB>& m, const float* ca, const float* cb, const float* xb, const float* gbb, int h, int w,
+                                              int W, int C, int c8, int us, int Wl) {
+    m.xp = xb + ((long)(h / us) * Wl + w / us) * C + 8 * c8;
+    if constexpr (GB) {  // fold SPADE's gamma' / beta of the position into the affine: (x ca + cb) ga + be
+        const float* g = gbb + ((long)h * W + w) * (2 * C) + 8 * c8;
+        const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(g + C), e1 = *reinterpret_cast<const float4*>(g + C + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { m.b[c] = fmaf(cb[c], ga[c], be[c]); m.a[c] = ca[c] * ga[c]; }
+    }
+}
+
+template <bool GB>
+__device__ __forceinline__ void mod_pos4_eval(const ModPos4<GB>& m, const float* ca, const float* cb, long toff, int lrelu, float* d,
+                                              float& vmax) {
+    const float* p = m.xp + toff;
+    const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+    const float r0[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float r = GB ? fmaf(r0[c], m.a[c], m.b[c]) : fmaf(r0[c], ca[c], cb[c]);
+        d[c] = (lrelu && r < 0.f) ? 0.2f * r : r;
+        vmax = fmaxf(vmax, fabsf(d[c]));
+    }
+}
+
+template <bool GB>
 __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
                                                              const float* __restrict__ gb, char* __restrict__ out, int T, int H,
                                                              int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag,
@@ -377,7 +416,7 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
     const int Hl = H / us, Wl = W / us, Tl = T / ut;
     const float2* cp0 = coef ? coef + (long)b * C : nullptr;
     const float* xb = x + (long)b * Tl * Hl * Wl * C;
-    const float* gbb = gb ? gb + (long)b * H * W * 2 * C : nullptr;
+    const float* gbb = GB ? gb + (long)b * H * W * 2 * C : nullptr;
     const int nchunk = C >> 4;
     const long xstride = (long)Hl * Wl * C;
     const int lane = threadIdx.x & 63, jj = lane >> 2;
@@ -401,25 +440,26 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
 #pragma unroll
             for (int k = 0; k < 8; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
         }
-        ModPos m1, m2, m3, m4, me;
-        mod_pos_init(m1, ca, cb, xb, gbb, h, 4 * j, W, C, c8, us, Wl);
-        mod_pos_init(m2, ca, cb, xb, gbb, h, 4 * j + 1, W, C, c8, us, Wl);
-        mod_pos_init(m3, ca, cb, xb, gbb, h, 4 * j + 2, W, C, c8, us, Wl);
-        mod_pos_init(m4, ca, cb, xb, gbb, h, 4 * j + 3, W, C, c8, us, Wl);
+        ModPos4<GB> m1, m2, m3, m4, me;
+        mod_pos4_init<GB>(m1, ca, cb, xb, gbb, h, 4 * j, W, C, c8, us, Wl);
+        mod_pos4_init<GB>(m2, ca, cb, xb, gbb, h, 4 * j + 1, W, C, c8, us, Wl);
+        mod_pos4_init<GB>(m3, ca, cb, xb, gbb, h, 4 * j + 2, W, C, c8, us, Wl);
+        mod_pos4_init<GB>(m4, ca, cb, xb, gbb, h, 4 * j + 3, W, C, c8, us, Wl);
         const bool left_row = j == 0, right_row = j == J - 1;
         const bool left_own = !left_row && jj == 0, right_own = !right_row && jj == 15;
-        if (left_own || right_own) mod_pos_init(me, ca, cb, xb, gbb, h, left_own ? 4 * j - 1 : 4 * j + 4, W, C, c8, us, Wl);
+        me = m1;
+        if (left_own || right_own) mod_pos4_init<GB>(me, ca, cb, xb, gbb, h, left_own ? 4 * j - 1 : 4 * j + 4, W, C, c8, us, Wl);
         float d0[8], d1[8], d2[8], d3[8], d4[8], d5[8], de[8];
         char* ob = out + ((((long)b * T * nchunk + chunk) * 6 * H + h) * J + j) * 64 + p * 16;
         const long ostride_x = (long)H * J * 64, ostride_t = (long)nchunk * 6 * ostride_x;
         for (int t = 0; t < T; ++t) {
             if (t % ut == 0) {
                 const long toff = (long)(t / ut) * xstride;
-                mod_pos_eval(m1, toff, lrelu, d1, vmax);
-                mod_pos_eval(m2, toff, lrelu, d2, vmax);
-                mod_pos_eval(m3, toff, lrelu, d3, vmax);
-                mod_pos_eval(m4, toff, lrelu, d4, vmax);
-                if (left_own || right_own) mod_pos_eval(me, toff, lrelu, de, vmax);
+                mod_pos4_eval<GB>(m1, ca, cb, toff, lrelu, d1, vmax);
+                mod_pos4_eval<GB>(m2, ca, cb, toff, lrelu, d2, vmax);
+                mod_pos4_eval<GB>(m3, ca, cb, toff, lrelu, d3, vmax);
+                mod_pos4_eval<GB>(m4, ca, cb, toff, lrelu, d4, vmax);
+                if (left_own || right_own) mod_pos4_eval<GB>(me, ca, cb, toff, lrelu, de, vmax);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float up = __shfl_up(d4[c], 4), dn = __shfl_down(d1[c], 4);
@@ -731,8 +771,12 @@ int run_modulate_wino4(const float* x, const float* coef, const float* gb, float
     I2V_REQUIRE(per % 64 == 0, I2V_E_INVALID, "modulate (F(4,3) operand): %ld threads per sample (need whole wavefronts)", per);
     I2V_REQUIRE(per * T * 6 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
-    hipLaunchKernelGGL(modulate_wino4_kernel, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
-                       reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax);
+    if (gb)
+        hipLaunchKernelGGL(modulate_wino4_kernel<true>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
+                           reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax);
+    else
+        hipLaunchKernelGGL(modulate_wino4_kernel<false>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
+                           reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
