@@ -365,38 +365,42 @@ __global__ __launch_bounds__(256) void modulate_wino_kernel(const float* __restr
 //   V3 = -2 d1 - d2 + 2 d3 + d4   V4 = 2 d1 - d2 - 2 d3 + d4   V5 = 4 d1 - 5 d3 + d5
 // Same thread mapping as modulate_wino_kernel: one thread = one 16-byte piece of the V rows of one (h, tile) column; it
 // evaluates its OWN four positions (d1..d4), gets d0 / d5 from the neighbouring tiles by lane shuffle and loops over the frames.
-// GB: SPADE's gamma' / beta are present -- every position then has its own affine (a, b)[8], kept in registers over the frame
-// loop (5 x 16 registers); without them (the ADAIN operand of conv_1, SPADE's own activation) all positions share the sample's
-// (ca, cb) and the kernel fits three waves per SIMD instead of two (round 3's single kernel: 215 VGPRs + 44 bytes of scratch).
+// Thread = (h, chunk, tile j, q): the FOUR channels 4q .. 4q+3 of the chunk, hi AND lo parts: per plane it writes two 8-byte
+// half-pieces (hi at byte (q >> 1) * 32 + (q & 1) * 8 of the 64-byte row, lo 16 bytes behind) with two back-to-back store
+// instructions, so that the four lanes of a tile complete the row within a few cycles (round 3 gave a lane 8 channels of the hi
+// OR the lo part: every value was loaded, evaluated and kept twice -- 215 VGPRs and scratch; now every element is loaded and
+// evaluated once).  GB: SPADE's gamma' / beta are present -- every position then has its own affine (a, b)[4], kept in
+// registers over the frame loop; without them (the ADAIN operand of conv_1, SPADE's own activation) all positions share the
+// sample's (ca, cb).
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
 template <bool GB>
 struct ModPos4 {
-    float a[GB ? 8 : 1], b[GB ? 8 : 1];
+    float a[GB ? 4 : 1], b[GB ? 4 : 1];
     const float* xp;
 };
 
 template <bool GB>
 __device__ __forceinline__ void mod_pos4_init(ModPos4<GB>& m, const float* ca, const float* cb, const float* xb, const float* gbb, int h, int w,
-                                              int W, int C, int c8, int us, int Wl) {
-    m.xp = xb + ((long)(h / us) * Wl + w / us) * C + 8 * c8;
+                                              int W, int C, int c4, int us, int Wl) {
+    m.xp = xb + ((long)(h / us) * Wl + w / us) * C + 4 * c4;
     if constexpr (GB) {  // fold SPADE's gamma' / beta of the position into the affine: (x ca + cb) ga + be
-        const float* g = gbb + ((long)h * W + w) * (2 * C) + 8 * c8;
-        const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
-        const float4 e0 = *reinterpret_cast<const float4*>(g + C), e1 = *reinterpret_cast<const float4*>(g + C + 4);
-        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        const float* g = gbb + ((long)h * W + w) * (2 * C) + 4 * c4;
+        const float4 g0 = *reinterpret_cast<const float4*>(g), e0 = *reinterpret_cast<const float4*>(g + C);
+        const float ga[4] = {g0.x, g0.y, g0.z, g0.w};
+        const float be[4] = {e0.x, e0.y, e0.z, e0.w};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { m.b[c] = fmaf(cb[c], ga[c], be[c]); m.a[c] = ca[c] * ga[c]; }
+        for (int c = 0; c < 4; ++c) { m.b[c] = fmaf(cb[c], ga[c], be[c]); m.a[c] = ca[c] * ga[c]; }
     }
 }
 
 template <bool GB>
 __device__ __forceinline__ void mod_pos4_eval(const ModPos4<GB>& m, const float* ca, const float* cb, long toff, int lrelu, float* d,
                                               float& vmax) {
-    const float* p = m.xp + toff;
-    const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
-    const float r0[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const float4 v0 = *reinterpret_cast<const float4*>(m.xp + toff);
+    const float r0[4] = {v0.x, v0.y, v0.z, v0.w};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < 4; ++c) {
         const float r = GB ? fmaf(r0[c], m.a[c], m.b[c]) : fmaf(r0[c], ca[c], cb[c]);
         d[c] = (lrelu && r < 0.f) ? 0.2f * r : r;
         vmax = fmaxf(vmax, fabsf(d[c]));
@@ -410,47 +414,50 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
                                                              int* __restrict__ umax) {
     bool bad = false;
     float vmax = 0.f;
-    const int C8 = C >> 3, J = W >> 2;
+    const int C4 = C >> 2, J = W >> 2;
     const int b = blockIdx.y;
-    const int per = H * J * C8 * 2;
+    const int per = H * J * C4;        // threads per sample (a multiple of 64: whole waves stay active for the shuffles)
     const int Hl = H / us, Wl = W / us, Tl = T / ut;
     const float2* cp0 = coef ? coef + (long)b * C : nullptr;
     const float* xb = x + (long)b * Tl * Hl * Wl * C;
     const float* gbb = GB ? gb + (long)b * H * W * 2 * C : nullptr;
     const int nchunk = C >> 4;
     const long xstride = (long)Hl * Wl * C;
-    const int lane = threadIdx.x & 63, jj = lane >> 2;
+    const int lane = threadIdx.x & 63, jj = lane >> 2;   // jj: position of the tile inside the wave's 16-tile segment
     for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
-        const int p = i & 3;
+        // i = ((h * nchunk + chunk) * J + j) * 4 + q
+        const int q4 = i & 3;
         int q = i >> 2;
         const int j = q % J; q /= J;
         const int chunk = q % nchunk;
         const int h = q / nchunk;
-        const int c8 = chunk * 2 + (p >> 1);
-        const bool is_lo = p & 1;
-        float ca[8], cb[8];
+        const int c4 = chunk * 4 + q4;
+        float ca[4], cb[4];
         if (cp0) {
-            const float4* cp = reinterpret_cast<const float4*>(cp0 + 8 * c8);
+            const float4* cp = reinterpret_cast<const float4*>(cp0 + 4 * c4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 2; ++k) {
                 const float4 ab = cp[k];
                 ca[2 * k] = ab.x; cb[2 * k] = ab.y; ca[2 * k + 1] = ab.z; cb[2 * k + 1] = ab.w;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
+            for (int k = 0; k < 4; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
         }
         ModPos4<GB> m1, m2, m3, m4, me;
-        mod_pos4_init<GB>(m1, ca, cb, xb, gbb, h, 4 * j, W, C, c8, us, Wl);
-        mod_pos4_init<GB>(m2, ca, cb, xb, gbb, h, 4 * j + 1, W, C, c8, us, Wl);
-        mod_pos4_init<GB>(m3, ca, cb, xb, gbb, h, 4 * j + 2, W, C, c8, us, Wl);
-        mod_pos4_init<GB>(m4, ca, cb, xb, gbb, h, 4 * j + 3, W, C, c8, us, Wl);
+        mod_pos4_init<GB>(m1, ca, cb, xb, gbb, h, 4 * j, W, C, c4, us, Wl);
+        mod_pos4_init<GB>(m2, ca, cb, xb, gbb, h, 4 * j + 1, W, C, c4, us, Wl);
+        mod_pos4_init<GB>(m3, ca, cb, xb, gbb, h, 4 * j + 2, W, C, c4, us, Wl);
+        mod_pos4_init<GB>(m4, ca, cb, xb, gbb, h, 4 * j + 3, W, C, c4, us, Wl);
+        // own positions w = 4j .. 4j+3; the outer neighbours 4j - 1 / 4j + 4 come from lane -+ 4 unless this tile opens / closes the
+        // wave's segment (then they are evaluated here) or the row (then they are 0: the conv's zero padding)
         const bool left_row = j == 0, right_row = j == J - 1;
         const bool left_own = !left_row && jj == 0, right_own = !right_row && jj == 15;
         me = m1;
-        if (left_own || right_own) mod_pos4_init<GB>(me, ca, cb, xb, gbb, h, left_own ? 4 * j - 1 : 4 * j + 4, W, C, c8, us, Wl);
-        float d0[8], d1[8], d2[8], d3[8], d4[8], d5[8], de[8];
-        char* ob = out + ((((long)b * T * nchunk + chunk) * 6 * H + h) * J + j) * 64 + p * 16;
+        if (left_own || right_own) mod_pos4_init<GB>(me, ca, cb, xb, gbb, h, left_own ? 4 * j - 1 : 4 * j + 4, W, C, c4, us, Wl);
+        float d0[4], d1[4], d2[4], d3[4], d4[4], d5[4], de[4];
+        // V row of (t, chunk, plane, h, j): 64 bytes [hi c0-7 | lo c0-7 | hi c8-15 | lo c8-15]; this thread's channels 4 q4 .. 4 q4 + 3
+        char* ob = out + ((((long)b * T * nchunk + chunk) * 6 * H + h) * J + j) * 64 + (q4 >> 1) * 32 + (q4 & 1) * 8;
         const long ostride_x = (long)H * J * 64, ostride_t = (long)nchunk * 6 * ostride_x;
         for (int t = 0; t < T; ++t) {
             if (t % ut == 0) {
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
                 mod_pos4_eval<GB>(m4, ca, cb, toff, lrelu, d4, vmax);
                 if (left_own || right_own) mod_pos4_eval<GB>(me, ca, cb, toff, lrelu, de, vmax);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
+                for (int c = 0; c < 4; ++c) {
                     const float up = __shfl_up(d4[c], 4), dn = __shfl_down(d1[c], 4);
                     d0[c] = left_row ? 0.f : (left_own ? de[c] : up);
                     d5[c] = right_row ? 0.f : (right_own ? de[c] : dn);
@@ -470,9 +477,9 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
             char* o = ob + (long)t * ostride_t;
 #pragma unroll
             for (int xq = 0; xq < 6; ++xq) {
-                half8_t piece;
+                half4_t ph, pl;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
+                for (int c = 0; c < 4; ++c) {
                     float v;
                     if (xq == 0) v = fmaf(4.f, d0[c], fmaf(-5.f, d2[c], d4[c]));
                     else if (xq == 1) v = fmaf(-4.f, d1[c] + d2[c], d3[c] + d4[c]);
@@ -482,9 +489,11 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
                     else v = fmaf(4.f, d1[c], fmaf(-5.f, d3[c], d5[c]));
                     const _Float16 hh = (_Float16)v;
                     bad |= !(fabsf(v) <= 65504.f);
-                    piece[c] = is_lo ? (_Float16)(v - (float)hh) : hh;
+                    ph[c] = hh;
+                    pl[c] = (_Float16)(v - (float)hh);
                 }
-                *reinterpret_cast<half8_t*>(o + xq * ostride_x) = piece;
+                *reinterpret_cast<half4_t*>(o + xq * ostride_x) = ph;
+                *reinterpret_cast<half4_t*>(o + xq * ostride_x + 16) = pl;
             }
         }
     }
@@ -767,7 +776,7 @@ int run_modulate(const float* x, const float* coef, const float* gb, float* out,
 int run_modulate_wino4(const float* x, const float* coef, const float* gb, float* out, int B, int T, int H, int W, int C, int ut,
                        int us, int lrelu, hipStream_t st, int* range_flag, int* umax = nullptr) {
     I2V_REQUIRE(C % 32 == 0 && W % 4 == 0, I2V_E_INVALID, "modulate (F(4,3) operand): channels %d / width %d", C, W);
-    const long per = (long)H * (W / 4) * (C / 8) * 2;
+    const long per = (long)H * (W / 4) * (C / 4);   // one thread per (h, tile, 4 channels)
     I2V_REQUIRE(per % 64 == 0, I2V_E_INVALID, "modulate (F(4,3) operand): %ld threads per sample (need whole wavefronts)", per);
     I2V_REQUIRE(per * T * 6 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
