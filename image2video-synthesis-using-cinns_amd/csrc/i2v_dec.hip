@@ -411,7 +411,7 @@ template <bool GB>
 __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __restrict__ x, const float2* __restrict__ coef,
                                                              const float* __restrict__ gb, char* __restrict__ out, int T, int H,
                                                              int W, int C, int ut, int us, int lrelu, int* __restrict__ range_flag,
-                                                             int* __restrict__ umax, int order) {
+                                                             int* __restrict__ umax) {
     bool bad = false;
     float vmax = 0.f;
     const int C4 = C >> 2, J = W >> 2;
@@ -425,15 +425,14 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
     const long xstride = (long)Hl * Wl * C;
     const int lane = threadIdx.x & 63, jj = lane >> 2;   // jj: position of the tile inside the wave's 16-tile segment
     for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
-        // i = ((chunk * H + h) * J + j) * 4 + q  [I2V_MOD_ORDER=1, default]: the four waves of a workgroup write consecutive rows
-        // h of ONE (t, chunk, plane) slab (4-8 KB contiguous per plane and frame); 0: ((h * nchunk + chunk) * J + j) * 4 + q (four
-        // chunks of one row: contiguous 256-byte reads, 1-2 KB writes)
+        // i = ((h * nchunk + chunk) * J + j) * 4 + q
+        // (workgroup = four chunks of one row.  Four rows of one chunk -- 4-8 KB contiguous writes per plane and frame instead of
+        //  1-2 KB -- measured the same: profiles/r04_h_operand_writer_order.txt)
         const int q4 = i & 3;
         int q = i >> 2;
         const int j = q % J; q /= J;
-        int chunk, h;
-        if (order) { h = q % H; chunk = q / H; }
-        else { chunk = q % nchunk; h = q / nchunk; }
+        const int chunk = q % nchunk;
+        const int h = q / nchunk;
         const int c4 = chunk * 4 + q4;
         float ca[4], cb[4];
         if (cp0) {
@@ -783,14 +782,12 @@ int run_modulate_wino4(const float* x, const float* coef, const float* gb, float
     I2V_REQUIRE(per % 64 == 0, I2V_E_INVALID, "modulate (F(4,3) operand): %ld threads per sample (need whole wavefronts)", per);
     I2V_REQUIRE(per * T * 6 < (1L << 31), I2V_E_INVALID, "modulate: tensor too large");
     const unsigned gx = (unsigned)std::min<long>((per + 255) / 256, 8192);
-    const char* eo = std::getenv("I2V_MOD_ORDER");
-    const int order = eo ? std::atoi(eo) : 1;
     if (gb)
         hipLaunchKernelGGL(modulate_wino4_kernel<true>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
-                           reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax, order);
+                           reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax);
     else
         hipLaunchKernelGGL(modulate_wino4_kernel<false>, dim3(gx, B), dim3(256), 0, st, x, reinterpret_cast<const float2*>(coef), gb,
-                           reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax, order);
+                           reinterpret_cast<char*>(out), T, H, W, C, ut, us, lrelu, range_flag, umax);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
