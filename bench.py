@@ -127,11 +127,14 @@ def main():
         # the job must really be N ranks over RCCL on N distinct GPUs -- not N replicas that never met
         if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl" or not torch.cuda.nccl.version():
             raise SystemExit(f"bench.py: expected {args.gpus} ranks over RCCL, got world {dist.get_world_size()} / backend {dist.get_backend()}")
-        seen = [None] * world
-        dist.all_gather_object(seen, (rank, torch.cuda.current_device(), str(torch.cuda.get_device_properties(dev).uuid)
-                                      if hasattr(torch.cuda.get_device_properties(dev), "uuid") else str(local_rank)))
-        if len({s_[2] for s_ in seen}) != world or sorted(s_[0] for s_ in seen) != list(range(world)):
-            raise SystemExit(f"bench.py: ranks do not sit on {world} distinct GPUs: {seen}")
+        rank_devices = [None] * world    # (recorded in the line; RCCL itself refuses two ranks on one GPU)
+        try:
+            uuid = str(torch.cuda.get_device_properties(dev).uuid)
+        except Exception:
+            uuid = None
+        dist.all_gather_object(rank_devices, (rank, torch.cuda.current_device(), uuid))
+    else:
+        rank_devices = [(0, torch.cuda.current_device(), None)]
     torch.set_grad_enabled(False)
 
     if args.scaling == "weak":
@@ -272,11 +275,13 @@ def main():
     # steady state: >= 10 s of back-to-back steps (a fresh box clocks higher for the first seconds than under sustained load)
     sustained = None
     if not args.no_extras and args.sustain > 0:
-        n_c = max(int(args.sustain / 5 / max(dt / args.steps, 1e-4)), 1)   # steps per chunk: about a fifth of the span
+        n_c = max(int(args.sustain / 5 / max(dt / args.steps, 1e-4)) + 1, 1)   # steps per chunk: a fifth of the span
         chunks, done_s = [], 0
         barrier()
         ts0 = time.perf_counter()
-        while time.perf_counter() - ts0 < args.sustain + 0.05:             # time-based: at least `sustain` seconds
+        # six chunks = 1.2x the span at the timed rate: the SAME count on every rank (dt is the max over ranks), so that the
+        # collectives inside stay matched; a single process may add chunks until the span is really covered
+        while len(chunks) < 6 or (world == 1 and time.perf_counter() - ts0 < args.sustain + 0.05):
             tc = time.perf_counter()
             run_steps(n_c)
             collator.result()
@@ -351,6 +356,7 @@ def main():
             "sustained": sustained,
             "exact_fp32": exact,
             "rank_ms_per_step": rank_ms,
+            "rank_devices": [list(t) for t in rank_devices],
             "pipeline": {"cinn_of_next_step_under_decoder": bool(args.pipeline),
                          "single_call_ms": single_ms,
                          "note": "value counts `steps` cINN passes + `steps` decoder runs inside the timed region; with pipelining "
