@@ -83,6 +83,13 @@ __device__ unsigned long long w4_tt[2 * 8 * 18 * 2];   // [pass][wave][tap slot]
 // 36.4 -> 37.2 ms, Landscape 12.10 -> 12.23 ms.  Kept selectable (and statically checked) as the base of further work.
 constexpr int W4_DEFAULT_PIPE = 0;
 constexpr int W4_DEFAULT_ORDER = 2;   // brick -> XCD order (kernel comment); I2V_W4_ORDER overrides for A/B runs
+// Cache-policy experiments (measurement builds, tools/build_measurement_libs.sh nt): -DW4_V_NT marks the V stream (LDS-DMA loads)
+// non-temporal so that it does not turn the weight fragments out of the 4 MB L2; -DW4_OUT_NT stores the output non-temporally.
+#ifdef W4_V_NT
+#define W4_V_POLICY " nt"
+#else
+#define W4_V_POLICY ""
+#endif
 constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
 constexpr int W4_KC = 16;       // input channels per K chunk
 constexpr int W4_ROWS_A = 1024; // staged V rows per buffer, pass A (4 planes); pass B stages 512 (2 planes)
@@ -171,7 +178,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
 #define W4_GLDS(src_, dst_)                                                                                          \
     {                                                                                                                \
         unsigned keep_;                                                                                              \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" W4_V_POLICY "\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                              \
     }
 #define W4_REQUEST_V(ch_, VB, HF)                                                                                    \
@@ -695,7 +702,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                     for (int it = 0; it < NIT; ++it) {
                         const long p = tpos[tb + tid / NQ + TPI * it];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.out + (p + c) * a.Cout + n) = rres[it][c];
+                        for (int c = 0; c < 4; ++c) {
+#ifdef W4_OUT_NT
+                            __builtin_nontemporal_store(rres[it][c], reinterpret_cast<f32x4*>(a.out + (p + c) * a.Cout + n));
+#else
+                            *reinterpret_cast<f32x4*>(a.out + (p + c) * a.Cout + n) = rres[it][c];
+#endif
+                        }
                     }
                 }
                 if (half == 0 && th == 0) W4_STAMP(10)

@@ -397,7 +397,12 @@ __device__ __forceinline__ void mod_pos4_init(ModPos4<GB>& m, const float* ca, c
 template <bool GB>
 __device__ __forceinline__ void mod_pos4_eval(const ModPos4<GB>& m, const float* ca, const float* cb, long toff, int lrelu, float* d,
                                               float& vmax) {
+#ifdef MOD_NT   // measurement build: the writer's reads and writes are pure streams
+    typedef float f4v_ __attribute__((ext_vector_type(4)));
+    const f4v_ v0 = __builtin_nontemporal_load(reinterpret_cast<const f4v_*>(m.xp + toff));
+#else
     const float4 v0 = *reinterpret_cast<const float4*>(m.xp + toff);
+#endif
     const float r0[4] = {v0.x, v0.y, v0.z, v0.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -494,8 +499,13 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
                     ph[c] = hh;
                     pl[c] = (_Float16)(v - (float)hh);
                 }
+#ifdef MOD_NT
+                __builtin_nontemporal_store(ph, reinterpret_cast<half4_t*>(o + xq * ostride_x));
+                __builtin_nontemporal_store(pl, reinterpret_cast<half4_t*>(o + xq * ostride_x + 16));
+#else
                 *reinterpret_cast<half4_t*>(o + xq * ostride_x) = ph;
                 *reinterpret_cast<half4_t*>(o + xq * ostride_x + 16) = pl;
+#endif
             }
         }
     }

@@ -15,6 +15,8 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libi2v_hip.so")
+if os.environ.get("I2V_LIB_PATH"):   # measurement: another build of the same library (tools/build_measurement_libs.sh), relative to the repo
+    LIB_PATH = os.path.join(os.path.dirname(_PKG), os.environ["I2V_LIB_PATH"])
 CSRC = os.path.join(_PKG, "csrc")
 
 I2V_F32, I2V_I64, I2V_U8 = 0, 1, 2
