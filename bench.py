@@ -200,7 +200,12 @@ def main():
         for _ in range(n):
             barrier()
             t = time.perf_counter()
-            decode(flow(res_d, emb_d, reverse=True), g)
+            if args.pipeline:   # like get_model.Model.synthesize: the cINN pass on the side stream, the SPADE branches meanwhile
+                tk = prefetch.submit(res_d, emb_d)
+                (g or gen).prepare(x0_d)
+                decode(prefetch.get(tk), g)
+            else:
+                decode(flow(res_d, emb_d, reverse=True), g)
             collator.result()
             barrier()
             ts.append((time.perf_counter() - t) * 1e3)
@@ -351,7 +356,8 @@ def main():
             "value_is": ("pipelined stream rate: `steps` cINN passes + `steps` decoder runs, the pass of step k+1 enqueued under the "
                          "decoder of step k" if args.pipeline else "serial steps") + "; `single_call` is SURVEY §8d(i)'s one-call figure",
             "single_call": None if single_ms is None else {"ms": single_ms, "frames_per_s": frames_per_step / (single_ms * 1e-3),
-                                                           "what": "ONE serial call (cINN pass, then the decoder), median of 3"},
+                                                           "what": "ONE Model.synthesize-equivalent call, median of 3: the cINN pass on a side stream while the "
+                                                                   "decoder's SPADE branches (start frame only) are computed, then the rest of the decoder"},
             "steps_check": steps_check,
             "sustained": sustained,
             "exact_fp32": exact,

@@ -51,6 +51,8 @@ class Model(torch.nn.Module):
         self.z_dim = config.Decoder["z_dim"]
         self.vid_length = vid_length
         self.config = opt
+        self.overlap = True       # synthesize(): cINN pass on a side stream underneath the decoder's SPADE branches
+        self._prefetch = None
 
     @torch.no_grad()
     def sample_latent(self, x_0, cond=None, residual=None, embed=None):
@@ -70,8 +72,20 @@ class Model(torch.nn.Module):
 
     @torch.no_grad()
     def synthesize(self, x_0, cond=None, residual=None, embed=None):
-        """[B,3,H,W] -> [B, 16*ceil(vid_length/16), 3, H, W]; no batch slice."""
-        return self.decode(x_0, self.sample_latent(x_0, cond, residual, embed))
+        """[B,3,H,W] -> [B, 16*ceil(vid_length/16), 3, H, W]; no batch slice.
+        ONE call overlaps its own two halves where they are independent: the cINN pass (a 122-launch dependent chain that leaves
+        most of the chip idle) runs on a high-priority side stream while the current stream already computes the decoder's
+        SPADE branches, which depend on the start frame only (``overlap = False`` restores the strictly serial order; the
+        frames are the same bits either way)."""
+        if not (self.overlap and x_0.is_cuda):
+            return self.decode(x_0, self.sample_latent(x_0, cond, residual, embed))
+        import i2v_pipeline
+        if self._prefetch is None:
+            self._prefetch = i2v_pipeline.LatentPrefetcher(lambda a, b, c, d: self.sample_latent(a, b, c, d), device=x_0.device)
+        x_0 = x_0.contiguous()
+        ticket = self._prefetch.submit(x_0, cond, residual, embed)
+        self.decoder.prepare(x_0)
+        return self.decode(x_0, self._prefetch.get(ticket))
 
     def check(self):
         """Raises if the decoder's split-fp16 operands left the fp16 range in any call since the last check (sticky device

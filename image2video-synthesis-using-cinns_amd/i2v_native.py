@@ -96,6 +96,7 @@ SYMBOLS = {
     "i2v_dec_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32, c_int32]),
     "i2v_dec_flops_per_sample": (c_double, [c_void_p, c_int32, c_int32]),
     "i2v_dec_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "i2v_dec_prepare": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_int32, c_void_p]),
     "i2v_dec_set_profile": (c_int32, [c_void_p, c_int32]),
     "i2v_dec_debug_tap": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t]),
     "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
@@ -351,6 +352,20 @@ class NativeDecoder(_Handle):
             _check(lib().i2v_dec_debug_tap(self._h, -1, -1, None, 0), "i2v_dec_debug_tap")
         else:
             _check(lib().i2v_dec_debug_tap(self._h, block, which, dst.data_ptr(), dst.numel()), "i2v_dec_debug_tap")
+
+    @_on_device
+    def prepare(self, img):
+        """i2v_dec_prepare: enqueue the SPADE branches of all six blocks (they depend on the start frame only) on the current
+        stream; the next ``forward`` with the SAME tensor (same storage, batch, size) skips them.  Meant for a side stream
+        underneath the cINN pass; the caller orders the streams."""
+        _require_gpu(img)
+        B = img.shape[0]
+        if img.dim() != 4 or img.shape[1] != 3:
+            raise I2VError(f"decoder: expected img [B,3,H,W], got {tuple(img.shape)}")
+        nbytes = lib().i2v_dec_workspace_bytes(self._h, B, img.shape[2], img.shape[3])
+        ws = self._ws.get(nbytes, img.device)
+        _check(lib().i2v_dec_prepare(self._h, img.data_ptr(), img.shape[2], img.shape[3], ws.data_ptr(), ws.numel(), B, _stream()),
+               "i2v_dec_prepare")
 
     @_on_device
     def forward(self, img, motion):

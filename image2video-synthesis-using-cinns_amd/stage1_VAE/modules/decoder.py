@@ -74,3 +74,9 @@ class Generator(NativeBacked):
 
     def forward(self, img, motion):
         return self.native().forward(img.contiguous(), motion.contiguous())
+
+    def prepare(self, img):
+        """Not a reference method: enqueue the SPADE branches of all blocks for the start frames ``img`` (they do not depend on
+        the motion latent) on the current stream.  The next ``forward(img, z)`` with the SAME contiguous tensor skips them
+        (i2v_dec_prepare); ``get_model.Model.synthesize`` uses it to fill the time the cINN pass takes."""
+        self.native().prepare(img.contiguous())

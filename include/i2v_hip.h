@@ -157,6 +157,14 @@ double i2v_dec_flops_per_sample(const i2v_dec* d, int32_t img_h, int32_t img_w);
  * img [B,3,img_h,img_w] (NCHW, [-1,1]), motion [B,z_dim] -> out [B,T,3,H,W] contiguous. */
 int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, const float* motion,
                     float* out, void* workspace, size_t workspace_bytes, int32_t batch, void* stream);
+/* Optional first half of Generator.forward: the SPADE conditioning branches of all six blocks (normalization_layer.py:20-23:
+ * F.interpolate(start frame) -> Conv2d(3,128) + lrelu -> conv_gamma | conv_beta).  They depend on the start frame only, not on
+ * the motion latent, so a caller can enqueue them on a SIDE stream while the cINN pass that produces the latent runs
+ * (get_model.py:59-66), and then call i2v_dec_forward with the SAME img pointer, size, batch and workspace (after making its
+ * stream wait for the side stream): that forward skips the branches and reads the prepared gamma | beta maps from the
+ * workspace.  One prepare serves one forward; any other forward in between discards it.  Same kernels, same bits. */
+int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, void* workspace, size_t workspace_bytes,
+                    int32_t batch, void* stream);
 /* Roofline instrumentation.  With profiling on, every 3x3x3 Conv3d launch (the dominant kernel) is bracketed by HIP
  * events recorded on the launch stream -- no synchronisation is added to the forward.  After the caller has
  * synchronised, i2v_dec_get_profile resolves the pending pairs and returns the totals since set_profile(d, 1):

@@ -315,6 +315,30 @@ def test_f43_structure_switches_keep_the_bits(golden, monkeypatch):
     assert torch.equal(big[:3], ref) and torch.equal(big[15:], ref)
 
 
+def test_decoder_prepare_equals_plain_forward():
+    """i2v_dec_prepare (Generator.prepare): the SPADE branches of all blocks computed ahead of the forward -- the next forward
+    with the same start-frame tensor must give the same bits as a plain one; a forward with ANOTHER tensor in between must
+    ignore (and drop) the prepared maps; sub-batching and a prepare issued on a side stream work too."""
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    img, z = cu(g["img"]), cu(g["z"])
+    ref = gen(img, z)
+    gen.prepare(img)
+    assert torch.equal(gen(img, z), ref)
+    other = (img * 0.5).contiguous()
+    ref_other = gen(other, z)
+    gen.prepare(img)
+    assert torch.equal(gen(other, z), ref_other)          # different tensor: computed normally
+    assert torch.equal(gen(img, z), ref)                  # and the stale prepare was dropped, not reused later
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gen.prepare(img)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(gen(img, z), ref)
+    assert rel_l2(ref.cpu(), g["out"]) < TOL
+
+
 def _write_checkpoints(tmp_path, meta, with_embedder=False, with_encoder=False):
     """Checkpoint tree as get_model.Model expects it (get_model.py:15-43): <stage2>/config_stage2.yaml + cINN.pth,
     <stage1>/config_stage1.yaml + best_PFVD_GEN.pth."""
@@ -360,6 +384,11 @@ def test_model_forward_semantics_vs_golden(tmp_path):
     model.vid_length = 20
     assert list(model(cu(g["x1"]), residual=cu(g["r1"]), embed=cu(g["e1"])).shape) == list(g["y20_shape"])
     assert model.synthesize(cu(g["x3"]), residual=cu(g["r3"]), embed=cu(g["e3"])).shape[0] == 3
+    # one call overlaps its cINN pass (side stream) with the decoder's SPADE branches: same bits as the strictly serial order
+    a = model.synthesize(cu(g["x3"]), residual=cu(g["r3"]), embed=cu(g["e3"]))
+    model.overlap = False
+    b = model.synthesize(cu(g["x3"]), residual=cu(g["r3"]), embed=cu(g["e3"]))
+    assert torch.equal(a, b)
 
 
 def test_model_from_pixels_with_embedder(tmp_path):
