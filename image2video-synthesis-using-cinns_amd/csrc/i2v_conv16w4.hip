@@ -151,12 +151,12 @@ struct W4Next {
     int valid;          // there is a next brick
 };
 
-template <int NT, int WM, int VH, bool PRE, bool PIPE, class Between>
+template <int NT, int WM, int VH, bool PRE, bool PREL, int VXP, class Between>
 __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* gpos, const int* gposN, f32x16 (&acc)[WM],
                                         int (&arow)[WM], const char* wfrag, int HH, int tid, int lane, int wave, int rb0, int rb1,
                                         const W4Next& nxt, Between&& between, int w4_tlv_) {
     constexpr int VROWS = VH * 2 * 128;
-    constexpr int VX = PIPE && PRE ? 2 : 0;   // extra LDS-DMA loads per half-request (the next brick's first V brick)
+    constexpr int VX = PRE ? VXP : 0;   // extra LDS-DMA loads per half-request (the next brick's first V brick; PREL: this brick's was preloaded)
     const int kg = lane >> 5;
     char* v_lds = smem;
     const long cstride = (long)a.CoutPad * 384;          // bytes per (tap, chunk): 6 planes x CoutPad x 64
@@ -276,7 +276,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         W4_REQUEST_B(bq6, 6 % NT, 6 / NT)
         W4_REQUEST_B(bq7, 7 % NT, 7 / NT)
     }
-    if constexpr (!PRE && !PIPE) {
+    if constexpr (!PRE && !PREL) {
         __syncthreads();  // tables written
         W4_REQUEST_V(0, 0, 0)
         W4_REQUEST_V(0, 0, 1)
@@ -505,15 +505,17 @@ constexpr int W4_TABLE_BYTES = (2 * W4_ROWS_A + W4_TILES + 4 * W4_TILES) * 4;   
 //   * the epilogue therefore works in FOUR passes (32-channel half x 64-tile half: E = 6 x 64 x 32 fp32 = 48 KB) inside pass
 //     B's region and leaves the other one alone.
 // LDS (PIPE): [0, 64 K) [64 K, 128 K) the two regions, then two table sets; statistics partials behind E; one dump row.
-template <int NT, int BN, bool PIPE>
+// PIPE = 2 ("lite"): the persistent loop with only what was free in the measurement of PIPE = 1: the next brick's tables under pass
+// B's prologue, and its first V brick requested right behind the epilogue's last read of the exchange buffer (in front of the
+// statistics tail), into the fixed first region -- pass B and the two-half epilogue are those of the default kernel.
+template <int NT, int BN, int PIPE>
 __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
+    constexpr bool FULL = PIPE == 1, LITE = PIPE == 2, PERSIST = PIPE != 0;
     constexpr int WMA = BN == 64 ? 4 : 2, WMB = BN == 64 ? 2 : 1;
     constexpr int KT = NT / 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = lane >> 5, l31 = lane & 31;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int HH = a.TH + 2;
     const int plane = (a.TT + KT - 1) * HH * 4;
     const int nblk = a.CoutPad >> 5;
@@ -523,12 +525,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     int v = (int)blockIdx.x;
     W4Brick bk = w4_decode<BN>(a, v);
     int w4_tlv_ = v;   // (timeline builds index their stamps by the virtual workgroup)
-    W4_STAMP(0)
-    w4_tables<KT>(a, bk, reinterpret_cast<int*>(smem + a.tofs), tid);
-    if constexpr (PIPE) {
-        // the first brick of this workgroup: its first V brick is requested here (every later one by the previous brick's pass B)
-        __syncthreads();
-        const int* gq = reinterpret_cast<const int*>(smem + a.tofs) + (tid >> 2);
+    {
+        const int tid = tid0;
+        W4_STAMP(0)
+    }
+    w4_tables<KT>(a, bk, reinterpret_cast<int*>(smem + a.tofs), tid0);
+    // a brick's first V brick (pass A, chunk 0) into the first region: 8 LDS-DMA loads per thread from the table gq0
+    auto request_chunk0 = [&](const int* gq0, int tid) {
+        const int* gq = gq0 + (tid >> 2);
         const long vpiece = (long)((tid & 3) ^ ((tid >> 4) & 3)) * 16;
         const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
 #pragma unroll
@@ -536,25 +540,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             const int g = gq[128 * u];
             const char* src = g >= 0 ? a.in + vpiece + (long)g * 64 : a.zeros;
             unsigned keep_;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" W4_V_POLICY "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep_) : "v"(src), "s"(vdst + (unsigned)(u * 8192)) : "memory");
         }
+    };
+    if constexpr (PERSIST) {
+        // the first brick of this workgroup: its first V brick is requested here (every later one during the previous brick)
+        __syncthreads();
+        request_chunk0(reinterpret_cast<const int*>(smem + a.tofs), tid0);
     }
 #pragma unroll 1
     for (;;) {
-        int* gposA = reinterpret_cast<int*>(smem + a.tofs + (PIPE ? set * W4_TABLE_BYTES : 0));
+        // (persistent kernels: everything derived from the thread index is re-derived per brick -- hoisted out of the brick loop it
+        //  stays live across both tap loops and the epilogue and costs the 9-tap kernel more registers than it has)
+        int tid = tid0;
+        if constexpr (PERSIST) asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int kg = lane >> 5, l31 = lane & 31;
+        int* gposA = reinterpret_cast<int*>(smem + a.tofs + (PERSIST ? set * W4_TABLE_BYTES : 0));
         int* gposB = gposA + W4_ROWS_A;
         const int* tpos = gposB + W4_ROWS_A;
         const int* tres = tpos + W4_TILES;
         const int n0 = bk.ntile * BN, b0 = bk.b0;
         const char* wbase = a.wp + (long)bk.par * a.wset_stride;   // wave-uniform; the lane's 16 bytes are added by the load
         const int vn = v + (int)gridDim.x;
-        const bool more = PIPE && vn < a.nvirt;
+        const bool more = PERSIST && vn < a.nvirt;
         const W4Brick bn_ = more ? w4_decode<BN>(a, vn) : bk;
         int* gposAn = reinterpret_cast<int*>(smem + a.tofs + (set ^ 1) * W4_TABLE_BYTES);
         // V buffers (LDS rows): pass A alternates between the two 64 KB regions starting at `flip`; pass B's two 32 KB buffers
         // live in region `flip` (pass A's last chunk -- an odd one -- reads the other region)
-        const int rA0 = PIPE ? flip * 1024 : 0, rA1 = PIPE ? (flip ^ 1) * 1024 : W4_ROWS_A;
+        const int rA0 = FULL ? flip * 1024 : 0, rA1 = FULL ? (flip ^ 1) * 1024 : W4_ROWS_A;
         const int rB0 = rA0, rB1 = rA0 + 512;
 
         // ---- pass A: planes 0..3, wave = (plane, 32-channel half), all 128 tiles   [BN = 32: (plane, tile half)]
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                 for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
             }
             const W4Next none{gposA, 0u, 0u, 0};
-            w4_pass<NT, WMA, 4, false, PIPE>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid,
+            w4_pass<NT, WMA, 4, false, PERSIST, 0>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid,
                                              lane, wave, rA0, rA1, none, [] {}, w4_tlv_);
         }
         W4_STAMP(2)
@@ -595,11 +610,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             const W4Next nxt{(more ? gposAn : gposA) + (tid >> 2),
                              (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(flip ^ 1) * 65536u + (unsigned)wave * 1024u)),
                              (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)flip * 65536u + 30720u)), more ? 1 : 0};   // dump: rows 480..495 of pass B's first buffer (zero padding, never read)
-            w4_pass<NT, WMB, 2, true, PIPE>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid,
+            w4_pass<NT, WMB, 2, true, PERSIST, FULL ? 2 : 0>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid,
                                             lane, wave, rB0, rB1, nxt, [&] {
                                                 // (PIPE) the next brick's tables, built while this pass's first weight fragments
                                                 // travel; published by the barrier in front of the loop
-                                                if constexpr (PIPE) { if (more) w4_tables<KT>(a, bn_, gposAn, tid); }
+                                                if constexpr (PERSIST) { if (more) w4_tables<KT>(a, bn_, gposAn, tid); }
                                             }, w4_tlv_);
         }
         W4_STAMP(4)
@@ -610,10 +625,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         // !PIPE: one 32-channel half at a time, all 128 tiles (98 KB over both V regions).  PIPE: (32-channel half, 64-tile half)
         // quarters of 48 KB inside pass B's region -- the other region holds the next brick's first V brick already.
         constexpr int NQ = 8, TPI = 64;
-        constexpr int NTH = PIPE ? 2 : 1;             // tile halves per channel half
+        constexpr int NTH = FULL ? 2 : 1;             // tile halves per channel half
         constexpr int ET = W4_TILES / NTH;            // tiles in E
         constexpr int NIT = ET / TPI;
-        float* E = reinterpret_cast<float*>(smem + (PIPE ? flip * 65536 : 0));
+        float* E = reinterpret_cast<float*>(smem + (FULL ? flip * 65536 : 0));
         double* S = reinterpret_cast<double*>(reinterpret_cast<char*>(E) + 6 * ET * 32 * 4);   // [2 halves][8 waves][32 channels][2] behind E
         const int n4 = tid % NQ;
         const int e3 = kg * 96, e5 = kg * 160;   // row offsets (in floats) of the wave's upper lanes, see the E writes
@@ -735,8 +750,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             }
             W4_STAMP(5 + half)
         }
-        if (a.stats) {
+        if constexpr (LITE) {
+            // every wave has read the exchange buffer for the last time: the first region may take the next brick's first V brick
+            // (its tables were written under pass B's prologue); the statistics tail and the loop-back hide part of its latency
             __syncthreads();
+            if (more) request_chunk0(gposAn, tid);
+        }
+        if (a.stats) {
+            if constexpr (!LITE) __syncthreads();
             if (wave < BN / 32 && lane < 32 && n0 + wave * 32 + lane < a.Cout) {   // wave h sums channel half h
                 const double* Sh = S + wave * (8 * 32 * 2);
                 double s0 = 0.0, s1 = 0.0;
@@ -752,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         }
         W4_STAMP(7)
         if (!more) break;
-        v = vn; bk = bn_; flip ^= 1; set ^= 1;
+        v = vn; bk = bn_; flip ^= FULL ? 1 : 0; set ^= 1;
         w4_tlv_ = v;
         W4_STAMP(0)
     }
@@ -851,7 +872,7 @@ int Wino4Weights::pack_tdup(const float* w_src, const float* bias_src, int cout,
     return I2V_OK;
 }
 
-template <int NT, int BN, bool PIPE>
+template <int NT, int BN, int PIPE>
 static int launch_wino4_(const W4Args& a, unsigned grid, size_t lds, hipStream_t st) {
     auto kern = conv_wino4_f16x3_kernel<NT, BN, PIPE>;
     static bool attr_set[I2V_MAX_DEV] = {};
@@ -891,14 +912,15 @@ static int launch_wino4(W4Args& a, unsigned nblk, hipStream_t st) {
         int grid = std::min(a.nvirt, device_cus());
         if (grid >= 8) grid &= ~7;
         const size_t lds = (size_t)body + 2 * (size_t)W4_TABLE_BYTES;
-        return launch_wino4_<NT, BN, true>(a, (unsigned)grid, lds, st);
+        if (env_pipe == 2) return launch_wino4_<NT, BN, 2>(a, (unsigned)grid, lds, st);
+        return launch_wino4_<NT, BN, 1>(a, (unsigned)grid, lds, st);
     }
 #ifdef W4_TAPTIME
     const size_t lds = 160 * 1024;
 #else
     const size_t lds = (size_t)body + (size_t)W4_TABLE_BYTES;
 #endif
-    return launch_wino4_<NT, BN, false>(a, (unsigned)a.nvirt, lds, st);
+    return launch_wino4_<NT, BN, 0>(a, (unsigned)a.nvirt, lds, st);
 }
 
 int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T, int H,

@@ -304,15 +304,16 @@ def test_f43_structure_switches_keep_the_bits(golden, monkeypatch):
     x0, z = x0.cuda(), z.cuda()
     ref = _gen(meta)(x0, z)
     assert rel_l2(ref[1:2, ..., ::2, ::2].cpu(), g["out_s2"]) < TOL
-    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"), ("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2")):
+    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_PIPE", "2"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"), ("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2")):
         monkeypatch.setenv(env, val)
         alt = _gen(meta)(x0, z)
         monkeypatch.delenv(env)
         assert torch.equal(alt, ref), (env, val, float((alt - ref).abs().max()))
-    monkeypatch.setenv("I2V_W4_PIPE", "1")
-    gen = _gen(meta)
-    big = gen(x0.repeat(6, 1, 1, 1), z.repeat(6, 1))              # 18 samples: several bricks per persistent workgroup
-    assert torch.equal(big[:3], ref) and torch.equal(big[15:], ref)
+    for pipe in ("1", "2"):
+        monkeypatch.setenv("I2V_W4_PIPE", pipe)
+        gen = _gen(meta)
+        big = gen(x0.repeat(6, 1, 1, 1), z.repeat(6, 1))              # 18 samples: several bricks per persistent workgroup
+        assert torch.equal(big[:3], ref) and torch.equal(big[15:], ref), pipe
 
 
 def test_decoder_prepare_equals_plain_forward():

@@ -327,11 +327,11 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     text = asm.read_text()
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import check_asm_waits as caw
-    kernels = re.findall(r"^(_ZN3i2v23conv_wino4_f16x3_kernelILi(\d)ELi(\d+)ELb(\d)EEEvNS_6W4ArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+    kernels = re.findall(r"^(_ZN3i2v23conv_wino4_f16x3_kernelILi(\d)ELi(\d+)ELi(\d)EEEvNS_6W4ArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
                          flags=re.S | re.M)
-    # <9,64> <6,64> <3,64> (SPADE's 2-D convs) <9,32> <6,32>, each as the software-pipelined persistent kernel (PIPE = 1) and as
-    # round 3's one-workgroup-per-brick kernel (PIPE = 0)
-    assert len(kernels) == 10, [k[0] for k in kernels]
+    # <9,64> <6,64> <3,64> (SPADE's 2-D convs) <9,32> <6,32>, each as round 3's one-workgroup-per-brick kernel (PIPE = 0), as the
+    # software-pipelined persistent kernel (PIPE = 1) and as its "lite" form (PIPE = 2)
+    assert len(kernels) == 15, [k[0] for k in kernels]
     for name, nt, bn, pipe, whole in kernels:
         nt = int(nt)
         assert "scratch_" not in whole and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", whole), name
