@@ -111,6 +111,7 @@ struct W4Args {
     float oscale;
     int tofs;           // LDS byte offset of the index tables
     int order;          // brick -> XCD order (see w4_decode): 0 round-robin over the flat brick index, 1 / 2 one w-column per XCD
+    int skew;           // persistent kernels: start delay of workgroup i in units of ~5 us x ((i >> 3) & 3) (measurement, I2V_W4_SKEW)
     int nvirt;          // virtual workgroups = bricks x channel tiles x frame parities (PIPE: looped over by gridDim.x workgroups)
 };
 
@@ -545,6 +546,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         }
     };
     if constexpr (PERSIST) {
+        // (measurement: de-synchronise the persistent workgroups -- the CUs of an XCD start a quarter of a brick apart)
+        for (int i = 0; i < a.skew * (int)((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(127);
         // the first brick of this workgroup: its first V brick is requested here (every later one during the previous brick)
         __syncthreads();
         request_chunk0(reinterpret_cast<const int*>(smem + a.tofs), tid0);
@@ -965,6 +968,7 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     if (env_bn == 32 && wts.KT != 1) BN = 32;
     if (env_bn == 64 && a.CoutPad % 64 == 0) BN = 64;
     a.order = env_order;
+    { const char* es_ = getenv("I2V_W4_SKEW"); a.skew = es_ ? atoi(es_) : 0; }
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
     // the kernel's index tables (gpos: V rows, tpos / tres: output and residual positions) are 32-bit
