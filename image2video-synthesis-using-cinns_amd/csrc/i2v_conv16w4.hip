@@ -76,11 +76,13 @@ __device__ unsigned long long w4_tt[2 * 8 * 18 * 2];   // [pass][wave][tap slot]
 #else
 #define W4_TT(U)
 #endif
-// 0: one workgroup per brick (round 3's structure, the default); 1 (I2V_W4_PIPE=1): the software-pipelined persistent kernel.
-// Measured (profiles/r04_b_*): correct on every shape and in the whole GPU suite, but not faster -- per workgroup of the
-// 128 -> 128 layer it removes 1.9 us of prologue and 1.0 us of pass A and pays 0.7 us (tables under pass B's prologue), 1.5 us (pass B
-// with the extra loads) and 1.4 us (four-quarter epilogue): 81.9 -> 82.7 us; thin layers +2..4 %, wide ones -2..4 %; B = 64 BAIR step
-// 36.4 -> 37.2 ms, Landscape 12.10 -> 12.23 ms.  Kept selectable (and statically checked) as the base of further work.
+// Structure of the kernel (I2V_W4_PIPE): 0 one workgroup per brick (round 3's structure, the default); 1 the software-pipelined
+// persistent kernel; 2 its "lite" form (see the kernel's comment).  All three give the same bits and pass the static checks.
+// Measured (profiles/r04_b_*, r04_l_*): 1 removes 1.9 us of prologue and 1.0 us of pass A per workgroup of the 128 -> 128 layer
+// and pays 0.7 us (tables under pass B's prologue), 1.5 us (pass B with the extra loads) and 1.4 us (four-quarter epilogue):
+// 81.9 -> 82.7 us.  2 gains 2.3 % there (82.3 -> 80.4 us) and loses 11 % on 64 -> 64, where both tap loops slow down: the 256
+// persistent workgroups run the same phase at the same time, which the hardware dispatcher of the default kernel avoids.
+// Whole steps +-1 % either way, so the default stays 0.
 constexpr int W4_DEFAULT_PIPE = 0;
 constexpr int W4_DEFAULT_ORDER = 2;   // brick -> XCD order (kernel comment); I2V_W4_ORDER overrides for A/B runs
 // Cache-policy experiments (measurement builds, tools/build_measurement_libs.sh nt): -DW4_V_NT marks the V stream (LDS-DMA loads)
