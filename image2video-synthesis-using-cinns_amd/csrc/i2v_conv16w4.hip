@@ -422,7 +422,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
 struct W4Brick { int par, ntile, b0, t0, h0, j0; };
 
 template <int BN>
-__device__ __forceinline__ W4Brick w4_decode(const W4Args& a, int v) {
+__host__ __device__ __forceinline__ W4Brick w4_decode(const W4Args& a, int v) {
     const int nNt = a.CoutPad / BN;
     const int npar = a.tdup ? 2 : 1;
     const int per_brick = nNt * npar;
@@ -1033,4 +1033,46 @@ void w4_timeline_report(unsigned nwg) {
 }
 #endif
 
+#ifdef W4_DECODE_SELFTEST
+// Host-side self-test of the virtual-workgroup -> (brick, channel tile, frame parity) map (tests/test_host_cpu.py compiles this
+// file with -DW4_DECODE_SELFTEST for the host only): for every order and a sweep of geometries the map must be a bijection onto
+// {samples} x {t bricks} x {h bricks} x {w bricks} x {channel tiles} x {parities}.
+template <int BN>
+static long w4_decode_check(int B, int nbT, int nbH, int nbJ, int coutpad, int tdup, int order) {
+    W4Args a{};
+    a.B = B; a.nbT = nbT; a.nbH = nbH; a.nbJ = nbJ; a.CoutPad = coutpad; a.tdup = tdup; a.order = order; a.TT = 4; a.TH = 8;
+    const int nNt = coutpad / BN, npar = tdup ? 2 : 1;
+    a.nvirt = B * nbT * nbH * nbJ * nNt * npar;
+    std::vector<char> seen((size_t)a.nvirt, 0);
+    long bad = 0;
+    for (int v = 0; v < a.nvirt; ++v) {
+        const W4Brick k = w4_decode<BN>(a, v);
+        const int bt = k.t0 / a.TT, bh = k.h0 / a.TH, bj = k.j0 / 4;
+        if (k.par < 0 || k.par >= npar || k.ntile < 0 || k.ntile >= nNt || k.b0 < 0 || k.b0 >= B || bt < 0 || bt >= nbT || bh < 0 || bh >= nbH ||
+            bj < 0 || bj >= nbJ) { ++bad; continue; }
+        const size_t id = (((((size_t)k.b0 * nbT + bt) * nbH + bh) * nbJ + bj) * nNt + k.ntile) * npar + k.par;
+        if (seen[id]) ++bad;
+        seen[id] = 1;
+    }
+    return bad;
+}
 }  // namespace i2v
+int main() {
+    long bad = 0, cases = 0;
+    for (int order = 0; order < 3; ++order)
+        for (int B : {1, 2, 3, 8, 13, 64})
+            for (int nbT : {1, 2, 4})
+                for (int nbH : {1, 2, 8, 16})
+                    for (int nbJ : {1, 2, 4, 8})
+                        for (int tdup = 0; tdup < 2; ++tdup)
+                            for (int cp : {32, 64, 128, 512}) {
+                                bad += i2v::w4_decode_check<32>(B, nbT, nbH, nbJ, cp, tdup, order);
+                                if (cp % 64 == 0) bad += i2v::w4_decode_check<64>(B, nbT, nbH, nbJ, cp, tdup, order);
+                                ++cases;
+                            }
+    printf("w4_decode self-test: %ld geometries, %ld bad\n", cases, bad);
+    return bad ? 1 : 0;
+}
+#else
+}  // namespace i2v
+#endif

@@ -355,6 +355,23 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     assert caw.check_scalar_operands(text, "conv_wino4_f16x3_kernel") == []
 
 
+def test_f43_virtual_workgroup_map_is_a_bijection(tmp_path):
+    """The F(4,3) kernel turns a (virtual) workgroup index into (sample, brick, channel tile, frame parity) -- per XCD, in one of
+    three orders, also when the persistent variants loop over it.  A wrong map would skip or double bricks silently for the
+    geometries no parity test happens to cover, so the map is compiled for the HOST (-DW4_DECODE_SELFTEST) and enumerated over a
+    sweep of geometries: it must hit every work item exactly once."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = tmp_path / "w4_decode_selftest"
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-DW4_DECODE_SELFTEST", "-I" + os.path.join(PKG, "csrc"),
+                    "-I" + os.path.join(REPO, "include"), os.path.join(PKG, "csrc", "i2v_conv16w4.hip"), os.path.join(PKG, "csrc", "i2v_common.hip"),
+                    "-o", str(exe)], check=True, capture_output=True, timeout=900)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and " 0 bad" in out.stdout, out.stdout + out.stderr
+
+
 def waits_of(loop):
     return [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)]
 
