@@ -80,7 +80,7 @@ class Model(torch.nn.Module):
         if not (self.overlap and x_0.is_cuda):
             return self.decode(x_0, self.sample_latent(x_0, cond, residual, embed))
         import i2v_pipeline
-        if self._prefetch is None:
+        if self._prefetch is None or self._prefetch.stream.device != x_0.device:
             self._prefetch = i2v_pipeline.LatentPrefetcher(lambda a, b, c, d: self.sample_latent(a, b, c, d), device=x_0.device)
         x_0 = x_0.contiguous()
         ticket = self._prefetch.submit(x_0, cond, residual, embed)
