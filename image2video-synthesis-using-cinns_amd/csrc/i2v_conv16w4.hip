@@ -212,6 +212,9 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     AOps a0, a1;
     int adn[WM];
     constexpr int R = NT == 9 ? 9 : 6;
+    // tap at whose start the second half of the next chunk's V brick is requested (the first half: tap 0).  A 3-tap chunk
+    // (SPADE's 2-D convs) requests both at tap 0: the brick then has two taps instead of one to arrive before the chunk barrier.
+    constexpr int VT1 = NT == 3 ? 0 : 1;
     BOps bq0, bq1, bq2, bq3, bq4, bq5, bq6, bq7, bq8;
     /* LDS address of one row block of the A operands, and its two ds_read_b128 */
 #define W4_ADDR_A(TAP, VB, wm)                                                                                       \
@@ -314,22 +317,24 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     // Younger than the weight request of tap U (issued in the middle of tap U - R + 1): the weight requests of taps
     // U-R+2 .. U-1 (2 (R-2) loads) and the V half-requests (VH loads each) of every chunk's taps 0 and 1 among taps
     // U-R+2 .. U.  At a chunk's last tap the next chunk's brick must have landed: younger than its second half-request (start
-    // of tap 1) are the weight requests of taps 1 .. NT-2.
+    // of tap VT1) are the weight requests of taps VT1 .. NT-2.
 #define W4_TAP(U, ACUR, ANXT, BCUR, BREQ)                                                                            \
     {                                                                                                                \
         constexpr int cp_ = (U) / NT, t_ = (U) % NT;                                                                 \
         constexpr int un_ = (U) + R - 1, cn_ = un_ / NT, tn_ = un_ % NT;                                             \
-        constexpr int ng_ = w4_count(t_, R - 1, NT, 0) + w4_count(t_, R - 1, NT, 1 % NT);                            \
+        constexpr int ng_ = w4_count(t_, R - 1, NT, 0) + w4_count(t_, R - 1, NT, VT1);                               \
         constexpr int nb_ = 2 * (R - 2) + (VH + VX) * ng_;                                                           \
         W4_TT(U)                                                                                                     \
         if constexpr (W4_PRIO && (t_ == 0 || w4_prio(t_, NT) != w4_prio(t_ - 1, NT)))                                \
             __builtin_amdgcn_s_setprio(w4_prio(t_, NT));                                                             \
         if constexpr (WM >= 2) asm volatile("" : "+v"(arow[0]), "+v"(arow[1]), "+v"(arow[WM - 2]), "+v"(arow[WM - 1])); \
         else asm volatile("" : "+v"(arow[0]));                                                                       \
-        if constexpr (t_ < 2)                                                                                        \
-            W4_REQUEST_V(ch + cp_ + 1, 1 - cp_, t_)                                                                  \
+        if constexpr (t_ == 0)                                                                                       \
+            W4_REQUEST_V(ch + cp_ + 1, 1 - cp_, 0)                                                                   \
+        if constexpr (t_ == VT1)                                                                                     \
+            W4_REQUEST_V(ch + cp_ + 1, 1 - cp_, 1)                                                                   \
         if constexpr (t_ == NT - 1) {                                                                                \
-            W4_WAIT_VM(2 * (NT - 2))                                                                                 \
+            W4_WAIT_VM(2 * (NT - 1 - VT1))                                                                           \
             __syncthreads();                                                                                         \
         }                                                                                                            \
         W4_WAIT_B(BCUR, nb_)                                                                                         \
