@@ -86,10 +86,15 @@ def main():
                          "under rocprofv3 so that the kernel trace holds the timed steps only")
     ap.add_argument("--sustain", type=float, default=10.0, help="seconds of back-to-back steps after the timed region (0: skip)")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 (mma = 0) leg")
-    ap.add_argument("--live-traffic", action="store_true",
+    ap.add_argument("--live-traffic", dest="live_traffic", action="store_true", default=None,
                     help="after the timing, measure the HBM bytes per launch of the dominant kernel and per cINN pass NOW (two child runs of this "
-                         "workload under `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace`, tools/pmc_hbm_traffic.py; ~2 min) instead of "
-                         "quoting the newest committed profiles/r*_pmc_hbm_traffic.json")
+                         "workload under `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace`, tools/pmc_hbm_traffic.py; ~1-2 min) instead of "
+                         "quoting the newest committed profiles/r*_pmc_hbm_traffic.json.  DEFAULT for a full N = 1 run (no --no-extras); if "
+                         "rocprofv3 is missing or the child passes exceed I2V_PMC_TIMEOUT (default 240 s) the line falls back to the static figure "
+                         "and says so")
+    ap.add_argument("--no-live-traffic", dest="live_traffic", action="store_false")
+    ap.add_argument("--small-batch", type=int, default=8,
+                    help="second first-class workload of the default line: the per-GPU share of the BAIR B = 64 job on 8 GPUs (0: skip)")
     ap.add_argument("--per-layer", type=str, help="write the per-layer table of the 3x3x3 conv launches (CSV) here")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="1 (default): the cINN pass of step k+1 runs on a side stream underneath the decoder of step k "
@@ -175,9 +180,7 @@ def main():
         g = g or gen
         z = z.view(hi - lo, -1)
         last_z["z"] = z
-        seq = g(x0_d, z)
-        while seq.shape[1] < vid_length:
-            seq = torch.cat((seq, g(seq[:, -1].contiguous(), z)), dim=1)
+        seq = g.decode_sequence(x0_d, z, vid_length)   # get_model.py:68-73, decoded in place into one [B, vid_length, 3, H, W] buffer
         step_sums.append(checksum(seq))
         collator.submit(seq)   # N > 1: all-gather on a side stream, overlapping the next step; N = 1: keeps the tensor
         return seq
@@ -353,8 +356,10 @@ def main():
                                    "20-block cINN inverse + decoder pass(es)" + (" + RCCL all-gather (overlapped)" if world > 1 else ""),
                        "global_batch": total, "per_gpu_batch": nb, "frames_per_step": frames_per_step,
                        "parallelism": f"batch-shard x{world}"},
-            "value_is": ("pipelined stream rate: `steps` cINN passes + `steps` decoder runs, the pass of step k+1 enqueued under the "
-                         "decoder of step k" if args.pipeline else "serial steps") + "; `single_call` is SURVEY §8d(i)'s one-call figure",
+            "value_is": ("THE METRIC (BASELINE.json: synthesized frames/sec, whole-job throughput over `steps` steps): " +
+                         ("pipelined stream rate -- `steps` cINN passes + `steps` decoder runs, the pass of step k+1 enqueued under the "
+                          "decoder of step k" if args.pipeline else "serial steps") +
+                         ".  `single_call` is SURVEY §8d(i)'s frames/s of ONE call (latency figure, not the metric); both are printed"),
             "single_call": None if single_ms is None else {"ms": single_ms, "frames_per_s": frames_per_step / (single_ms * 1e-3),
                                                            "what": "ONE Model.synthesize-equivalent call, median of 3: the cINN pass on a side stream while the "
                                                                    "decoder's SPADE branches (start frame only) are computed, then the rest of the decoder"},
@@ -404,7 +409,10 @@ def main():
             result["encoder"] = encoder_latency(cfg, x0_d)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
-        if args.live_traffic and world == 1:
+        if default_workload and world == 1 and not args.no_extras and args.small_batch > 0:
+            result["small_batch"] = small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, args.small_batch, result)
+        live = args.live_traffic if args.live_traffic is not None else (not args.no_extras)
+        if live and world == 1:
             live_traffic(result, args)
         if args.per_layer:
             write_per_layer(args.per_layer, layers, args.steps, gen.mma)
@@ -526,22 +534,93 @@ def dry_run(args):
     return 0 if ok else 1
 
 
+def small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, nb, result):
+    """The per-GPU share of the default job on 8 GPUs (BASELINE north_star: >= 6x at 8 GPUs for BAIR 64x64x16): the same step at
+    batch `nb` on THIS GPU -- one serial call (median of 5) and the pipelined stream rate (30 steps) -- and the strong-scaling
+    figure they PROJECT: T(64) / T(nb) before collation.  A projection from one GPU, labelled so; no multi-GPU claim."""
+    import i2v_pipeline
+    x, r, e = x0_d[:nb].contiguous(), res_d[:nb].contiguous(), emb_d[:nb].contiguous()
+    pf = i2v_pipeline.LatentPrefetcher(lambda a, b: flow(a, b, reverse=True), device=x.device)
+
+    def one_call():
+        tk = pf.submit(r, e)
+        gen.prepare(x)
+        return gen.decode_sequence(x, pf.get(tk).view(nb, -1), vid_length)
+
+    def stream(n):
+        tk = pf.submit(r, e)
+        for k in range(n):
+            z = pf.get(tk)
+            if k + 1 < n:
+                tk = pf.submit(r, e)
+            gen.decode_sequence(x, z.view(nb, -1), vid_length)
+
+    for _ in range(2):
+        one_call()
+    ts = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        one_call()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t) * 1e3)
+    single = float(np.median(ts))
+    stream(3)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    stream(30)
+    torch.cuda.synchronize()
+    piped = (time.perf_counter() - t) / 30 * 1e3
+    big_single = (result.get("single_call") or {}).get("ms")
+    frames = nb * 16 * max(1, -(-vid_length // 16))
+    return {"what": f"the same step at batch {nb} = the per-GPU share of the B = 64 job on {64 // nb} GPUs, measured on this one GPU",
+            "batch": nb, "single_call_ms": single, "single_call_frames_per_s": frames / (single * 1e-3),
+            "pipelined_ms_per_step": piped, "pipelined_frames_per_s": frames / (piped * 1e-3),
+            "projected_strong_scaling": {"gpus": 64 // nb,
+                                         "single_call": None if not big_single else big_single / single,
+                                         "pipelined": result["ms_per_step"] / piped,
+                                         "note": "PROJECTION from one-GPU runs: T(B = 64) / T(B = %d), before the all-gather of the "
+                                                 "[B/N,16,3,64,64] blocks (0.8 MB per rank and step); not a multi-GPU measurement" % nb}}
+
+
 def live_traffic(result, args):
     """--live-traffic: run tools/pmc_hbm_traffic.py (separate FETCH_SIZE / WRITE_SIZE passes of one step of THIS workload under
-    rocprofv3, the guide's gfx950 correction) in a child process while this process idles, and replace the static figures."""
+    rocprofv3, the guide's gfx950 correction) in a child process group while this process idles, and replace the static figures.
+    On any failure (no rocprofv3, time limit) the static figures stay, labelled, with the reason next to them."""
+    import shutil
+    import signal
     import subprocess
     import tempfile
+    r = result.get("roofline")
+    if not r:
+        return
+    if not shutil.which("rocprofv3"):
+        r["traffic_live_error"] = "rocprofv3 not on PATH"
+        return
     out = os.environ.get("I2V_PMC_OUT") or tempfile.mkdtemp(prefix="i2v_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))   # (I2V_PMC_OUT: keep the summary)
     cmd = [sys.executable, os.path.join(REPO, "tools", "pmc_hbm_traffic.py"), out, "--config", args.config, "--scaling", args.scaling]
     if args.batch:
         cmd += ["--batch", str(args.batch)]
+    limit = float(os.environ.get("I2V_PMC_TIMEOUT", "240"))
+    t0 = time.perf_counter()
     try:
-        subprocess.run(cmd, check=True, cwd=REPO, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        proc = subprocess.Popen(cmd, cwd=REPO, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = proc.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)   # the whole group: pmc_hbm_traffic.py -> rocprofv3 -> bench.py
+            proc.wait()
+            raise
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, cmd)
         with open(os.path.join(out, "hbm_traffic.json")) as f:
             k = json.load(f)["kernels"]
     except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
-        result["roofline"]["traffic_live_error"] = repr(e)[:200]
+        r["traffic_live_error"] = repr(e)[:200]
+        if r.get("traffic_source"):
+            r["traffic_source"] += f"  [live measurement failed after {time.perf_counter() - t0:.0f} s]"
         return
+    r["traffic_live_seconds"] = time.perf_counter() - t0
     r = result["roofline"]
     name = next((n for n in k if r["kernel_name"] in n and "3x3x3" in n), None)
     if name:

@@ -43,12 +43,13 @@ struct ConvArgs {
     int nbB, nbT, nbH, nbW;   // bricks per dimension
     int rt, rs;               // nearest-upsample factors applied when reading `res`
     int epi;
+    long frames_bstride;      // EPI_FRAMES: floats between the samples of `out` (>= T * Cout * H * W)
 };
 
 // Chooses the brick and the tile variant and enqueues the kernel.
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
                  int B, int T, int H, int W, int epi, hipStream_t st, const float* coef = nullptr, int stride = 1,
-                 int stride_t = 1);
+                 int stride_t = 1, long frames_bstride = 0);
 
 // ---- 1x1(x1) convs / Linear layers as a plain pipelined GEMM (i2v_pointwise.hip); conv_forward dispatches to it
 bool pointwise_supported(const ConvWeights& wts, const float* res, int rt, int rs, int epi, int stride, int stride_t);
@@ -160,8 +161,8 @@ struct ConvImgMfmaWeights {
 };
 bool conv_img_mfma_supported(int T, int H, int W, int C);
 int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st,
-                          int* range_flag = nullptr);
+                          int* range_flag = nullptr, long out_bstride = 0);
 // in: fp32 channels-last [B][T][H][W][Cin]; out: frames [B][T][3][H][W] with tanh applied
-int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st);
+int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st, long out_bstride = 0);
 
 }  // namespace i2v

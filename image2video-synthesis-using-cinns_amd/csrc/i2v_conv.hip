@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
                 if (a.epi & EPI_LRELU) v = v >= 0.f ? v : 0.2f * v;
                 if (a.epi & EPI_FRAMES) {
                     const int bt_ = p / HWo, hw = p - bt_ * HWo;
-                    a.out[((long)bt_ * a.Cout + n) * HWo + hw] = tanhf(v);
+                    const int b_ = bt_ / a.T, t_ = bt_ - b_ * a.T;
+                    a.out[(long)b_ * a.frames_bstride + ((long)t_ * a.Cout + n) * HWo + hw] = tanhf(v);
                 } else if (a.epi & EPI_HL16) {
                     const _Float16 hi = (_Float16)v;
                     char* o = reinterpret_cast<char*>(a.out) + (long)p * a.Cout * 4 + (n >> 3) * 32 + (n & 7) * 2;
@@ -342,7 +343,7 @@ int launch(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
 }  // namespace
 
 int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* out, const float* res, int rt, int rs,
-                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef, int stride, int stride_t) {
+                 int B, int T, int H, int W, int epi, hipStream_t st, const float* coef, int stride, int stride_t, long frames_bstride) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv: weights not packed");
     I2V_REQUIRE(cin_act % 4 == 0 && cin_act >= wts.Cin, I2V_E_INVALID, "conv: activation channels %d (weights %d)",
                 cin_act, wts.Cin);
@@ -362,6 +363,7 @@ int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* ou
     a.Cout = wts.Cout; a.CoutPad = wts.CoutPad; a.nchunk = wts.nchunk;
     a.KT = wts.KT; a.KH = wts.KH; a.KW = wts.KW;
     a.rt = res ? rt : 1; a.rs = res ? rs : 1; a.epi = epi;
+    a.frames_bstride = frames_bstride ? frames_bstride : (long)T * wts.Cout * H * W;
     // brick: as cubic as the layer allows (small halo), remaining factor goes to the batch
     int TW = W < 8 ? W : 8, TH = H < 8 ? H : 8;
     int rem = CONV_BM / (TW * TH);

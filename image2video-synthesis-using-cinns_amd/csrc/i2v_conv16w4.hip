@@ -1022,16 +1022,24 @@ void w4_timeline_report(unsigned nwg) {
     const char* nm[6] = {"tables + first V brick", "pass A loop", "hand-over to pass B", "pass B loop", "epilogue half 0", "epilogue half 1"};
     double sum[6] = {}, sub[5] = {}, tot = 0;
     unsigned long long lo = ~0ull, hi = 0;
+    unsigned cnt = 0;
     for (unsigned w = 0; w < nwg; ++w) {
-        const unsigned long long* t = &h[w * 16];
+        unsigned long long t[16];
+        for (int i = 0; i < 16; ++i) t[i] = h[w * 16 + i];
+        if (!t[6]) t[6] = t[5];   // 32-channel workgroups have ONE epilogue half: stamp 6 is never written (it used to wrap to 1.8e17)
+        if (!t[0] || !t[7] || t[7] < t[0]) continue;   // workgroup not stamped
+        ++cnt;
         for (int i = 0; i < 6; ++i) sum[i] += (double)(t[i + 1] - t[i]);
         sub[0] += (double)(t[8] - t[4]); sub[1] += (double)(t[9] - t[8]); sub[2] += (double)(t[10] - t[9]); sub[3] += (double)(t[5] - t[10]);
         tot += (double)(t[7] - t[0]);
         lo = std::min(lo, t[0]); hi = std::max(hi, t[7]);
         sub[4] += (double)(t[7] - t[6]);
     }
+    if (!cnt) { printf("   F(4,3) timeline: no stamped workgroups\n"); return; }
+    const unsigned nall = nwg;
+    nwg = cnt;   // (means over the stamped workgroups)
     printf("   F(4,3) timeline over %u workgroups (us, 100 MHz clock): total %.2f per workgroup; kernel span %.1f = %.2f per workgroup slot of 256 CUs\n",
-           nwg, tot / nwg / 100.0, (double)(hi - lo) / 100.0, (double)(hi - lo) / 100.0 / (nwg / 256.0));
+           nwg, tot / nwg / 100.0, (double)(hi - lo) / 100.0, (double)(hi - lo) / 100.0 / (nall / 256.0));
     for (int i = 0; i < 6; ++i) printf("      %-24s %7.2f\n", nm[i], sum[i] / nwg / 100.0);
     printf("      epilogue half 0 = residual requests + first barrier %.2f | accumulators -> LDS + barrier %.2f | transform, bias, residual, stores issued %.2f | statistics (per-wave part) %.2f; cross-wave sums + atomics of both halves %.2f\n",
            sub[0] / nwg / 100.0, sub[1] / nwg / 100.0, sub[2] / nwg / 100.0, sub[3] / nwg / 100.0, sub[4] / nwg / 100.0);

@@ -24,7 +24,7 @@ constexpr int CI_WCH = 27 * CI_KC * 4;         // weight floats per chunk: [tap]
 // read, all lanes the same address) feeds two FMA triplets, which keeps the LDS pipe below the VALU time.
 __global__ __launch_bounds__(CI_NTHR) void conv_img_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int T,
-                                                       int H, int W, int C, int nchunk) {
+                                                       int H, int W, int C, int nchunk, long obs) {
     __shared__ __attribute__((aligned(16))) float in_lds[CI_NPOS * CI_LS];
     __shared__ __attribute__((aligned(16))) float w_lds[CI_WCH];
     __shared__ int gpos[CI_NPOS];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(CI_NTHR) void conv_img_kernel(const float* __restri
     }
     const int t = t0 + it, h = h0 + ih, w = w0 + iw;
     const long HWo = (long)H * W;
-    float* o = out + ((long)(b * T + t) * 3) * HWo + (long)h * W + w;
+    float* o = out + (long)b * obs + ((long)t * 3) * HWo + (long)h * W + w;   // obs: floats between the samples of `out`
     const float c0_ = bias[0], c1_ = bias[1], c2_ = bias[2];
     o[0] = tanhf(a0 + c0_); o[HWo] = tanhf(a1 + c1_); o[2 * HWo] = tanhf(a2 + c2_);
     o[4] = tanhf(b0 + c0_); o[HWo + 4] = tanhf(b1 + c1_); o[2 * HWo + 4] = tanhf(b2 + c2_);
@@ -128,12 +128,12 @@ int ConvImgWeights::pack(const float* w_src, const float* bias_src, int cin) {
 
 bool conv_img_supported(int T, int H, int W, int C) { return T % CI_TT == 0 && H % CI_TH == 0 && W % CI_TW == 0 && C % 4 == 0; }
 
-int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st) {
+int conv_img_forward(const ConvImgWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st, long out_bstride) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv_img: weights not packed");
     I2V_REQUIRE(conv_img_supported(T, H, W, wts.Cin), I2V_E_INVALID, "conv_img: unsupported geometry");
     const long nblk = (long)B * (T / CI_TT) * (H / CI_TH) * (W / CI_TW);
     hipLaunchKernelGGL(conv_img_kernel, dim3((unsigned)nblk), dim3(CI_NTHR), 0, st, in, wts.w.as<float>(), wts.bias.as<float>(), out,
-                       B, T, H, W, wts.Cin, wts.nchunk);
+                       B, T, H, W, wts.Cin, wts.nchunk, out_bstride ? out_bstride : (long)T * 3 * H * W);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -161,7 +161,7 @@ constexpr int CM_LD = CM_NB * 32;                    // 352 columns per plane ro
 template <int KS>   // KS = Cin / 16 k-steps
 __global__ __launch_bounds__(256) void conv_img_mfma_kernel(const float* __restrict__ in, const ci_half8* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ out, int B, int T,
-                                                            int H, int W, int* __restrict__ range_flag) {
+                                                            int H, int W, int* __restrict__ range_flag, long obs) {
     __shared__ float Y[32 * CM_LD];
     bool bad = false;   // an activation left the fp16 range of its hi part (sticky flag like every other hl16 producer)
     constexpr int C = 16 * KS;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_img_mfma_kernel(const float* __restr
         __syncthreads();   // Y is overwritten by the next temporal tap
     }
     const size_t HWo = (size_t)H * W;
-    float* o = out + (((size_t)b * T + t) * 3) * HWo + (size_t)(h0 + oh) * W + w0 + ow;
+    float* o = out + (size_t)b * (size_t)obs + ((size_t)t * 3) * HWo + (size_t)(h0 + oh) * W + w0 + ow;   // obs: floats between the samples of `out`
     o[0] = tanhf(o0 + bias[0]); o[HWo] = tanhf(o1 + bias[1]); o[2 * HWo] = tanhf(o2 + bias[2]);
     if (bad && range_flag) atomicOr(range_flag, 1);
 }
@@ -275,18 +275,19 @@ bool conv_img_mfma_supported(int T, int H, int W, int C) {
 }
 
 int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float* out, int B, int T, int H, int W, hipStream_t st,
-                          int* range_flag) {
+                          int* range_flag, long out_bstride) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv_img (MFMA): weights not packed");
     I2V_REQUIRE(conv_img_mfma_supported(T, H, W, wts.Cin), I2V_E_INVALID, "conv_img (MFMA): unsupported geometry");
     const long nblk = (long)B * T * (H / CM_TH) * (W / CM_TW);
     I2V_REQUIRE(nblk < (1L << 31), I2V_E_INVALID, "conv_img (MFMA): %ld workgroups", nblk);
     const dim3 grid((unsigned)nblk), block(256);
     const ci_half8* wp = wts.w.as<ci_half8>();
+    const long obs = out_bstride ? out_bstride : (long)T * 3 * H * W;
     switch (wts.Cin / 16) {
-        case 1: hipLaunchKernelGGL(conv_img_mfma_kernel<1>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag); break;
-        case 2: hipLaunchKernelGGL(conv_img_mfma_kernel<2>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag); break;
-        case 3: hipLaunchKernelGGL(conv_img_mfma_kernel<3>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag); break;
-        default: hipLaunchKernelGGL(conv_img_mfma_kernel<4>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag); break;
+        case 1: hipLaunchKernelGGL(conv_img_mfma_kernel<1>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs); break;
+        case 2: hipLaunchKernelGGL(conv_img_mfma_kernel<2>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs); break;
+        case 3: hipLaunchKernelGGL(conv_img_mfma_kernel<3>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs); break;
+        default: hipLaunchKernelGGL(conv_img_mfma_kernel<4>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs); break;
     }
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;

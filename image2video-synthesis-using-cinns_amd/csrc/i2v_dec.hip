@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void modulate_wino4_kernel(const float* __rest
 // zero padding = skipped taps.  Consecutive lanes = consecutive w: every load and store is coalesced.
 // out: frames [B][T][3][H][W].
 __global__ __launch_bounds__(256) void conv_img_gather_kernel(const float* __restrict__ y, const float* __restrict__ bias,
-                                                              float* __restrict__ out, long total, int T, int H, int W) {
+                                                              float* __restrict__ out, long total, int T, int H, int W, long obs) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int w = (int)(i % W);
@@ -547,14 +547,14 @@ __global__ __launch_bounds__(256) void conv_img_gather_kernel(const float* __res
         }
     }
     const long hw = (long)h * W + w, HW = (long)H * W;
-    float* o = out + ((b * T + t) * 3) * HW + hw;
+    float* o = out + b * obs + ((long)t * 3) * HW + hw;
     o[0] = tanhf(s0); o[HW] = tanhf(s1); o[2 * HW] = tanhf(s2);
 }
 
 // F.interpolate(img, size=(h,w), mode='bilinear', align_corners=True) (normalization_layer.py:20), written
 // channels-last with the 3 colour channels zero-padded to 16 (the conv kernel's K chunk).
 __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
-                              int hl16, int* __restrict__ range_flag) {
+                              int hl16, int* __restrict__ range_flag, long ibs) {   // ibs: floats between the samples of `img`
     bool bad = false;
     const long total = (long)B * Ho * Wo;
     const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
@@ -571,7 +571,7 @@ __global__ void resize_kernel(const float* __restrict__ img, float* __restrict__
         float v[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float* pl = img + ((long)b * 3 + c) * Hi * Wi;
+            const float* pl = img + (long)b * ibs + (long)c * Hi * Wi;
             v[c] = lh0 * (lw0 * pl[h0 * Wi + w0] + lw1 * pl[h0 * Wi + w1]) +
                    lh1 * (lw0 * pl[h1 * Wi + w0] + lw1 * pl[h1 * Wi + w1]);
         }
@@ -659,7 +659,9 @@ struct i2v_dec {
     const float* prep_img = nullptr;   // i2v_dec_prepare: the start frames whose SPADE branches are in the workspace's gbs[] ...
     int prep_B = 0;                    // ... their batch, image size and the workspace they live in (consumed by the next matching forward)
     int prep_h = 0, prep_w = 0;
+    long prep_bstride = 0;
     const void* prep_ws = nullptr;
+    long img_bstride = 0;              // floats between the samples of the current call's start frames (0: dense [B][3][H][W])
     int sub = 0;   // samples per sub-batch of the last two levels (env I2V_DEC_SUB; 0: the whole batch per launch)
     int pw16 = 1;  // 1: split-fp16 mode runs the shortcut convs on split-fp16 operands too (env I2V_DEC_PW16=0: exact-fp32 MFMA)
     int device = 0;             // the device the packed weights live on
@@ -890,7 +892,9 @@ bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
 // F(4,3): its bricks hold 512 output positions x 64 or 32 channels (the launcher picks 32-channel workgroups when 64-channel ones
 // would not fill the chip; both give the same bits) -- wherever one SAMPLE gives >= 16 workgroups of 32 channels, i.e. from the
 // 16x16 level on (round 3 stopped at 32x32: g_1 ran F(2,3); measured at B = 64: g_1.conv_0 1.94 -> 1.49 ms, conv_1 1.47 -> 1.13,
-// at B = 8 equal).  The rule depends on the layer only, never on the batch: shards reproduce the full batch bit for bit.
+// at B = 8 equal).  WHETHER a layer runs F(4,3) depends on the layer only; the workgroup width (64 or 32 channels) is chosen by the
+// launcher from batch x bricks against the CU count -- it changes the schedule, not the accumulation order of any output, so
+// shards reproduce the full batch bit for bit (test_f43_tile_width_switch_across_batches crosses the threshold).
 bool w4_fills(const Level& l, int cout) { return (long)l.T * l.H * l.W / 512 * std::max(cout / 32, 1) >= 16; }
 bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l) {
     const bool tdup = l.ut == 2;
@@ -917,7 +921,7 @@ int coef_forward(const double* sums, float* coef, int B, int C, int groups, doub
 int resize_forward(const float* img, float* out, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
     const long tot = (long)B * Ho * Wo;
     hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, out, B, Hi, Wi,
-                       Ho, Wo, 0, static_cast<int*>(nullptr));
+                       Ho, Wo, 0, static_cast<int*>(nullptr), (long)3 * Hi * Wi);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -944,7 +948,7 @@ int spade_branch(i2v_dec* d, Block& b, const Level& l, const float* img, int img
     {
         const long tot = (long)B * l.H * l.W;
         hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, y0,
-                           B, img_h, img_w, l.H, l.W, d->cfg.mma == 1 ? 1 : 0, d->status_dev);
+                           B, img_h, img_w, l.H, l.W, d->cfg.mma == 1 ? 1 : 0, d->status_dev, d->img_bstride ? d->img_bstride : (long)3 * img_h * img_w);
         I2V_HIP_CHECK(hipGetLastError());
     }
     if (d->cfg.mma == 1 && b.sp_gb_w4.w.p && w.y1v) {
@@ -1392,11 +1396,31 @@ int i2v_dec_get_layer_profile(i2v_dec* d, int32_t layer, char* name, int32_t nam
 
 int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, const float* motion, float* out,
                     void* workspace, size_t workspace_bytes, int32_t batch, void* stream) {
+    return i2v_dec_forward_strided(d, img, img_h, img_w, 0, motion, out, 0, workspace, workspace_bytes, batch, stream);
+}
+
+int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, int64_t img_bstride, const float* motion, float* out,
+                            int64_t out_bstride, void* workspace, size_t workspace_bytes, int32_t batch, void* stream) {
+    // One prepare serves at most the NEXT forward on the handle: whatever happens below (range error of the previous call, bad
+    // argument, workspace too small), a prepared set of SPADE maps must never survive into a later call, whose start frames can
+    // sit at the same address (caching allocators, buffers refilled in place).
+    const float* prep_img = d ? d->prep_img : nullptr;
+    if (d) d->prep_img = nullptr;
     I2V_REQUIRE(d && d->loaded, I2V_E_STATE, "i2v_dec_forward: weights not loaded");
     if (int rc0 = check_entry(d, "i2v_dec_forward")) return rc0;
     I2V_REQUIRE(img && motion && out && workspace && batch > 0 && img_h > 0 && img_w > 0, I2V_E_INVALID,
                 "i2v_dec_forward: null argument or bad size");
     const int B = batch;
+    {
+        const Level& lo = d->lvl[5];
+        const int64_t img_dense = (int64_t)3 * img_h * img_w, out_dense = (int64_t)lo.T * 3 * lo.H * lo.W;
+        I2V_REQUIRE((img_bstride == 0 || img_bstride >= img_dense) && (out_bstride == 0 || out_bstride >= out_dense), I2V_E_INVALID,
+                    "i2v_dec_forward_strided: sample strides %lld / %lld below the dense %lld / %lld", (long long)img_bstride,
+                    (long long)out_bstride, (long long)img_dense, (long long)out_dense);
+        if (img_bstride == 0) img_bstride = img_dense;
+        if (out_bstride == 0) out_bstride = out_dense;
+        d->img_bstride = img_bstride;
+    }
     const DecWs L = dec_ws(d, B);
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_dec_forward: workspace %zu < required %zu", workspace_bytes,
                 L.total);
@@ -1417,8 +1441,8 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     bool x_stats_ready = false;
     double* sums3 = reinterpret_cast<double*>(ws + L.sums3);
     // SPADE branches computed ahead by i2v_dec_prepare for exactly these start frames (same pointer, batch, size, workspace)?
-    const bool prepared = d->prep_img == img && d->prep_B == B && d->prep_h == img_h && d->prep_w == img_w && d->prep_ws == workspace;
-    d->prep_img = nullptr;   // consumed (or stale): one prepare serves one forward
+    const bool prepared = prep_img == img && d->prep_B == B && d->prep_h == img_h && d->prep_w == img_w && d->prep_ws == workspace &&
+                          d->prep_bstride == img_bstride;
     for (int k = 0; k < 6; ++k) {
         const Block& b = d->blk[k];
         const Level& l = d->lvl[k];
@@ -1438,7 +1462,7 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
                            prepared ? F(L.gbs[k]) + (size_t)s0 * l.H * l.W * 2 * b.n_in : nullptr};
             bool ready = x_stats_ready;
             if ((rc = block_forward(d, k, d->blk[k], l, x + (size_t)s0 * Pl * b.n_in, xn + (size_t)s0 * P * b.n_out,
-                                    img + (size_t)s0 * 3 * img_h * img_w, img_h, img_w, zl + (size_t)s0 * d->Nz, d->Nz, n, bufs, ready, k == 5, st)))
+                                    img + (size_t)s0 * (size_t)img_bstride, img_h, img_w, zl + (size_t)s0 * d->Nz, d->Nz, n, bufs, ready, k == 5, st)))
                 return rc;
             ready_out = ready;
         }
@@ -1447,16 +1471,16 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     }
     {
         const Level& l = d->lvl[5];
-        if (d->conv_img_m.w.p) rc = conv_img_mfma_forward(d->conv_img_m, x, out, B, l.T, l.H, l.W, st, d->status_dev);
+        if (d->conv_img_m.w.p) rc = conv_img_mfma_forward(d->conv_img_m, x, out, B, l.T, l.H, l.W, st, d->status_dev, out_bstride);
         else if (d->conv_img16.w.p) {
             const long P = (long)l.T * l.H * l.W, tot = (long)B * P;
             I2V_REQUIRE((tot + 255) / 256 < (1L << 31), I2V_E_INVALID, "conv_img: %ld positions", tot);
             if ((rc = pointwise16_forward(d->conv_img16, x, a, nullptr, tot, P, EPI_NONE, st, nullptr, d->status_dev, true))) return rc;
             hipLaunchKernelGGL(conv_img_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a,
-                               d->conv_img_bias.as<float>(), out, tot, l.T, l.H, l.W);
+                               d->conv_img_bias.as<float>(), out, tot, l.T, l.H, l.W, (long)out_bstride);
             I2V_HIP_CHECK(hipGetLastError());
-        } else if (conv_img_supported(l.T, l.H, l.W, d->nf)) rc = conv_img_forward(d->conv_img_v, x, out, B, l.T, l.H, l.W, st);
-        else rc = conv_forward(d->conv_img, x, d->nf, out, nullptr, 1, 1, B, l.T, l.H, l.W, EPI_FRAMES, st);
+        } else if (conv_img_supported(l.T, l.H, l.W, d->nf)) rc = conv_img_forward(d->conv_img_v, x, out, B, l.T, l.H, l.W, st, out_bstride);
+        else rc = conv_forward(d->conv_img, x, d->nf, out, nullptr, 1, 1, B, l.T, l.H, l.W, EPI_FRAMES, st, nullptr, 1, 1, out_bstride);
         if (rc) return rc;
     }
     if (d->cfg.mma == 1) {
@@ -1479,10 +1503,18 @@ int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     d->prep_img = nullptr;
+    d->img_bstride = 0;
     for (int k = 0; k < 6; ++k)
         if (int rc = spade_branch(d, d->blk[k], d->lvl[k], img, img_h, img_w, B, F(L.py0), F(L.py1), L.has_y1v ? F(L.py1v) : nullptr, F(L.gbs[k]), st))
             return rc;
     d->prep_img = img; d->prep_B = B; d->prep_h = img_h; d->prep_w = img_w; d->prep_ws = workspace;
+    d->prep_bstride = (long)3 * img_h * img_w;
+    return I2V_OK;
+}
+
+int i2v_dec_prepare_cancel(i2v_dec* d) {
+    I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_prepare_cancel: null handle");
+    d->prep_img = nullptr;
     return I2V_OK;
 }
 
@@ -1715,7 +1747,7 @@ int i2v_gblock_norm(i2v_gblock* g, int32_t part, const float* x, const float* co
         if ((rc = run_coef(sums, coef, B, C, b.groups_spade, (double)P, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
         const long tot = (long)B * h * w;
         hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, cond, F(L.y0), B,
-                           img_h, img_w, h, w, g->ctx.cfg.mma == 1 ? 1 : 0, g->ctx.status_dev);
+                           img_h, img_w, h, w, g->ctx.cfg.mma == 1 ? 1 : 0, g->ctx.status_dev, (long)3 * img_h * img_w);
         I2V_HIP_CHECK(hipGetLastError());
         if (g->ctx.cfg.mma == 1) {
             if ((rc = conv16_forward(b.sp_conv16, F(L.y0), reinterpret_cast<float*>(F(L.y1)), nullptr, 1, 1, B, 1, h, w,

@@ -64,11 +64,7 @@ class Model(torch.nn.Module):
     @torch.no_grad()
     def decode(self, x_0, z):
         """Second half (get_model.py:68-73): decoder pass(es), autoregressive on the last frame with the same z."""
-        seq = self.decoder(x_0, z)
-        while seq.shape[1] < self.vid_length:
-            seq1 = self.decoder(seq[:, -1].contiguous(), z)
-            seq = torch.cat((seq, seq1), dim=1)
-        return seq
+        return self.decoder.decode_sequence(x_0, z, self.vid_length)   # the same loop, decoded in place into one buffer
 
     @torch.no_grad()
     def synthesize(self, x_0, cond=None, residual=None, embed=None):
@@ -77,7 +73,8 @@ class Model(torch.nn.Module):
         most of the chip idle) runs on a high-priority side stream while the current stream already computes the decoder's
         SPADE branches, which depend on the start frame only (``overlap = False`` restores the strictly serial order; the
         frames are the same bits either way)."""
-        if not (self.overlap and x_0.is_cuda):
+        # (single-stream semantics are kept while the caller captures a graph: a side stream cannot be forked inside a capture here)
+        if not (self.overlap and x_0.is_cuda) or torch.cuda.is_current_stream_capturing():
             return self.decode(x_0, self.sample_latent(x_0, cond, residual, embed))
         import i2v_pipeline
         if self._prefetch is None or self._prefetch.stream.device != x_0.device:
@@ -116,8 +113,4 @@ class Model(torch.nn.Module):
         res, _ = self.flow(z, [seq_query[:, 0].contiguous()], embed=embed_query)       # :90 cINN forward
         res = res.view(z.size(0), -1).repeat(x_0.size(0), 1).contiguous()
         z_ref = self.flow(res, [x_0], reverse=True, embed=embed).view(x_0.size(0), -1)  # :93
-        seq_gen = self.decoder(x_0, z_ref)                                             # :96
-        while seq_gen.shape[1] < self.vid_length:                                      # :99-101
-            seq1 = self.decoder(seq_gen[:, -1].contiguous(), z_ref)
-            seq_gen = torch.cat((seq_gen, seq1), dim=1)
-        return seq_gen
+        return self.decoder.decode_sequence(x_0, z_ref, self.vid_length)               # :96-101

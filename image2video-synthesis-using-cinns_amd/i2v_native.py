@@ -5,6 +5,7 @@ PyTorch-ROCm tensors are used only as containers: every call passes raw device p
 library is missing, or a tensor does not live on a GPU, the call raises.
 """
 import ctypes
+import weakref
 import functools
 import os
 import subprocess
@@ -96,7 +97,10 @@ SYMBOLS = {
     "i2v_dec_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32, c_int32]),
     "i2v_dec_flops_per_sample": (c_double, [c_void_p, c_int32, c_int32]),
     "i2v_dec_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "i2v_dec_forward_strided": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                                          c_int32, c_void_p]),
     "i2v_dec_prepare": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_int32, c_void_p]),
+    "i2v_dec_prepare_cancel": (c_int32, [c_void_p]),
     "i2v_dec_set_profile": (c_int32, [c_void_p, c_int32]),
     "i2v_dec_debug_tap": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t]),
     "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
@@ -364,21 +368,61 @@ class NativeDecoder(_Handle):
             raise I2VError(f"decoder: expected img [B,3,H,W], got {tuple(img.shape)}")
         nbytes = lib().i2v_dec_workspace_bytes(self._h, B, img.shape[2], img.shape[3])
         ws = self._ws.get(nbytes, img.device)
+        self._prep = None
+        if not img.is_contiguous():
+            raise I2VError("decoder.prepare: the start frames must be contiguous")
         _check(lib().i2v_dec_prepare(self._h, img.data_ptr(), img.shape[2], img.shape[3], ws.data_ptr(), ws.numel(), B, _stream()),
                "i2v_dec_prepare")
+        # the C side recognises the prepared frames by ADDRESS; a caching allocator hands the same address to the next same-size
+        # tensor and a buffer refilled in place keeps it, so the binding also remembers WHICH tensor (weak) and its version
+        self._prep = (weakref.ref(img), img._version)
+
+    @staticmethod
+    def _sample_strided(t, inner_shape):
+        """(data_ptr, sample stride in floats) of a float32 tensor [B, *inner_shape] whose samples are contiguous blocks."""
+        if t.dtype != torch.float32 or tuple(t.shape[1:]) != tuple(inner_shape):
+            return None
+        inner = 1
+        for n, s in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+            if n != 1 and s != inner:
+                return None
+            inner *= n
+        bs = t.stride(0) if t.shape[0] > 1 else inner
+        return (t.data_ptr(), bs) if bs >= inner else None
 
     @_on_device
-    def forward(self, img, motion):
-        _require_gpu(img, motion)
+    def forward(self, img, motion, out=None):
+        """i2v_dec_forward_strided.  ``img``: [B,3,H,W] whose samples are contiguous [3,H,W] blocks (any sample stride: e.g. the view
+        ``seq[:, -1]`` of a [B,T,3,H,W] buffer).  ``out``: optional float32 view [B,T,3,H,W] with contiguous [T,3,H,W] sample blocks
+        (e.g. ``buf[:, 16:32]`` of a [B,32,3,H,W] buffer) that receives the frames; a dense tensor is allocated otherwise."""
+        for t in (img, motion):
+            if not t.is_cuda:
+                _require_gpu(t)   # raises: no CPU fallback
+            if t.dtype != torch.float32:
+                raise I2VError(f"expected float32 tensors, got {t.dtype}")
+        prep, self._prep = getattr(self, "_prep", None), None
+        if prep is not None and (prep[0]() is not img or prep[1] != img._version):
+            _check(lib().i2v_dec_prepare_cancel(self._h), "i2v_dec_prepare_cancel")   # another tensor, or this one was written since
         B = img.shape[0]
         if img.dim() != 4 or img.shape[1] != 3 or motion.shape != (B, self.z_dim):
             raise I2VError(f"decoder: expected img [B,3,H,W] and motion [B,{self.z_dim}], got {tuple(img.shape)}, {tuple(motion.shape)}")
+        iv = self._sample_strided(img, img.shape[1:])
+        if iv is None:
+            img = img.contiguous()
+            iv = (img.data_ptr(), 3 * img.shape[2] * img.shape[3])
+        if not motion.is_contiguous():
+            motion = motion.contiguous()
         nbytes = lib().i2v_dec_workspace_bytes(self._h, B, img.shape[2], img.shape[3])
         ws = self._ws.get(nbytes, img.device)
         T, H, W = self.out_shape
-        out = torch.empty(B, T, 3, H, W, dtype=torch.float32, device=img.device)
-        _check(lib().i2v_dec_forward(self._h, img.data_ptr(), img.shape[2], img.shape[3], motion.data_ptr(),
-                                     out.data_ptr(), ws.data_ptr(), ws.numel(), B, _stream()), "i2v_dec_forward")
+        if out is None:
+            out = torch.empty(B, T, 3, H, W, dtype=torch.float32, device=img.device)
+        ov = self._sample_strided(out, (T, 3, H, W)) if (out.is_cuda and out.device == img.device and out.shape[0] == B) else None
+        if ov is None:
+            raise I2VError(f"decoder: out must be a float32 [B={B},{T},3,{H},{W}] view on {img.device} with contiguous sample blocks, "
+                           f"got {tuple(out.shape)} strides {out.stride()}")
+        _check(lib().i2v_dec_forward_strided(self._h, iv[0], img.shape[2], img.shape[3], iv[1], motion.data_ptr(), ov[0], ov[1],
+                                             ws.data_ptr(), ws.numel(), B, _stream()), "i2v_dec_forward_strided")
         return out
 
 

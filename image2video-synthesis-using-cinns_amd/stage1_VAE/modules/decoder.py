@@ -72,8 +72,25 @@ class Generator(NativeBacked):
         h.load(self.state_dict())
         return h
 
-    def forward(self, img, motion):
-        return self.native().forward(img.contiguous(), motion.contiguous())
+    def forward(self, img, motion, out=None):
+        """decoder.py:97-120.  ``out`` (not a reference argument): a float32 view [B,16,3,H,W] with contiguous sample blocks to
+        decode into; ``img`` may be a sample-strided view such as ``seq[:, -1]`` -- together they let the autoregressive loop of
+        ``Model.forward`` (get_model.py:68-73) run without ``torch.cat`` / ``.contiguous()`` copies."""
+        return self.native().forward(img, motion, out=out)
+
+    def decode_sequence(self, x_0, z, vid_length):
+        """get_model.py:68-73 -- ``seq = G(x_0, z); while T < vid_length: seq = cat(seq, G(seq[:, -1], z))`` -- into ONE
+        pre-allocated [B, 16*ceil(vid_length/16), 3, H, W] buffer: pass k writes frames [16k, 16k+16) in place and pass k+1 reads
+        its start frames from the strided view seq[:, 16k+15] (i2v_dec_forward_strided).  Same kernels, same bits as the loop."""
+        T, H, W = self.native().out_shape
+        n = max(1, -(-int(vid_length) // T))
+        if n == 1:
+            return self.forward(x_0, z)
+        seq = torch.empty(x_0.shape[0], n * T, 3, H, W, dtype=torch.float32, device=x_0.device)
+        self.forward(x_0, z, out=seq[:, :T])
+        for k in range(1, n):
+            self.forward(seq[:, k * T - 1], z, out=seq[:, k * T:(k + 1) * T])
+        return seq
 
     def prepare(self, img):
         """Not a reference method: enqueue the SPADE branches of all blocks for the start frames ``img`` (they do not depend on

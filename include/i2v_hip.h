@@ -157,14 +157,29 @@ double i2v_dec_flops_per_sample(const i2v_dec* d, int32_t img_h, int32_t img_w);
  * img [B,3,img_h,img_w] (NCHW, [-1,1]), motion [B,z_dim] -> out [B,T,3,H,W] contiguous. */
 int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, const float* motion,
                     float* out, void* workspace, size_t workspace_bytes, int32_t batch, void* stream);
+/* The same with explicit SAMPLE strides (in floats; 0 = dense) for the start frames and the output: img sample b starts at
+ * img + b * img_bstride (its [3,img_h,img_w] planes stay contiguous), out sample b at out + b * out_bstride (its [T,3,H,W]
+ * block stays contiguous).  This is what the autoregressive loop of Model.forward (get_model.py:68-73) needs to run without
+ * torch.cat / .contiguous() copies: pass k decodes straight into frames [16k, 16k+16) of ONE pre-allocated
+ * [B, vid_length, 3, H, W] buffer (out = buf + 16k * 3*H*W, out_bstride = vid_length * 3*H*W) and pass k+1 reads its start
+ * frames seq[:, -1] from the same buffer (img = buf + (16k + 15) * 3*H*W, img_bstride = vid_length * 3*H*W). */
+int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, int64_t img_bstride,
+                            const float* motion, float* out, int64_t out_bstride, void* workspace, size_t workspace_bytes,
+                            int32_t batch, void* stream);
 /* Optional first half of Generator.forward: the SPADE conditioning branches of all six blocks (normalization_layer.py:20-23:
  * F.interpolate(start frame) -> Conv2d(3,128) + lrelu -> conv_gamma | conv_beta).  They depend on the start frame only, not on
  * the motion latent, so a caller can enqueue them on a SIDE stream while the cINN pass that produces the latent runs
  * (get_model.py:59-66), and then call i2v_dec_forward with the SAME img pointer, size, batch and workspace (after making its
  * stream wait for the side stream): that forward skips the branches and reads the prepared gamma | beta maps from the
- * workspace.  One prepare serves one forward; any other forward in between discards it.  Same kernels, same bits. */
+ * workspace.  One prepare serves AT MOST the next forward call on the handle: every i2v_dec_forward* entry -- matching or not,
+ * successful or not (I2V_E_RANGE of the previous call, bad arguments, workspace too small) -- consumes or discards it before
+ * anything else.  The identity test is by address: the CONTENTS of img must not change between the prepare and its forward;
+ * a caller that refills the buffer in place calls i2v_dec_prepare_cancel (the Python binding does, keyed on the tensor's
+ * version counter).  Same kernels, same bits. */
 int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, void* workspace, size_t workspace_bytes,
                     int32_t batch, void* stream);
+/* Drops a pending prepare (no-op without one). */
+int i2v_dec_prepare_cancel(i2v_dec* d);
 /* Roofline instrumentation.  With profiling on, every 3x3x3 Conv3d launch (the dominant kernel) is bracketed by HIP
  * events recorded on the launch stream -- no synchronisation is added to the forward.  After the caller has
  * synchronised, i2v_dec_get_profile resolves the pending pairs and returns the totals since set_profile(d, 1):
@@ -187,8 +202,10 @@ int i2v_dec_get_layer_profile(i2v_dec* d, int32_t layer, char* name, int32_t nam
  * the flag (bit 0 = overflow seen) and optionally clears it; use mma = 0 (exact fp32 MFMA) for such checkpoints.
  * Bit 1 (value 2) = UNDERFLOW warning: the format has an absolute error floor of ~2^-25 (the lo part is an fp16 subnormal
  * below |x| = 2^-3), so a conv whose whole operand tensor lies below 2^-10 no longer holds the 1e-4 gate (measured table:
- * INTEGRATION.md §3).  Every operand writer publishes the largest |activation| it wrote; a non-zero tensor whose maximum is
- * below 2^-10 sets bit 1.  It is reported by i2v_dec_status only (sticky until reset) and does NOT make the next call fail:
+ * INTEGRATION.md §3).  The two operand writers of every block (the inputs of conv_0 and conv_1: 12 tensors per forward) publish
+ * the largest |activation| they wrote; a non-zero tensor whose maximum is below 2^-10 sets bit 1.  Coverage, as built: the
+ * maximum is per operand TENSOR over the whole batch (one normal sample hides an underflowing one in the same call), and SPADE's
+ * internal 128-channel operand, the EPI_HL16 conv epilogue and conv_img's input are not watched (they carry bit 0 only).  It is reported by i2v_dec_status only (sticky until reset) and does NOT make the next call fail:
  * the output is finite and merely less precise; mma = 0 is exact there too. */
 int i2v_dec_status(i2v_dec* d, int32_t* flags, int32_t reset, void* stream);
 

@@ -316,6 +316,19 @@ def test_f43_structure_switches_keep_the_bits(golden, monkeypatch):
         assert torch.equal(big[:3], ref) and torch.equal(big[15:], ref), pipe
 
 
+def test_f43_tile_width_switch_across_batches():
+    """The F(4,3) launcher narrows its workgroups to 32 channels when 64-channel ones would leave CUs idle -- a decision that
+    depends on batch x bricks (round-4 advisor finding: only tested through I2V_W4_BN at one batch).  nf = 8 BAIR: g_1's convs have 4
+    workgroups per sample, so B = 1 / 8 run 32-channel workgroups and B = 64 / 96 run 64-channel ones: rows must equal shards."""
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    x0, z, _ = synth.bench_inputs(96, g["img"].shape[-1], 64)
+    x0, z = x0.cuda(), z.cuda()
+    big = gen(x0, z)
+    for lo, hi in ((0, 1), (40, 48), (95, 96), (0, 64)):
+        assert torch.equal(gen(x0[lo:hi].contiguous(), z[lo:hi].contiguous()), big[lo:hi]), (lo, hi)
+
+
 def test_decoder_prepare_equals_plain_forward():
     """i2v_dec_prepare (Generator.prepare): the SPADE branches of all blocks computed ahead of the forward -- the next forward
     with the same start-frame tensor must give the same bits as a plain one; a forward with ANOTHER tensor in between must
@@ -338,6 +351,68 @@ def test_decoder_prepare_equals_plain_forward():
     torch.cuda.current_stream().wait_stream(side)
     assert torch.equal(gen(img, z), ref)
     assert rel_l2(ref.cpu(), g["out"]) < TOL
+
+
+def test_decoder_prepare_never_outlives_its_start_frames():
+    """A prepare must not leak into a later call whose start frames sit at the SAME address (round-4 advisor finding): (1) the
+    buffer is refilled in place between prepare and forward -- the binding sees the tensor's version counter and cancels;
+    (2) a forward that FAILS in between (workspace too small, straight through the C ABI) consumes the prepare, so that a later
+    forward on the same pointer -- refilled behind the version counter's back -- recomputes its SPADE maps."""
+    import ctypes
+    import i2v_native
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    img, z = cu(g["img"]), cu(g["z"])
+    other = (img * 0.5 - 0.1).contiguous()
+    ref, ref_other = gen(img, z), gen(other, z)
+    assert not torch.equal(ref, ref_other)
+    buf = img.clone()
+    gen.prepare(buf)
+    buf.copy_(other)                                      # in-place refill: same address, new version
+    assert torch.equal(gen(buf, z), ref_other)
+    # (2) same address, contents changed WITHOUT a version bump; the failing call in between must have dropped the prepare
+    buf.copy_(img)
+    gen.prepare(buf)
+    nat = gen.native()
+    out = torch.empty_like(ref)
+    rc = i2v_native.lib().i2v_dec_forward(nat._h, buf.data_ptr(), buf.shape[2], buf.shape[3], z.data_ptr(), out.data_ptr(),
+                                          buf.data_ptr(), 16, buf.shape[0], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0                                        # I2V_E_WORKSPACE
+    buf.data.copy_(other)
+    torch.cuda.synchronize()
+    assert torch.equal(gen(buf, z), ref_other)
+    # and the explicit cancel
+    buf.data.copy_(img)
+    gen.prepare(buf)
+    assert i2v_native.lib().i2v_dec_prepare_cancel(nat._h) == 0
+    buf.data.copy_(other)
+    assert torch.equal(gen(buf, z), ref_other)
+
+
+def test_decoder_strided_in_place_sequence():
+    """i2v_dec_forward_strided / Generator.decode_sequence: the autoregressive loop of get_model.py:68-73 decoded in place into ONE
+    [B, 32, 3, H, W] buffer (pass 2 reads its start frames from the strided view seq[:, 15] and writes frames 16..31) must give
+    the bits of the reference-shaped loop (torch.cat of dense tensors); prepared SPADE maps work with it."""
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    img, z = synth.bench_inputs(3, g["img"].shape[-1], 64)[:2]
+    img, z = img.cuda(), z.cuda()
+    seq = gen(img, z)
+    ref = torch.cat((seq, gen(seq[:, -1].contiguous(), z)), dim=1)
+    ref = torch.cat((ref, gen(ref[:, -1].contiguous(), z)), dim=1)
+    got = gen.decode_sequence(img, z, 48)
+    assert got.shape == ref.shape == (3, 48, 3, 64, 64) and got.is_contiguous()
+    assert torch.equal(got, ref)
+    gen.prepare(img)
+    assert torch.equal(gen.decode_sequence(img, z, 40), ref)      # 40 -> three passes as well (get_model.py:71: while T < vid_length)
+    assert torch.equal(gen.decode_sequence(img, z, 16), seq)
+    # a sample-strided start-frame view and an output view in the middle of a larger buffer
+    big = torch.full((3, 5, 16, 3, 64, 64), 7.0, device="cuda")
+    out = gen(ref[:, 15], z, out=big[:, 2])
+    assert out.data_ptr() == big[:, 2].data_ptr() and torch.equal(big[:, 2], ref[:, 16:32])
+    assert bool((big[:, 1] == 7.0).all()) and bool((big[:, 3] == 7.0).all())
+    with pytest.raises(Exception):
+        gen(img, z, out=big[:, :, 0])                              # sample blocks not contiguous
 
 
 def _write_checkpoints(tmp_path, meta, with_embedder=False, with_encoder=False):
@@ -710,6 +785,7 @@ def test_model_128_t32_vs_golden():
     seq = gen(x0, z)
     while seq.shape[1] < 32:
         seq = torch.cat((seq, gen(seq[:, -1].contiguous(), z)), dim=1)
+    assert torch.equal(gen.decode_sequence(x0, z, 32), seq)       # the in-place form Model.decode uses: same bits
     assert seq.shape == (2, 32, 3, 128, 128) and bool(torch.isfinite(seq).all())
     assert rel_l2(seq[:, :16, :, ::4, ::4].cpu(), g["out_s4"][:, :16]) < TOL
     assert rel_l2(seq[:, 16:, :, ::4, ::4].cpu(), g["out_s4"][:, 16:]) < TOL   # second (autoregressive) pass
@@ -838,10 +914,14 @@ def test_flow_fp16_operand_mode(emb):
     assert rel_l2(z32, zr32) < TOL
     e_emul, e_fp32 = rel_l2(z16, zr16), rel_l2(z16, zr32)
     print(f"fp16-operand cINN (E = {emb}): z rel-L2 vs emulated oracle {e_emul:.2e}, vs fp32 oracle {e_fp32:.2e}")
-    assert e_emul < 5e-4 and e_fp32 < 2e-2, (e_emul, e_fp32)   # (a rounding flip of one activation costs 2^-11 on that element)
+    # measured on MI355X: 2.2e-4 / 3.0e-4 (both E); bounds = ~2.5-3x that (a rounding flip of one activation costs 2^-11 on that element)
+    assert e_emul < 6e-4 and e_fp32 < 9e-4, (e_emul, e_fp32)
     assert not torch.equal(z16, z32)                      # the mode really changes the arithmetic
     zt16, ld16 = flows[1](residual.cuda(), embed.cuda())
-    assert rel_l2(zt16.view(24, -1).cpu(), ztr16.reshape(24, -1)) < 5e-4 and np.allclose(ld16.cpu(), ldr16, rtol=1e-3, atol=1e-3)
+    e_zt = rel_l2(zt16.view(24, -1).cpu(), ztr16.reshape(24, -1))
+    e_ld = float(np.max(np.abs(ld16.cpu().numpy().reshape(-1) - np.asarray(ldr16).reshape(-1)) / (1.0 + np.abs(np.asarray(ldr16).reshape(-1)))))
+    print(f"fp16-operand cINN forward: z~ rel-L2 vs emulated oracle {e_zt:.2e}, log-det max |err| / (1 + |ld|) {e_ld:.2e}")
+    assert e_zt < 6e-4 and e_ld < 1e-3, (e_zt, e_ld)
     # shards equal the full batch bit for bit in this mode too
     zs = flows[1](residual[8:16].cuda().contiguous(), embed[8:16].cuda().contiguous(), reverse=True).view(8, -1).cpu()
     assert torch.equal(zs, z16[8:16])
