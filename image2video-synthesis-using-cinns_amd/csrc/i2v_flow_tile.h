@@ -45,7 +45,7 @@ inline bool flow_tile_geometry_ok(int in_channels, int H, int depth, int E) {
 int flow_tile_pack(FlowTilePack& p, int S, int H, int depth, int E, const float* W0, const float* Wmid, const float* W3T, bool f16 = false);
 
 struct FlowTileWs {
-    size_t x, x2, logdet, pre, hA, hB, P, total;
+    size_t x, x2, logdet, pre, hA, hB, P, P2, total;   // P / P2: partial products of the final Linear, alternating per half-step
 };
 FlowTileWs flow_tile_ws(const FlowTilePack& p, int B);
 

@@ -394,6 +394,213 @@ __global__ __launch_bounds__(512) void flow_tail_tile_kernel(const float* P_, co
     FTL_END(a.seq)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the tail FOLDED into the first hidden layer's launch (2 instead of 3 dependent launches per half-step: 1 + 2 S + 1 = 82
+// launches per pass instead of 122).  Every workgroup of the first hidden Linear(H, H) of half-step k+1 needs ALL of h0 = lrelu(pre +
+// W0x . x_passive) of its net for its sample tiles, and x_passive needs the coupling of half-step k.  Instead of waiting for a launch
+// that computes them once (1.5 us of kernel boundary + 1-2 us from kernel entry to the first requests + the launch's own span, 41
+// times per pass), every workgroup recomputes them for its own sample tiles: sum the 2 x 32 partial tiles of the final Linear (128 KB
+// per sample tile, L2 hits after the first workgroup of the XCD), coupling, log-det, Shuffle / ActNorm / InvLeakyRelu / half swap in
+// LDS, then each wave evaluates the K = 32 first Linear for exactly the KPW row tiles of h0 that are ITS K slice of the hidden
+// layer -- they never leave the registers.  The hidden layer's own weight fragments are requested at kernel entry and travel
+// underneath all of that.  One workgroup per sample-tile group (row tile 0) stores the new state and the log-det.
+// Same operations in the same order as flow_tail_tile_kernel + flow_hid_tile_kernel: the bits do not change (tested).
+template <int KPW, int NS, bool F16>
+__global__ __launch_bounds__(512) void flow_first_tile_kernel(const float* WT_, const float* P_, const float* x_, const float* W0T_,
+                                                              const float* pre_, const float* bias_, int NRT_, int NST_, int flags_,
+                                                              const float* b3_, const FlowIo* io_, float* xo_, float* logdet_,
+                                                              const int* shuf_, const float* an_loc_, const float* an_scale_,
+                                                              float an_logdet_, float* out_, const float* W3P_, float* Pout_, int B_,
+                                                              int seq_) {
+    constexpr int HB = 8 * KPW;       // row tiles per net
+    constexpr int HB2 = HB / 2;
+    const int NRT = NRT_, NST = NST_;
+    const bool io_in = flags_ & 1, ld_init = (flags_ >> 2) & 1, reverse = (flags_ >> 3) & 1, do_lrelu = (flags_ >> 4) & 1,
+               do_swap = (flags_ >> 5) & 1;
+    const int l1 = (flags_ >> 6) & 3;
+    __shared__ v4f red[8][NS][64];
+    __shared__ v4f ps[8][64];
+    __shared__ __attribute__((aligned(16))) float xs[16][68];
+    __shared__ __attribute__((aligned(16))) float xs2[16][68];
+    __shared__ float ld[2][16];
+    __shared__ float anl[64], ans[64];
+    __shared__ int sidx[64];
+    FTL_BEGIN(seq_)
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int net = xcd >> 2;
+    const int sg = slot / (HB / 4), rt = net * HB + (xcd & 3) + 4 * (slot - sg * (HB / 4)), st0 = sg * NS;
+    const bool writer = rt == 0;      // one workgroup per sample-tile group stores the new state and the log-det
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, n = lane & 15;
+    // Request order = the order in which the chain of this launch needs the operands (vector loads return in order, so a wait for an
+    // early request leaves the later ones in flight): block-boundary tables and the final Linear's biases, then per sample tile the
+    // partial tiles and the old state (coupling), the embedding part of the first Linear; behind the first sample tile's requests
+    // the fragments of the first Linear for the KPW row tiles of h0 that ARE this wave's K slice, the hidden layer's weight row
+    // and the epilogue operands -- those travel underneath the whole tail.
+    v4f bs = {0.f, 0.f, 0.f, 0.f}, bt = bs;
+    if (P_ && w < 2) { bs = ld4(b3_ + 16 * w + 4 * q); bt = ld4(b3_ + 32 + 16 * w + 4 * q); }
+    float tab0 = 0.f, tab1 = 1.f;
+    int tabi = 0;
+    if (tid >= 256 && tid < 320) {
+        if (an_loc_) { tab0 = an_loc_[tid - 256]; tab1 = an_scale_[tid - 256]; }
+    } else if (tid >= 320 && tid < 384) {
+        tabi = shuf_ ? shuf_[tid - 320] : tid - 320;
+    }
+    typename WFrag<F16>::T A[KPW];
+    typename WFrag<F16>::T A0[KPW][2] = {};
+    const int es = w >> 1, cb = w & 1;
+    const bool epi = w < 2 * NS;
+    v4f bias4 = {0.f, 0.f, 0.f, 0.f};
+    typename WFrag<F16>::T A3 = {};
+    v4f Bv[NS][KPW];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool live = st0 + s < NST;
+        const int st = live ? st0 + s : NST - 1;
+        // ---- requests of this sample tile: partial tiles of the final Linear (wave = (net, column block, half of the row tiles)),
+        // the old state, the embedding part of the first Linear for this wave's KPW row tiles
+        v4f pp[HB2];
+        if (P_) {
+            const int pnet = w >> 2, pcb = (w >> 1) & 1, half = w & 1;
+            const float* base = P_ + (((size_t)st * NRT + pnet * HB + half * HB2) * 2 + pcb) * 256 + lane * 4;
+#pragma unroll
+            for (int i = 0; i < HB2; ++i) pp[i] = ld4(base + (size_t)i * 512);
+        }
+        v4f xv0 = {0.f, 0.f, 0.f, 0.f};
+        if (tid < 256) {
+            const int nn = tid >> 4, c4 = tid & 15, b = st * 16 + nn;
+            if (io_in) { if (b < B_) xv0 = ld4(io_->xin + (size_t)b * 64 + 4 * c4); }
+            else xv0 = ld4(x_ + (size_t)b * 64 + 4 * c4);
+        }
+        v4f D0[KPW];
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) D0[i] = ld4(pre_ + ((size_t)st * NRT + net * HB + w * KPW + i) * 256 + lane * 4);
+        if (s == 0) {
+            if (l1 == 1) {
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) {
+                    const size_t r0 = (size_t)(net * HB + w * KPW + i) * 2;
+                    A0[i][0] = ldw<F16>(W0T_, r0, lane);
+                    A0[i][1] = ldw<F16>(W0T_, r0 + 1, lane);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) A[i] = ldw<F16>(WT_, (size_t)rt * HB + w * KPW + i, lane);
+            if (epi) {
+                bias4 = ld4(bias_ + rt * 16 + q * 4);
+                if (W3P_) A3 = ldw<F16>(W3P_, (size_t)rt * 2 + cb, lane);
+            }
+            if (tid >= 256 && tid < 320) { anl[tid - 256] = tab0; ans[tid - 256] = tab1; }
+            else if (tid >= 320 && tid < 384) sidx[tid - 320] = tabi;
+        }
+        if (tid < 256) st4(&xs[tid >> 4][4 * (tid & 15)], xv0);
+        if (s == 0) { FTL_STAMP(seq_, 1) FTL_LANDED() FTL_STAMP(seq_, 2) }
+        if (P_) {
+            v4f sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < HB2; ++i) sum += pp[i];
+            ps[w][lane] = sum;
+        }
+        __syncthreads();
+        // ---- affine coupling of the transformed half (flow_blocks.py:91-93 / 103) and its log-det: waves 0, 1 = channel blocks
+        if (P_ && w < 2) {
+            const v4f sv = (bs + ps[w * 2][lane]) + ps[w * 2 + 1][lane];
+            const v4f tv = (bt + ps[4 + w * 2][lane]) + ps[4 + w * 2 + 1][lane];
+            v4f xv = ld4(&xs[n][32 + 16 * w + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[r] = reverse ? (xv[r] - tv[r]) * expf(-sv[r]) : fmaf(xv[r], expf(sv[r]), tv[r]);
+            st4(&xs[n][32 + 16 * w + 4 * q], xv);
+            if (logdet_ && !reverse) {
+                float l = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+                l += __shfl_xor(l, 16);
+                l += __shfl_xor(l, 32);
+                if (q == 0) ld[w][n] = l;
+            }
+        }
+        __syncthreads();
+        // ---- block boundary: Shuffle gather, ActNorm, InvLeakyRelu, half swap (as flow_tail_tile_kernel)
+        {
+            const int nn = tid >> 5, e2 = (tid & 31) * 2, b = st * 16 + nn;
+            float o[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int cp = e2 + e;
+                const int c1 = do_swap ? cp ^ 32 : cp;
+                const int c0 = sidx[c1];
+                float v = xs[nn][c0];
+                if (!reverse) {
+                    if (an_loc_) v = ans[c1] * (v + anl[c1]);
+                    if (do_lrelu) v = v * (v >= 0.f ? 1.0f : 0.9f);
+                } else {
+                    if (do_lrelu) v = v / (v >= 0.f ? 1.0f : 0.9f);
+                    if (an_loc_) v = v / ans[c0] - anl[c0];
+                }
+                o[e] = v;
+            }
+            *reinterpret_cast<float2*>(&xs2[nn][e2]) = make_float2(o[0], o[1]);
+            if (writer && live) {
+                *reinterpret_cast<float2*>(xo_ + (size_t)b * 64 + e2) = make_float2(o[0], o[1]);
+                if (logdet_ && tid < 16) {
+                    const int bb = st * 16 + tid;
+                    float v = ld_init ? 0.f : logdet_[bb];
+                    if (P_) v += ld[0][tid] + ld[1][tid];
+                    if (an_loc_) v += an_logdet_;
+                    logdet_[bb] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- first Linear of this half-step (modules.py:14-17) for the wave's own K slice of the hidden layer: stays in registers
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            v4f D = D0[i];
+            if (l1 == 1) {
+                D = mma16<F16>(A0[i][0], ld4(&xs2[n][4 * q]), D);
+                D = mma16<F16>(A0[i][1], ld4(&xs2[n][16 + 4 * q]), D);
+            }
+            Bv[s][i] = lrelu4(D, 0.01f);
+        }
+        if (NS > 1) __syncthreads();   // xs / xs2 / ps are rewritten for the next sample tile
+    }
+    // ---- the hidden Linear(H, H) + LeakyReLU of flow_hid_tile_kernel on the h0 tiles in registers
+    v4f D[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) D[s] = v4f{0.f, 0.f, 0.f, 0.f};
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) D[s] = mma16<true>(A[i], Bv[s][i], D[s]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) D[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][j], Bv[s][i][j], D[s], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) red[w][s][lane] = D[s];
+    FTL_STAMP(seq_, 3)
+    __syncthreads();
+    FTL_STAMP(seq_, 4)
+    if (!epi) return;
+    const int st = st0 + es;
+    if (st >= NST) return;
+    v4f h = bias4;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) h += red[v][es][lane];
+    h = lrelu4(h, 0.01f);
+    if (out_ && cb == 0) st4(out_ + ((size_t)st * NRT + rt) * 256 + lane * 4, h);
+    if (W3P_) {
+        const v4f d3 = mma16<F16>(A3, h, v4f{0.f, 0.f, 0.f, 0.f});
+        st4(Pout_ + (((size_t)st * NRT + rt) * 2 + cb) * 256 + lane * 4, d3);
+    }
+    FTL_STAMP(seq_, 5)
+    FTL_END(seq_)
+}
+
 __global__ void flow_set_io_kernel(FlowIo* dst, FlowIo v) { *dst = v; }
 
 template <int KPW, bool F16>
@@ -402,6 +609,24 @@ void launch_hid(const HidTileArgs& a, int ns, int groups, hipStream_t st) {
     if (ns == 1) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 1, F16>), grid, block, 0, st, a.WT, a.in, a.bias, a.out, a.W3P, a.P, a.NRT, a.NST, a.seq);
     else if (ns == 2) hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 2, F16>), grid, block, 0, st, a.WT, a.in, a.bias, a.out, a.W3P, a.P, a.NRT, a.NST, a.seq);
     else hipLaunchKernelGGL((flow_hid_tile_kernel<KPW, 4, F16>), grid, block, 0, st, a.WT, a.in, a.bias, a.out, a.W3P, a.P, a.NRT, a.NST, a.seq);
+}
+
+struct FirstTileArgs {
+    HidTileArgs m;      // the hidden layer (m.in unused)
+    TailTileArgs t;     // the tail in front of it (t.h0 unused; t.W0T / t.pre / t.l1: the first Linear of the hidden layer's half-step)
+};
+
+template <int KPW, bool F16>
+void launch_first(const FirstTileArgs& a, int ns, int groups, hipStream_t st) {
+    const dim3 grid(a.m.NRT * groups), block(512);
+    const TailTileArgs& t = a.t;
+    const int flags = t.io_in | t.ld_init << 2 | t.reverse << 3 | t.do_lrelu << 4 | t.do_swap << 5 | t.l1 << 6;
+#define I2V_FIRST_ARGS a.m.WT, t.P, t.x, t.W0T, t.pre, a.m.bias, a.m.NRT, a.m.NST, flags, t.b3, t.io, t.xo, t.logdet, t.shuf, t.an_loc, t.an_scale, \
+                       t.an_logdet, a.m.out, a.m.W3P, a.m.P, t.B, a.m.seq
+    if (ns == 1) hipLaunchKernelGGL((flow_first_tile_kernel<KPW, 1, F16>), grid, block, 0, st, I2V_FIRST_ARGS);
+    else if (ns == 2) hipLaunchKernelGGL((flow_first_tile_kernel<KPW, 2, F16>), grid, block, 0, st, I2V_FIRST_ARGS);
+    else hipLaunchKernelGGL((flow_first_tile_kernel<KPW, 4, F16>), grid, block, 0, st, I2V_FIRST_ARGS);
+#undef I2V_FIRST_ARGS
 }
 
 int env_int(const char* name, int dflt) {
@@ -482,6 +707,7 @@ FlowTileWs flow_tile_ws(const FlowTilePack& p, int B) {
     L.hA = take(NST * p.NRT * 1024);
     L.hB = take(NST * p.NRT * 1024);
     L.P = take(NST * p.NRT * 2 * 1024);
+    L.P2 = take(NST * p.NRT * 2 * 1024);
     L.total = o;
     return L;
 }
@@ -499,17 +725,20 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     const FlowTilePack& p = *c.pack;
     const FlowTileWs L = flow_tile_ws(p, B);
     const int NST = (B + 15) / 16, NRT = p.NRT, HB = p.HB, S = p.S, D = p.depth, N2 = 2 * p.H, nf = c.n_flows;
-    float* xbuf[2] = {reinterpret_cast<float*>(ws + L.x), reinterpret_cast<float*>(ws + L.x2)};   // state, ping-pong per tail launch
+    float* xbuf[2] = {reinterpret_cast<float*>(ws + L.x), reinterpret_cast<float*>(ws + L.x2)};   // state, ping-pong per tail
     int xcur = 0;
     float* logdet = reinterpret_cast<float*>(ws + L.logdet);
     float* pre = reinterpret_cast<float*>(ws + L.pre);
     float* hA = reinterpret_cast<float*>(ws + L.hA);
     float* hB = reinterpret_cast<float*>(ws + L.hB);
-    float* P = reinterpret_cast<float*>(ws + L.P);
+    float* Pbuf[2] = {reinterpret_cast<float*>(ws + L.P), reinterpret_cast<float*>(ws + L.P2)};   // half-step `it` writes Pbuf[it & 1]
     const FlowIo* io = p.io.as<FlowIo>();
     int ns = NST <= 4 ? 1 : NST <= 8 ? 2 : 4;   // sample tiles per hidden-layer workgroup: keep ~256 workgroups
     if (const int e = env_int("I2V_FLOW_NS", 0)) ns = e >= 4 ? 4 : e >= 2 ? 2 : 1;
     const int groups = (NST + ns - 1) / ns;
+    // 1 (default): the tail is folded into the first hidden layer's launch (82 launches per pass); 0: round 4's 122-launch chain.
+    // Same bits either way (test_flow_fold_keeps_the_bits).
+    const bool fold = env_int("I2V_FLOW_FOLD", 1) != 0;
     int seq = 0;   // launch number inside the pass
     const size_t fb = p.f16 ? 512 : 1024;   // bytes per weight fragment
 
@@ -527,10 +756,44 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
         const int i = reverse ? 1 - it % 2 : it % 2;
         return fl * 2 + i;
     };
-    auto tail = [&](bool coupling, int step, int shuf_block, int an_block, bool lrelu, bool swap, int next_step, bool first, bool last) -> int {
+    // hidden layer d of half-step `step`; its input in `cur`, its output in `nxt` (the last one writes partial products into Pout)
+    auto hid_args = [&](int step, int d, const float* cur, float* nxt, float* Pout) {
+        HidTileArgs m{};
+        m.WT = reinterpret_cast<const float*>(p.WT.as<char>() + ((size_t)step * D + d) * NRT * HB * fb);
+        m.bias = c.bmid + ((size_t)step * D + d) * N2;
+        m.in = cur;
+        m.out = d == D - 1 ? nullptr : nxt;
+        m.W3P = d == D - 1 ? reinterpret_cast<const float*>(p.W3P.as<char>() + (size_t)step * NRT * 2 * fb) : nullptr;
+        m.P = Pout;
+        m.NRT = NRT; m.NST = NST;
+        return m;
+    };
+    auto launch_hidden = [&](HidTileArgs m) -> int {
+        m.seq = seq++;
+        if (p.f16) {
+            switch (HB / 8) {
+                case 1: launch_hid<1, true>(m, ns, groups, st); break;
+                case 2: launch_hid<2, true>(m, ns, groups, st); break;
+                case 3: launch_hid<3, true>(m, ns, groups, st); break;
+                default: launch_hid<4, true>(m, ns, groups, st); break;
+            }
+        } else {
+            switch (HB / 8) {
+                case 1: launch_hid<1, false>(m, ns, groups, st); break;
+                case 2: launch_hid<2, false>(m, ns, groups, st); break;
+                case 3: launch_hid<3, false>(m, ns, groups, st); break;
+                default: launch_hid<4, false>(m, ns, groups, st); break;
+            }
+        }
+        I2V_HIP_CHECK(hipGetLastError());
+        return I2V_OK;
+    };
+    // the tail between two half-steps: coupling of `step` (partial products in Pin; null in front of the first half-step), block
+    // boundary ops, first Linear of next_step.  folded_hidden: the first hidden layer of next_step runs in the same launch.
+    auto tail = [&](const float* Pin, int step, int shuf_block, int an_block, bool lrelu, bool swap, int next_step, bool first, bool last,
+                    const HidTileArgs* folded_hidden) -> int {
         TailTileArgs t{};
-        t.seq = seq++;
-        t.P = coupling ? P : nullptr;
+        t.P = Pin;
         t.b3 = c.b3 + (size_t)step * 64;
         t.x = xbuf[xcur]; t.xo = xbuf[xcur ^ 1];
         xcur ^= 1;
@@ -548,6 +811,28 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
             t.pre = pre + (size_t)next_step * NST * NRT * 256;
             t.h0 = hA;
         }
+        if (folded_hidden) {
+            FirstTileArgs fa{*folded_hidden, t};
+            fa.m.seq = seq++;
+            if (p.f16) {
+                switch (HB / 8) {
+                    case 1: launch_first<1, true>(fa, ns, groups, st); break;
+                    case 2: launch_first<2, true>(fa, ns, groups, st); break;
+                    case 3: launch_first<3, true>(fa, ns, groups, st); break;
+                    default: launch_first<4, true>(fa, ns, groups, st); break;
+                }
+            } else {
+                switch (HB / 8) {
+                    case 1: launch_first<1, false>(fa, ns, groups, st); break;
+                    case 2: launch_first<2, false>(fa, ns, groups, st); break;
+                    case 3: launch_first<3, false>(fa, ns, groups, st); break;
+                    default: launch_first<4, false>(fa, ns, groups, st); break;
+                }
+            }
+            I2V_HIP_CHECK(hipGetLastError());
+            return I2V_OK;
+        }
+        t.seq = seq++;
         const int flags = t.io_in | t.io_out << 1 | t.ld_init << 2 | t.reverse << 3 | t.do_lrelu << 4 | t.do_swap << 5 | t.l1 << 6;
         auto tk = p.f16 ? flow_tail_tile_kernel<true> : flow_tail_tile_kernel<false>;
         hipLaunchKernelGGL(tk, dim3((NST + 7) / 8 * 64), dim3(512), 0, st, t.P, t.x, t.W0T, t.pre, t.b3, t.NST, t.NRT, t.HB2,
@@ -557,8 +842,11 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     };
     const bool act = c.use_act, an = c.use_an, sh = c.use_shuf;
     int rc;
-    if (!reverse) rc = tail(false, 0, -1, an ? 0 : -1, act, false, step_of(0), true, false);
-    else rc = tail(false, 0, sh ? nf - 1 : -1, -1, false, false, step_of(0), true, false);
+    // (folded: the hidden layer 0 of half-step step_of(it) travels with the tail in front of it; its output goes where the
+    //  unfolded chain's layer 0 puts it -- hB -- or, when it is also the last hidden layer, into Pbuf[it & 1])
+    HidTileArgs h0a = hid_args(step_of(0), 0, hA, hB, Pbuf[0]);
+    if (!reverse) rc = tail(nullptr, 0, -1, an ? 0 : -1, act, false, step_of(0), true, false, fold ? &h0a : nullptr);
+    else rc = tail(nullptr, 0, sh ? nf - 1 : -1, -1, false, false, step_of(0), true, false, fold ? &h0a : nullptr);
     if (rc) return rc;
     for (int it = 0; it < S; ++it) {
         const int fl = reverse ? nf - 1 - it / 2 : it / 2;
@@ -568,31 +856,7 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
         float* cur = hA;
         float* nxt = hB;
         for (int d = 0; d < D; ++d) {
-            HidTileArgs m{};
-            m.seq = seq++;
-            m.WT = reinterpret_cast<const float*>(p.WT.as<char>() + ((size_t)step * D + d) * NRT * HB * fb);
-            m.bias = c.bmid + ((size_t)step * D + d) * N2;
-            m.in = cur;
-            m.out = d == D - 1 ? nullptr : nxt;
-            m.W3P = d == D - 1 ? reinterpret_cast<const float*>(p.W3P.as<char>() + (size_t)step * NRT * 2 * fb) : nullptr;
-            m.P = P;
-            m.NRT = NRT; m.NST = NST;
-            if (p.f16) {
-                switch (HB / 8) {
-                    case 1: launch_hid<1, true>(m, ns, groups, st); break;
-                    case 2: launch_hid<2, true>(m, ns, groups, st); break;
-                    case 3: launch_hid<3, true>(m, ns, groups, st); break;
-                    default: launch_hid<4, true>(m, ns, groups, st); break;
-                }
-            } else {
-                switch (HB / 8) {
-                    case 1: launch_hid<1, false>(m, ns, groups, st); break;
-                    case 2: launch_hid<2, false>(m, ns, groups, st); break;
-                    case 3: launch_hid<3, false>(m, ns, groups, st); break;
-                    default: launch_hid<4, false>(m, ns, groups, st); break;
-                }
-            }
-            I2V_HIP_CHECK(hipGetLastError());
+            if (!(fold && d == 0) && (rc = launch_hidden(hid_args(step, d, cur, nxt, Pbuf[it & 1])))) return rc;
             std::swap(cur, nxt);
         }
         int shuf_block = -1, an_block = -1;
@@ -611,7 +875,10 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
                 if (fl - 1 >= 0 && sh) shuf_block = fl - 1;
             }
         }
-        if ((rc = tail(true, step, shuf_block, an_block, lrelu, swap, next_step, false, it == S - 1))) return rc;
+        HidTileArgs hn{};
+        const bool folded = fold && next_step >= 0;
+        if (folded) hn = hid_args(next_step, 0, hA, hB, Pbuf[(it + 1) & 1]);
+        if ((rc = tail(Pbuf[it & 1], step, shuf_block, an_block, lrelu, swap, next_step, false, it == S - 1, folded ? &hn : nullptr))) return rc;
     }
     return I2V_OK;
 }

@@ -999,6 +999,40 @@ def test_generic_flow_chain_and_other_geometries(monkeypatch):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_flow_fold_keeps_the_bits(monkeypatch):
+    """Round 5: the tail of every half-step is folded into the first hidden layer's launch (flow_first_tile_kernel: 82 launches per
+    pass instead of 122; I2V_FLOW_FOLD=0 restores round 4's chain).  Same operations in the same order: both directions, the log-det,
+    the control geometry ('cond' blocks: first Linear without state channels), fp16-operand mode, ragged batches over every sample-
+    tile grouping, and depth 1 (the folded layer is also the last hidden one: partial-product buffers alternate) give the same bits."""
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    _, residual, embed = synth.bench_inputs(150, 64, 128)
+    cases = [dict(emb=64, hidden=512, depth=2, nfl=20, control=False, f16=0, Bs=(64, 8, 3, 150)),
+             dict(emb=128, hidden=512, depth=2, nfl=20, control=False, f16=1, Bs=(24, 130)),
+             dict(emb=94, hidden=512, depth=2, nfl=20, control=True, f16=0, Bs=(21,)),
+             dict(emb=64, hidden=256, depth=1, nfl=3, control=False, f16=0, Bs=(70, 5)),
+             dict(emb=64, hidden=384, depth=3, nfl=2, control=False, f16=0, Bs=(33,))]
+    for cse in cases:
+        sd = T(synth.flow_state_dict(seed=11, embedding_dim=cse["emb"], n_flows=cse["nfl"], hidden_dim=cse["hidden"],
+                                     hidden_depth=cse["depth"], control=cse["control"]))
+        outs = {}
+        for fold in ("0", "1"):
+            monkeypatch.setenv("I2V_FLOW_FOLD", fold)
+            flow = ConditionalFlow(64, cse["emb"], cse["hidden"], cse["depth"], cse["nfl"], conditioning_option="None", control=cse["control"])
+            flow.load_state_dict(sd)
+            flow.linear_f16 = cse["f16"]
+            flow = flow.cuda().eval()
+            res = []
+            for B in cse["Bs"]:
+                r, e = residual[:B].cuda().contiguous(), embed[:B, :cse["emb"]].cuda().contiguous()
+                z = flow(r, e, reverse=True)
+                zt, ld = flow(r, e)
+                res += [z, zt, ld, flow(r, e, reverse=True)]      # (the last one replays the captured graph)
+            outs[fold] = res
+        monkeypatch.delenv("I2V_FLOW_FOLD")
+        for k, (a, b) in enumerate(zip(outs["0"], outs["1"])):
+            assert torch.equal(a, b), (cse, k, float((a - b).abs().max()))
+
+
 def test_pipelined_sampling_equals_serial():
     """i2v_pipeline.LatentPrefetcher: the cINN pass of batch k+1 on a high-priority side stream underneath the decoder of
     batch k.  The chain's workgroups are then dispatched irregularly between the decoder's -- the situation in which a
