@@ -736,9 +736,11 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     int ns = NST <= 4 ? 1 : NST <= 8 ? 2 : 4;   // sample tiles per hidden-layer workgroup: keep ~256 workgroups
     if (const int e = env_int("I2V_FLOW_NS", 0)) ns = e >= 4 ? 4 : e >= 2 ? 2 : 1;
     const int groups = (NST + ns - 1) / ns;
-    // 1 (default): the tail is folded into the first hidden layer's launch (82 launches per pass); 0: round 4's 122-launch chain.
-    // Same bits either way (test_flow_fold_keeps_the_bits).
-    const bool fold = env_int("I2V_FLOW_FOLD", 1) != 0;
+    // Folded chain (the tail travels with the first hidden layer's launch: 82 launches per pass) or round 4's 122-launch chain.
+    // Same bits either way (test_flow_fold_keeps_the_bits).  Every workgroup of a folded launch redoes the tail of its own sample
+    // tiles (128 KB of partial tiles each), so it pays while a workgroup holds ONE sample tile (B <= 64: 508 -> 473 us at B = 64,
+    // 460 -> 439 at B = 8) and loses with four (B = 256: 765 -> 1083 us): default = folded iff ns == 1.  I2V_FLOW_FOLD=0|1 forces.
+    const bool fold = env_int("I2V_FLOW_FOLD", ns == 1 ? 1 : 0) != 0;
     int seq = 0;   // launch number inside the pass
     const size_t fb = p.f16 ? 512 : 1024;   // bytes per weight fragment
 
