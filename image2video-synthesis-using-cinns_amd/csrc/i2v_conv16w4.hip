@@ -92,9 +92,25 @@ constexpr int W4_DEFAULT_ORDER = 2;   // brick -> XCD order (kernel comment); I2
 #else
 #define W4_V_POLICY ""
 #endif
-constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup
+constexpr int W4_TILES = 128;   // tiles (of four output positions) per workgroup of the 512-thread kernels
 constexpr int W4_KC = 16;       // input channels per K chunk
-constexpr int W4_ROWS_A = 1024; // staged V rows per buffer, pass A (4 planes); pass B stages 512 (2 planes)
+constexpr int W4_ROWS_A = 1024; // staged V rows per buffer, pass A (4 planes); pass B stages 512 (2 planes)  [512-thread kernels]
+
+// Workgroup geometry.  NTH = 512: the kernel as described above (8 waves, 128 tiles, one workgroup per CU: 138 KB of LDS).
+// NTH = 256 (round 5, 32-channel layers only): 4 waves, 64 tiles (4 frames x 4 rows x 16 positions), TWO workgroups per CU (2 x 78 KB).
+// A 32-channel workgroup of the 512-thread kernel is two independent 64-tile halves that share nothing but the V brick (pass A:
+// wave = (plane, tile half) with two row blocks per weight fragment; pass B: (plane, tile quarter) with one): splitting it into two
+// workgroups keeps every wave's loop exactly as it was -- same fragments per MFMA, same accumulation order, same bits -- and lets
+// the CU run one workgroup's tables / first brick / hand-over / epilogue (10 of 22 us per 128 tiles on the 64 -> 32 layer at 128 x 128,
+// matrix pipe idle) underneath the other one's tap loops, which one workgroup per CU cannot do and the software-pipelined
+// persistent variants did not manage to do by hand.  The halo brick of 64 tiles has 4 x 144 rows per chunk (36 KB) instead of
+// 4 x 240: 1.2 x the V bytes through L2 per tile.
+// A workgroup load instruction (global_load_lds_dwordx4, one per thread) stages NTH / 4 rows of 64 bytes; a chunk's brick is
+// requested in two half-requests of V0 and V1 such instructions.
+template <int NTH> struct W4Geo;
+template <> struct W4Geo<512> { static constexpr int TILES = 128, ROWS_A = 1024, ROWS_B = 512, VA0 = 4, VA1 = 4, VB0 = 2, VB1 = 2; };
+template <> struct W4Geo<256> { static constexpr int TILES = 64, ROWS_A = 576, ROWS_B = 320, VA0 = 5, VA1 = 4, VB0 = 3, VB1 = 2; };
+template <int NTH> constexpr int w4_table_bytes() { return (2 * W4Geo<NTH>::ROWS_A + 5 * W4Geo<NTH>::TILES) * 4; }
 
 struct W4Args {
     const char* in;     // V: hl16 [B][T][Cin/16][6][H][J][64 B], J = W / 4
@@ -154,11 +170,12 @@ struct W4Next {
     int valid;          // there is a next brick
 };
 
-template <int NT, int WM, int VH, bool PRE, bool PREL, int VXP, class Between>
+template <int NT, int WM, int VH0, int VH1, int NTH, bool PRE, bool PREL, int VXP, class Between>
 __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* gpos, const int* gposN, f32x16 (&acc)[WM],
                                         int (&arow)[WM], const char* wfrag, int HH, int tid, int lane, int wave, int rb0, int rb1,
                                         const W4Next& nxt, Between&& between, int w4_tlv_) {
-    constexpr int VROWS = VH * 2 * 128;
+    constexpr int RPL = NTH / 4;          // V rows staged by one load instruction of the workgroup (4 threads per 64-byte row)
+    static_assert(VXP == 0 || (VH0 == VH1 && NTH == 512), "PIPE needs the 512-thread geometry");
     constexpr int VX = PRE ? VXP : 0;   // extra LDS-DMA loads per half-request (the next brick's first V brick; PREL: this brick's was preloaded)
     const int kg = lane >> 5;
     char* v_lds = smem;
@@ -188,12 +205,13 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     {                                                                                                                \
         const bool nx_ = (ch_) >= a.nchunk;              /* behind the last chunk: the hand-over table, chunk 0 */    \
         const int* gt_ = nx_ ? gqn : gq;                                                                             \
-        int gp_[VH];                                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < VH; ++u) gp_[u] = gt_[128 * (VH * (HF) + u)];                          \
+        constexpr int nv_ = (HF) ? VH1 : VH0, v0_ = (HF) ? VH0 : 0;   /* this half-request's load instructions */     \
+        int gp_[nv_];                                                                                                \
+        _Pragma("unroll") for (int u = 0; u < nv_; ++u) gp_[u] = gt_[RPL * (v0_ + u)];                               \
         const char* vb_ = a.in + (long)(nx_ ? 0 : (ch_)) * vchunk + vpiece;                                          \
-        _Pragma("unroll") for (int u = 0; u < VH; ++u) {                                                             \
+        _Pragma("unroll") for (int u = 0; u < nv_; ++u) {                                                            \
             const char* s_ = gp_[u] >= 0 ? vb_ + (long)gp_[u] * 64 : a.zeros;                     \
-            W4_GLDS(s_, vdst + ((VB) ? voff1 : voff0) + (unsigned)((VH * (HF) + u) * 8192))                           \
+            W4_GLDS(s_, vdst + ((VB) ? voff1 : voff0) + (unsigned)((v0_ + u) * (NTH * 16)))                           \
         }                                                                                                            \
         if constexpr (VX > 0) {   /* the next brick's first V brick, pieces (chunk parity, half, u); real in chunks 0, 1 */ \
             constexpr int pc_ = ((1 - (VB)) * 2 + (HF)) * 2;   /* (the requesting chunk's parity is 1 - VB) */         \
@@ -322,8 +340,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     {                                                                                                                \
         constexpr int cp_ = (U) / NT, t_ = (U) % NT;                                                                 \
         constexpr int un_ = (U) + R - 1, cn_ = un_ / NT, tn_ = un_ % NT;                                             \
-        constexpr int ng_ = w4_count(t_, R - 1, NT, 0) + w4_count(t_, R - 1, NT, VT1);                               \
-        constexpr int nb_ = 2 * (R - 2) + (VH + VX) * ng_;                                                           \
+        constexpr int nb_ = 2 * (R - 2) + (VH0 + VX) * w4_count(t_, R - 1, NT, 0) + (VH1 + VX) * w4_count(t_, R - 1, NT, VT1);  \
         W4_TT(U)                                                                                                     \
         if constexpr (W4_PRIO && (t_ == 0 || w4_prio(t_, NT) != w4_prio(t_ - 1, NT)))                                \
             __builtin_amdgcn_s_setprio(w4_prio(t_, NT));                                                             \
@@ -465,15 +482,16 @@ __host__ __device__ __forceinline__ W4Brick w4_decode(const W4Args& a, int v) {
 
 // index tables of one brick: gposA [1024] (planes 0..3), gposB [1024] (planes 4, 5 in rows 0..511, -1 = zero page behind),
 // tpos [128] (output position of a tile's first column), tres [128][4] (residual rows of the tile's four columns)
-template <int KT>
+template <int KT, int NTH>
 __device__ __forceinline__ void w4_tables(const W4Args& a, const W4Brick& k, int* gposA, int tid) {
-    int* gposB = gposA + W4_ROWS_A;
-    int* tpos = gposB + W4_ROWS_A;
-    int* tres = tpos + W4_TILES;
+    constexpr int ROWS_A = W4Geo<NTH>::ROWS_A, TILES = W4Geo<NTH>::TILES;
+    int* gposB = gposA + ROWS_A;
+    int* tpos = gposB + ROWS_A;
+    int* tres = tpos + TILES;
     const int pt = a.tdup ? 1 - k.par : KT / 2;
     const int HT = a.TT + KT - 1, HH = a.TH + 2;
     const int plane = HT * HH * 4;        // (TJ = 4 tiles along w in every brick of this kernel)
-    if (tid < W4_TILES) {
+    if (tid < TILES) {
         int m = tid;
         const int ij = m & 3; m >>= 2;       // (no integer divisions in the index tables: they cost a workgroup ~1.5 us)
         const int ih = m & (a.TH - 1); m >>= a.th_shift;
@@ -484,9 +502,9 @@ __device__ __forceinline__ void w4_tables(const W4Args& a, const W4Brick& k, int
 #pragma unroll
         for (int c = 0; c < 4; ++c) tres[4 * tid + c] = rbase + ((w + c) >> a.rs_shift);
     }
-    for (int r = tid; r < 2 * W4_ROWS_A; r += 512) {
-        const bool pb = r >= W4_ROWS_A;                 // row of pass B's brick
-        const int rr = pb ? r - W4_ROWS_A : r;
+    for (int r = tid; r < 2 * ROWS_A; r += NTH) {
+        const bool pb = r >= ROWS_A;                    // row of pass B's brick
+        const int rr = pb ? r - ROWS_A : r;
         const int x = (rr >= plane) + (rr >= 2 * plane) + (rr >= 3 * plane) + (rr >= 4 * plane);   // (>= 4: not a row of the brick)
         int q = rr - x * plane;
         const int ij = q & 3; q >>= 2;
@@ -499,7 +517,7 @@ __device__ __forceinline__ void w4_tables(const W4Args& a, const W4Brick& k, int
     }
 }
 
-constexpr int W4_TABLE_BYTES = (2 * W4_ROWS_A + W4_TILES + 4 * W4_TILES) * 4;   // one table set
+constexpr int W4_TABLE_BYTES = w4_table_bytes<512>();   // one table set of the 512-thread kernels
 
 // NT: (kt, kh) taps: 9 = 3x3x3, 6 = temporal-duplication pair kernels (2x3x3), 3 = one time slice (1x3x3: Conv2d).
 // BN: output channels per workgroup.  64: as described above.  32 (layers with 32 output channels): pass A wave = (plane,
@@ -516,9 +534,13 @@ constexpr int W4_TABLE_BYTES = (2 * W4_ROWS_A + W4_TILES + 4 * W4_TILES) * 4;   
 // PIPE = 2 ("lite"): the persistent loop with only what was free in the measurement of PIPE = 1: the next brick's tables under pass
 // B's prologue, and its first V brick requested right behind the epilogue's last read of the exchange buffer (in front of the
 // statistics tail), into the fixed first region -- pass B and the two-half epilogue are those of the default kernel.
-template <int NT, int BN, int PIPE>
-__global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
+// NTH: threads per workgroup (W4Geo): 512, or 256 = the 32-channel kernel as two workgroups per CU.
+template <int NT, int BN, int PIPE, int NTH>
+__global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     constexpr bool FULL = PIPE == 1, LITE = PIPE == 2, PERSIST = PIPE != 0;
+    static_assert(NTH == 512 || (NTH == 256 && BN == 32 && PIPE == 0), "the 256-thread geometry exists for 32-channel one-brick workgroups");
+    using Geo = W4Geo<NTH>;
+    constexpr int NW = NTH / 64;
     constexpr int WMA = BN == 64 ? 4 : 2, WMB = BN == 64 ? 2 : 1;
     constexpr int KT = NT / 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -537,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         const int tid = tid0;
         W4_STAMP(0)
     }
-    w4_tables<KT>(a, bk, reinterpret_cast<int*>(smem + a.tofs), tid0);
+    w4_tables<KT, NTH>(a, bk, reinterpret_cast<int*>(smem + a.tofs), tid0);
     // a brick's first V brick (pass A, chunk 0) into the first region: 8 LDS-DMA loads per thread from the table gq0
     auto request_chunk0 = [&](const int* gq0, int tid) {
         const int* gq = gq0 + (tid >> 2);
@@ -568,9 +590,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         const int lane = tid & 63;
         const int kg = lane >> 5, l31 = lane & 31;
         int* gposA = reinterpret_cast<int*>(smem + a.tofs + (PERSIST ? set * W4_TABLE_BYTES : 0));
-        int* gposB = gposA + W4_ROWS_A;
-        const int* tpos = gposB + W4_ROWS_A;
-        const int* tres = tpos + W4_TILES;
+        int* gposB = gposA + Geo::ROWS_A;
+        const int* tpos = gposB + Geo::ROWS_A;
+        const int* tres = tpos + Geo::TILES;
         const int n0 = bk.ntile * BN, b0 = bk.b0;
         const char* wbase = a.wp + (long)bk.par * a.wset_stride;   // wave-uniform; the lane's 16 bytes are added by the load
         const int vn = v + (int)gridDim.x;
@@ -579,8 +601,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         int* gposAn = reinterpret_cast<int*>(smem + a.tofs + (set ^ 1) * W4_TABLE_BYTES);
         // V buffers (LDS rows): pass A alternates between the two 64 KB regions starting at `flip`; pass B's two 32 KB buffers
         // live in region `flip` (pass A's last chunk -- an odd one -- reads the other region)
-        const int rA0 = FULL ? flip * 1024 : 0, rA1 = FULL ? (flip ^ 1) * 1024 : W4_ROWS_A;
-        const int rB0 = rA0, rB1 = rA0 + 512;
+        const int rA0 = FULL ? flip * 1024 : 0, rA1 = FULL ? (flip ^ 1) * 1024 : Geo::ROWS_A;
+        const int rB0 = rA0, rB1 = rA0 + Geo::ROWS_B;
 
         // ---- pass A: planes 0..3, wave = (plane, 32-channel half), all 128 tiles   [BN = 32: (plane, tile half)]
         const int xa = wave & 3, nha = BN == 64 ? wave >> 2 : 0, mha = BN == 64 ? 0 : (wave >> 2) * 64;
@@ -597,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                 for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
             }
             const W4Next none{gposA, 0u, 0u, 0};
-            w4_pass<NT, WMA, 4, false, PERSIST, 0>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid,
+            w4_pass<NT, WMA, Geo::VA0, Geo::VA1, NTH, false, PERSIST, 0>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid,
                                              lane, wave, rA0, rA1, none, [] {}, w4_tlv_);
         }
         W4_STAMP(2)
@@ -620,11 +642,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             const W4Next nxt{(more ? gposAn : gposA) + (tid >> 2),
                              (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(flip ^ 1) * 65536u + (unsigned)wave * 1024u)),
                              (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)flip * 65536u + 30720u)), more ? 1 : 0};   // dump: rows 480..495 of pass B's first buffer (zero padding, never read)
-            w4_pass<NT, WMB, 2, true, PERSIST, FULL ? 2 : 0>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid,
+            w4_pass<NT, WMB, Geo::VB0, Geo::VB1, NTH, true, PERSIST, FULL ? 2 : 0>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid,
                                             lane, wave, rB0, rB1, nxt, [&] {
                                                 // (PIPE) the next brick's tables, built while this pass's first weight fragments
                                                 // travel; published by the barrier in front of the loop
-                                                if constexpr (PERSIST) { if (more) w4_tables<KT>(a, bn_, gposAn, tid); }
+                                                if constexpr (PERSIST) { if (more) w4_tables<KT, NTH>(a, bn_, gposAn, tid); }
                                             }, w4_tlv_);
         }
         W4_STAMP(4)
@@ -634,12 +656,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         // m ^ ((m >> 2) & 1), which puts the two halves of the wave on the two halves of the banks.
         // !PIPE: one 32-channel half at a time, all 128 tiles (98 KB over both V regions).  PIPE: (32-channel half, 64-tile half)
         // quarters of 48 KB inside pass B's region -- the other region holds the next brick's first V brick already.
-        constexpr int NQ = 8, TPI = 64;
-        constexpr int NTH = FULL ? 2 : 1;             // tile halves per channel half
-        constexpr int ET = W4_TILES / NTH;            // tiles in E
+        constexpr int NQ = 8, TPI = NTH / NQ;         // a thread owns four channels of one tile per iteration
+        constexpr int NTHALF = FULL ? 2 : 1;          // tile halves per channel half
+        constexpr int ET = Geo::TILES / NTHALF;       // tiles in E
         constexpr int NIT = ET / TPI;
         float* E = reinterpret_cast<float*>(smem + (FULL ? flip * 65536 : 0));
-        double* S = reinterpret_cast<double*>(reinterpret_cast<char*>(E) + 6 * ET * 32 * 4);   // [2 halves][8 waves][32 channels][2] behind E
+        double* S = reinterpret_cast<double*>(reinterpret_cast<char*>(E) + 6 * ET * 32 * 4);   // [2 halves][NW waves][32 channels][2] behind E
         const int n4 = tid % NQ;
         const int e3 = kg * 96, e5 = kg * 160;   // row offsets (in floats) of the wave's upper lanes, see the E writes
 #pragma unroll 1
@@ -651,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             if (a.bias && ncol) bias = *reinterpret_cast<const float4*>(a.bias + n);
             const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll 1
-            for (int th = 0; th < NTH; ++th) {
+            for (int th = 0; th < NTHALF; ++th) {
                 const int tb = th * ET;               // first tile of this E
                 // residual rows first, all of them, so that their latency hides behind the LDS exchange.  (PIPE: requesting both
                 // tile halves' rows in front of the first one costs 16 spilled registers in the 64-channel kernels; per quarter
@@ -749,7 +771,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                 }
                 // (each half has its own 4 KB of S: the cross-wave sums and the atomics of both halves wait until after the loop,
                 //  one barrier and two waves instead of a barrier and a serial section of wave 0 per half)
-                double* Sh = S + half * (8 * 32 * 2);
+                double* Sh = S + half * (NW * 32 * 2);
                 if (lane < NQ) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -769,10 +791,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         if (a.stats) {
             if constexpr (!LITE) __syncthreads();
             if (wave < BN / 32 && lane < 32 && n0 + wave * 32 + lane < a.Cout) {   // wave h sums channel half h
-                const double* Sh = S + wave * (8 * 32 * 2);
+                const double* Sh = S + wave * (NW * 32 * 2);
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) {
+                for (int w = 0; w < NW; ++w) {
                     s0 += Sh[(w * 32 + lane) * 2];
                     s1 += Sh[(w * 32 + lane) * 2 + 1];
                 }
@@ -833,14 +855,16 @@ static int wino4_pack_sets(Wino4Weights& o, const std::vector<double>& w3, int n
     return o.w.upload(p.data(), p.size() * 2);
 }
 
-// brick of 128 tiles = TT frames x TH rows x 4 tiles (16 output positions)
-static bool wino4_tiling(int T, int H, int W, int KT, int* TT_, int* TH_) {
+// brick of `tiles` (128: 512-thread kernels, 64: 256-thread kernels) = TT frames x TH rows x 4 tiles (16 output positions); rows_a /
+// rows_b: V rows one buffer of pass A / pass B can stage
+static bool wino4_tiling(int T, int H, int W, int KT, int* TT_, int* TH_, int tiles = W4_TILES, int rows_a = W4_ROWS_A, int rows_b = W4_ROWS_A / 2 - 16) {
     if (T < 1 || (T < 2 && KT != 1) || W % 16 || H < 8) return false;
     int TT = 1;
     while (TT < 4 && T % (TT * 2) == 0) TT *= 2;
-    const int TH = W4_TILES / (TT * 4);
-    if (TH > H || H % TH || TH * 4 % 32) return false;
-    if (4 * (TT + KT - 1) * (TH + 2) * 4 > W4_ROWS_A) return false;   // pass A's halo brick (pass B: half of it)
+    const int TH = tiles / (TT * 4);
+    if (TH < 4 || TH > H || H % TH || TH * 4 % 16) return false;       // (16 consecutive tiles = 16 consecutive V rows: conflict-free ds_read_b128)
+    if (4 * (TT + KT - 1) * (TH + 2) * 4 > rows_a) return false;       // pass A's halo brick
+    if (2 * (TT + KT - 1) * (TH + 2) * 4 > rows_b) return false;       // pass B's (512-thread kernels keep 16 padding rows: PIPE's dump row)
     *TT_ = TT; *TH_ = TH;
     return true;
 }
@@ -882,12 +906,12 @@ int Wino4Weights::pack_tdup(const float* w_src, const float* bias_src, int cout,
     return I2V_OK;
 }
 
-template <int NT, int BN, int PIPE>
+template <int NT, int BN, int PIPE, int NTH = 512>
 static int launch_wino4_(const W4Args& a, unsigned grid, size_t lds, hipStream_t st) {
-    auto kern = conv_wino4_f16x3_kernel<NT, BN, PIPE>;
+    auto kern = conv_wino4_f16x3_kernel<NT, BN, PIPE, NTH>;
     static bool attr_set[I2V_MAX_DEV] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, st, a);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }
@@ -903,6 +927,14 @@ static int device_cus() {
         cus[dev] = n;
     }
     return cus[dev];
+}
+
+// the 32-channel kernel as two 256-thread workgroups per CU (W4Geo<256>): 2 V regions of 576 rows + one table set = 79 616 bytes
+template <int NT>
+static int launch_wino4_thin(W4Args& a, unsigned nblk, hipStream_t st) {
+    a.nvirt = (int)(a.tdup ? 2 * nblk : nblk);
+    a.tofs = 2 * W4Geo<256>::ROWS_A * 64;
+    return launch_wino4_<NT, 32, 0, 256>(a, (unsigned)a.nvirt, (size_t)a.tofs + (size_t)w4_table_bytes<256>(), st);
 }
 
 template <int NT, int BN>
@@ -958,22 +990,34 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     a.oscale = (float)std::ldexp(1.0, -wts.wexp);
     int TT = 1, TH = 1;
     (void)wino4_tiling(T, H, W, wts.KT, &TT, &TH);
-    a.TT = TT; a.TH = TH; a.TJ = 4; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = a.J / 4;
-    a.th_shift = 0;
-    while ((1 << a.th_shift) < TH) ++a.th_shift;
-    I2V_REQUIRE((1 << a.th_shift) == TH, I2V_E_INVALID, "wino4: brick height %d is not a power of two", TH);
-    a.hh_magic = ((1 << 20) + TH + 1) / (TH + 2);
-    I2V_REQUIRE(2 * 4 * (TT + wts.KT - 1) * (TH + 2) + 16 <= W4_ROWS_A / 2, I2V_E_INVALID, "wino4: pass B's brick leaves no padding rows");
-    I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
     int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
     const char* eb_ = getenv("I2V_W4_BN");        // measurement switches (read per launch)
     const char* eo_ = getenv("I2V_W4_ORDER");
-    const int env_bn = eb_ ? atoi(eb_) : 0, env_order = eo_ ? atoi(eo_) : W4_DEFAULT_ORDER;
+    const char* en_ = getenv("I2V_W4_NTH");
+    const int env_bn = eb_ ? atoi(eb_) : 0, env_order = eo_ ? atoi(eo_) : W4_DEFAULT_ORDER, env_nth = en_ ? atoi(en_) : 0;
     // 64-channel workgroups that would leave CUs idle (16x16 maps at small batches) become twice as many 32-channel ones: the
     // accumulation order of every output does not depend on the tile width, so the bits are the same
     if (BN == 64 && wts.KT != 1 && (long)B * (T / TT) * (H / TH) * (a.J / 4) * (a.CoutPad / 64) * (wts.tdup ? 2 : 1) < device_cus()) BN = 32;
     if (env_bn == 32 && wts.KT != 1) BN = 32;
     if (env_bn == 64 && a.CoutPad % 64 == 0) BN = 64;
+    // 32-channel layers: two 256-thread workgroups of 64 tiles per CU instead of one 512-thread workgroup of 128 (W4Geo; same
+    // bits: neither the brick shape nor the workgroup size enters the accumulation order of an output).  I2V_W4_NTH=512 restores
+    // round 4's geometry for A/B runs.
+    bool thin = false;
+    {
+        int TT2 = 1, TH2 = 1;
+        const char* ep_ = getenv("I2V_W4_PIPE");
+        if (BN == 32 && wts.KT != 1 && env_nth != 512 && !(ep_ && atoi(ep_) != 0) &&
+            wino4_tiling(T, H, W, wts.KT, &TT2, &TH2, W4Geo<256>::TILES, W4Geo<256>::ROWS_A, W4Geo<256>::ROWS_B)) {
+            thin = true; TT = TT2; TH = TH2;
+        }
+    }
+    a.TT = TT; a.TH = TH; a.TJ = 4; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = a.J / 4;
+    a.th_shift = 0;
+    while ((1 << a.th_shift) < TH) ++a.th_shift;
+    I2V_REQUIRE((1 << a.th_shift) == TH, I2V_E_INVALID, "wino4: brick height %d is not a power of two", TH);
+    a.hh_magic = ((1 << 20) + TH + 1) / (TH + 2);
+    I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
     a.order = env_order;
     { const char* es_ = getenv("I2V_W4_SKEW"); a.skew = es_ ? atoi(es_) : 0; }
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
@@ -992,6 +1036,9 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
         return launch_wino4<3, 64>(a, (unsigned)nblk, st);   // one time slice: SPADE's 2-D convs
     }
     I2V_REQUIRE(wts.KT != 1, I2V_E_INVALID, "wino4: the 1x3x3 variant exists for 64-channel tiles only");
+#ifndef W4_TAPTIME
+    if (thin) return wts.KT == 3 ? launch_wino4_thin<9>(a, (unsigned)nblk, st) : launch_wino4_thin<6>(a, (unsigned)nblk, st);
+#endif
     if (wts.KT == 3) return launch_wino4<9, 32>(a, (unsigned)nblk, st);
     return launch_wino4<6, 32>(a, (unsigned)nblk, st);
 }
@@ -1036,7 +1083,7 @@ void w4_timeline_report(unsigned nwg) {
         sub[4] += (double)(t[7] - t[6]);
     }
     if (!cnt) { printf("   F(4,3) timeline: no stamped workgroups\n"); return; }
-    const unsigned nall = nwg;
+    const unsigned nall = cnt;
     nwg = cnt;   // (means over the stamped workgroups)
     printf("   F(4,3) timeline over %u workgroups (us, 100 MHz clock): total %.2f per workgroup; kernel span %.1f = %.2f per workgroup slot of 256 CUs\n",
            nwg, tot / nwg / 100.0, (double)(hi - lo) / 100.0, (double)(hi - lo) / 100.0 / (nall / 256.0));

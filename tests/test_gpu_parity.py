@@ -304,7 +304,7 @@ def test_f43_structure_switches_keep_the_bits(golden, monkeypatch):
     x0, z = x0.cuda(), z.cuda()
     ref = _gen(meta)(x0, z)
     assert rel_l2(ref[1:2, ..., ::2, ::2].cpu(), g["out_s2"]) < TOL
-    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_PIPE", "2"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"), ("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2")):
+    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_PIPE", "2"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"), ("I2V_W4_NTH", "512"), ("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2")):
         monkeypatch.setenv(env, val)
         alt = _gen(meta)(x0, z)
         monkeypatch.delenv(env)
@@ -914,14 +914,15 @@ def test_flow_fp16_operand_mode(emb):
     assert rel_l2(z32, zr32) < TOL
     e_emul, e_fp32 = rel_l2(z16, zr16), rel_l2(z16, zr32)
     print(f"fp16-operand cINN (E = {emb}): z rel-L2 vs emulated oracle {e_emul:.2e}, vs fp32 oracle {e_fp32:.2e}")
-    # measured on MI355X: 2.2e-4 / 3.0e-4 (both E); bounds = ~2.5-3x that (a rounding flip of one activation costs 2^-11 on that element)
+    # measured on MI355X (round 5): E = 64: 3.3e-4 / 4.2e-4, E = 128: 2.2e-4 / 3.1e-4; bounds = ~2x the larger (a rounding flip of one
+    # activation costs 2^-11 on that element)
     assert e_emul < 6e-4 and e_fp32 < 9e-4, (e_emul, e_fp32)
     assert not torch.equal(z16, z32)                      # the mode really changes the arithmetic
     zt16, ld16 = flows[1](residual.cuda(), embed.cuda())
     e_zt = rel_l2(zt16.view(24, -1).cpu(), ztr16.reshape(24, -1))
     e_ld = float(np.max(np.abs(ld16.cpu().numpy().reshape(-1) - np.asarray(ldr16).reshape(-1)) / (1.0 + np.abs(np.asarray(ldr16).reshape(-1)))))
     print(f"fp16-operand cINN forward: z~ rel-L2 vs emulated oracle {e_zt:.2e}, log-det max |err| / (1 + |ld|) {e_ld:.2e}")
-    assert e_zt < 6e-4 and e_ld < 1e-3, (e_zt, e_ld)
+    assert e_zt < 6e-4 and e_ld < 4e-4, (e_zt, e_ld)   # measured 3.2e-4 / 1.3e-4
     # shards equal the full batch bit for bit in this mode too
     zs = flows[1](residual[8:16].cuda().contiguous(), embed[8:16].cuda().contiguous(), reverse=True).view(8, -1).cpu()
     assert torch.equal(zs, z16[8:16])

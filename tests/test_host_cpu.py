@@ -327,22 +327,26 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     text = asm.read_text()
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import check_asm_waits as caw
-    kernels = re.findall(r"^(_ZN3i2v23conv_wino4_f16x3_kernelILi(\d)ELi(\d+)ELi(\d)EEEvNS_6W4ArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+    kernels = re.findall(r"^(_ZN3i2v23conv_wino4_f16x3_kernelILi(\d)ELi(\d+)ELi(\d)ELi(\d+)EEEvNS_6W4ArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
                          flags=re.S | re.M)
     # <9,64> <6,64> <3,64> (SPADE's 2-D convs) <9,32> <6,32>, each as round 3's one-workgroup-per-brick kernel (PIPE = 0), as the
-    # software-pipelined persistent kernel (PIPE = 1) and as its "lite" form (PIPE = 2)
-    assert len(kernels) == 15, [k[0] for k in kernels]
-    for name, nt, bn, pipe, whole in kernels:
+    # software-pipelined persistent kernel (PIPE = 1) and as its "lite" form (PIPE = 2); round 5: <9,32> <6,32> as 256-thread
+    # workgroups of 64 tiles (two per CU), whose half-requests are 5 + 4 (pass A) and 3 + 2 (pass B) load instructions
+    assert len(kernels) == 17, [k[0] for k in kernels]
+    assert sorted(k[0] for k in kernels if k[4] == "256") == sorted(
+        "_ZN3i2v23conv_wino4_f16x3_kernelILi%dELi32ELi0ELi256EEEvNS_6W4ArgsE" % n for n in (9, 6))
+    for name, nt, bn, pipe, nth, whole in kernels:
         nt = int(nt)
         assert "scratch_" not in whole and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", whole), name
         loops = [mm.group(2) for mm in re.finditer(r"^(\.LBB\d+_\d+):[^\n]*\n((?:(?!^\.LBB).)*?)s_cbranch_\w+ \1\n", whole, flags=re.S | re.M)
                  if "v_mfma" in mm.group(2)]
         assert len(loops) == 2, (name, len(loops))
         # PIPE: pass B's half-requests carry two extra loads (the next brick's first V brick)
-        for loop, wm, vh in zip(loops, (4, 2) if bn == "64" else (2, 1), (4, 4) if pipe == "1" else (4, 2)):
+        # V load instructions per chunk (both half-requests)
+        for loop, wm, vh2 in zip(loops, (4, 2) if bn == "64" else (2, 1), (9, 5) if nth == "256" else ((8, 8) if pipe == "1" else (8, 4))):
             taps = 2 * nt
             assert loop.count("v_mfma_f32_32x32x16_f16") == taps * 3 * wm, name
-            assert loop.count("global_load_lds_dwordx4") == 2 * 2 * vh, name                 # two half-requests per chunk
+            assert loop.count("global_load_lds_dwordx4") == 2 * vh2, name                    # two chunks per loop iteration
             assert len(re.findall(r"global_load_dwordx4", loop)) == taps * 2, name
             assert loop.count("s_barrier") == 2, name
             assert caw.check_loop(loop) == [], name

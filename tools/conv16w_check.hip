@@ -256,7 +256,7 @@ int main(int argc, char** argv) {
         if (which == 2) w4_taptime_report();
 #endif
 #ifdef W4_TIMELINE
-        if (which == 2) w4_timeline_report((unsigned)((size_t)B * T * H * W / 512 * ((Cout + 63) / 64)));
+        if (which == 2) w4_timeline_report(8192u);   // (the report averages over the workgroups that left stamps)
 #endif
     }
     return 0;
