@@ -51,6 +51,22 @@ int conv_forward(const ConvWeights& wts, const float* in, int cin_act, float* ou
                  int B, int T, int H, int W, int epi, hipStream_t st, const float* coef = nullptr, int stride = 1,
                  int stride_t = 1, long frames_bstride = 0);
 
+// ---- exact-fp32 mode: 3x3x3 conv with a Winograd F(4,3) transform along W (i2v_wino32.hip): six 3x3x1 plane convs on the kernel above
+struct Wino4F32Weights {
+    ConvWeights u[6];   // U_x = (G g)_x per (kt, kh), fp64 -> fp32 once at load
+    DevBuf bias;
+    int Cin = 0, Cout = 0;
+    // w_src: torch layout [Cout][Cin][3][3][3]; scale multiplies every weight (1 / sigma)
+    int pack(const float* w_src, const float* bias_src, int cout, int cin, double scale);
+};
+bool wino4f32_supported(int cout, int cin, int T, int H, int W);
+// V: [6][B][T][H][W/4][C] fp32 = B^T d of act((x A + B) gamma' + beta) read through the nearest up-sampling map (ut, us)
+int modulate_wino4_f32(const float* x, const float* coef, const float* gb, float* V, int B, int T, int H, int W, int C, int ut, int us,
+                       int lrelu, hipStream_t st);
+// M: scratch [6][B][T][H][W/4][Cout]; out: channels-last fp32 [B][T][H][W][Cout]; res as conv_forward
+int wino4f32_forward(const Wino4F32Weights& wts, const float* V, float* M, float* out, const float* res, int rt, int rs, int B, int T, int H,
+                     int W, int epi, hipStream_t st);
+
 // ---- 1x1(x1) convs / Linear layers as a plain pipelined GEMM (i2v_pointwise.hip); conv_forward dispatches to it
 bool pointwise_supported(const ConvWeights& wts, const float* res, int rt, int rs, int epi, int stride, int stride_t);
 // M = rows (B*T*H*W), P = positions per sample (row / P selects the coef row)

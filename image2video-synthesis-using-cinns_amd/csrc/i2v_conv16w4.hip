@@ -111,6 +111,27 @@ template <int NTH> struct W4Geo;
 template <> struct W4Geo<512> { static constexpr int TILES = 128, ROWS_A = 1024, ROWS_B = 512, VA0 = 4, VA1 = 4, VB0 = 2, VB1 = 2; };
 template <> struct W4Geo<256> { static constexpr int TILES = 64, ROWS_A = 576, ROWS_B = 320, VA0 = 5, VA1 = 4, VB0 = 3, VB1 = 2; };
 template <int NTH> constexpr int w4_table_bytes() { return (2 * W4Geo<NTH>::ROWS_A + 5 * W4Geo<NTH>::TILES) * 4; }
+// Which tile of its 32-tile row block an MFMA row (= A-operand lane l31) holds.  512-thread kernels: tile = row (32 consecutive
+// tiles = 32 consecutive V rows, which the XOR key (row >> 2) & 3 spreads over the 16-byte slots without conflicts for the four
+// 16-lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} ... of ds_read_b128).  The 64-tile brick is 4 frames x 4 rows x 4 tiles: a row
+// block is two 16-row runs 24 rows apart (keys k .. k+3 and k+2 .. k+5), and with tile = row both lane groups would read two
+// pairs of rows with equal keys (2-way conflicts: 41 % conflict cycles when round 3 tried this brick).  So the eight lane quads
+// take the tile quads 0 2 3 1 6 4 5 7: group {0,3,5,6} -> tile quads {0,1,4,5} = keys {k,k+1,k+2,k+3}, group {1,2,4,7} -> {2,3,6,7} =
+// keys {k+2,k+3,k,k+1}.  Only the row -> tile labels move (arow here, the accumulator scatter in the epilogue): no loop changes,
+// and no output's accumulation order either.
+// The accumulator scatter that goes with it (256-thread kernels).  Register r of lane (l31, kg) is MFMA row (r & 3) + 8 (r >> 2) + 4 kg =
+// lane quad j = 2 (r >> 2) + kg, i.e. tile quad tq = {0 2 3 1 6 4 5 7}[j], tile 4 tq + (r & 3), kept in E row tile ^ (tq & 1):
+//   r >> 2 = 0: tq = 0 | 2 -> row (r & 3)           + 8 kg        r >> 2 = 1: tq = 3 | 1 -> row 12 + ((r & 3) ^ 1) - 8 kg
+//   r >> 2 = 2: tq = 6 | 4 -> row 24 + (r & 3)      - 8 kg        r >> 2 = 3: tq = 5 | 7 -> row 20 + ((r & 3) ^ 1) + 8 kg
+// w4_escatter: the row for kg = 0 (compile-time in r); w4_escatter_up: whether the upper lanes sit 8 rows above (else below).
+__device__ __forceinline__ constexpr int w4_escatter(int base, int r) {
+    return base + ((r >> 2) == 0 ? 0 : (r >> 2) == 1 ? 12 : (r >> 2) == 2 ? 24 : 20) + ((r & 3) ^ ((r >> 2) & 1));
+}
+__device__ __forceinline__ constexpr bool w4_escatter_up(int r) { return (r >> 2) == 0 || (r >> 2) == 3; }
+template <int NTH> __device__ __forceinline__ int w4_row_tile(int l31) {
+    if constexpr (NTH == 256) return 4 * ((0x75461320u >> (4 * (l31 >> 2))) & 7) + (l31 & 3);
+    else return l31;
+}
 
 struct W4Args {
     const char* in;     // V: hl16 [B][T][Cin/16][6][H][J][64 B], J = W / 4
@@ -611,7 +632,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             int arow[WMA];
 #pragma unroll
             for (int wm = 0; wm < WMA; ++wm) {
-                int m = mha + wm * 32 + l31;
+                int m = mha + wm * 32 + w4_row_tile<NTH>(l31);
                 const int ij = m & 3; m >>= 2;
                 const int ih = m & (a.TH - 1); m >>= a.th_shift;
                 arow[wm] = xa * plane + (m * HH + ih) * 4 + ij;
@@ -630,7 +651,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             int arow[WMB];
 #pragma unroll
             for (int wm = 0; wm < WMB; ++wm) {
-                int m = mhb + wm * 32 + l31;
+                int m = mhb + wm * 32 + w4_row_tile<NTH>(l31);
                 const int ij = m & 3; m >>= 2;
                 const int ih = m & (a.TH - 1); m >>= a.th_shift;
                 arow[wm] = xb * plane + (m * HH + ih) * 4 + ij;
@@ -664,6 +685,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         double* S = reinterpret_cast<double*>(reinterpret_cast<char*>(E) + 6 * ET * 32 * 4);   // [2 halves][NW waves][32 channels][2] behind E
         const int n4 = tid % NQ;
         const int e3 = kg * 96, e5 = kg * 160;   // row offsets (in floats) of the wave's upper lanes, see the E writes
+        const int e8 = kg * 256;                 // (256-thread kernels: the upper lanes' tile quad is 2 tile quads = 8 rows away, see w4_escatter)
 #pragma unroll 1
         for (int half = 0; half < BN / 32; ++half) {
             const int n = n0 + half * 32 + 4 * n4;
@@ -696,9 +718,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                         if (m0 >= 0 && m0 < ET) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                // tile m = c + 4 kg sits in row m ^ ((m >> 2) & 1) = c + (r odd ? 3 : 5) kg: two base addresses + immediates
-                                const int c = m0 + (r & 3) + 8 * (r >> 2);
-                                E[(xa * ET + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accA[wm][r];
+                                if constexpr (NTH == 256) E[w4_escatter(xa * ET + m0, r) * 32 + l31 + (w4_escatter_up(r) ? e8 : -e8)] = accA[wm][r];
+                                else {
+                                    // tile m = c + 4 kg sits in row m ^ ((m >> 2) & 1) = c + (r odd ? 3 : 5) kg: two base addresses + immediates
+                                    const int c = m0 + (r & 3) + 8 * (r >> 2);
+                                    E[(xa * ET + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accA[wm][r];
+                                }
                             }
                         }
                     }
@@ -710,8 +735,11 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                         if (m0 >= 0 && m0 < ET) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const int c = m0 + (r & 3) + 8 * (r >> 2);
-                                E[((4 + xb) * ET + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accB[wm][r];
+                                if constexpr (NTH == 256) E[w4_escatter((4 + xb) * ET + m0, r) * 32 + l31 + (w4_escatter_up(r) ? e8 : -e8)] = accB[wm][r];
+                                else {
+                                    const int c = m0 + (r & 3) + 8 * (r >> 2);
+                                    E[((4 + xb) * ET + c) * 32 + l31 + ((r & 1) ? e3 : e5)] = accB[wm][r];
+                                }
                             }
                         }
                     }

@@ -631,6 +631,7 @@ struct Block {
     Wino4Weights sp_gb_w4;      // ... on the F(4,3) kernel (packed INSTEAD where the shape allows: W % 16 == 0, H % 32 == 0)
     Wino16Weights conv0_w, conv1_w;             // Winograd F(2,3) variants of conv_0 / conv_1 (packed where the shape allows)
     Wino4Weights conv0_w4, conv1_w4;            // Winograd F(4,3) variants (i2v_conv16w4.hip); packed INSTEAD of the F(2,3) ones
+    Wino4F32Weights conv0_wf, conv1_wf;         // exact-fp32 mode: Winograd F(4,3) on the fp32 matrix cores (i2v_wino32.hip), next to conv0 / conv1
     bool tdup0 = false;                          // conv_0 runs on the half-rate tensor (x2 temporal up-sampling in front)
     DevBuf gn_w, gn_b;
     int zoff = 0;  // offset of this block's ADAIN (gamma|beta) in the z-GEMM output
@@ -656,6 +657,7 @@ struct i2v_dec {
     int img16 = 2;  // split-fp16 mode: 2 fused matrix-core kernel (i2v_convimg.hip), 1 round 2's 81-plane GEMM + gather at nf >= 64, 0 vector-ALU kernel (env I2V_DEC_IMG16)
     int wino4 = 1; // 1: F(4,3) Winograd kernel where the shape allows and one sample gives >= 32 workgroups (env I2V_DEC_WINO4=0: F(2,3); 2: wherever the shape allows)
     int spw = 1;   // 1: SPADE's gamma|beta conv uses the Winograd kernel where the shape allows (env I2V_DEC_SPW=0: direct kernel)
+    int wino32 = 1;  // exact-fp32 mode (mma = 0): 1 = 3x3x3 convs from the 16x16 level on run Winograd F(4,3) on the fp32 matrix cores (env I2V_DEC_WINO32=0: direct kernel)
     const float* prep_img = nullptr;   // i2v_dec_prepare: the start frames whose SPADE branches are in the workspace's gbs[] ...
     int prep_B = 0;                    // ... their batch, image size and the workspace they live in (consumed by the next matching forward)
     int prep_h = 0, prep_w = 0;
@@ -691,6 +693,7 @@ namespace {
 struct DecWs {
     size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, sums3, coef, splitk, splitk_floats, y1v, total;
     size_t gbs[6], py0, py1, py1v;   // i2v_dec_prepare: one gamma|beta buffer per level and its own SPADE scratch
+    size_t m6 = 0;                   // exact-fp32 Winograd: the six partial outputs M_x of one conv
     bool has_y1v = false;
 };
 
@@ -698,6 +701,8 @@ bool want_wino0(const i2v_dec* d, const Block& b, const Level& l);
 bool want_wino1(const i2v_dec* d, const Block& b, const Level& l);
 bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l);
 bool want_w4_1(const i2v_dec* d, const Block& b, const Level& l);
+bool want_wf_0(const i2v_dec* d, const Block& b, const Level& l);
+bool want_wf_1(const i2v_dec* d, const Block& b, const Level& l);
 
 // SPADE's gamma|beta Conv2d(128, 2C, 3) on a Winograd kernel (F(4,3) 1x3x3 variant, else F(2,3)): the predicate of
 // i2v_dec_load's packing and of the y1v workspace
@@ -709,7 +714,7 @@ bool spade_wino_wanted(const i2v_dec* d, const Block& b, const Level& l) {
 }
 
 DecWs dec_ws(const i2v_dec* d, int B) {
-    size_t mx_x = (size_t)16 * d->blk[0].n_in, mx_a = 0, mx_dx = 0, mx_xsin = 0, mx_xslow = 0, mx_y = 0, mx_gb = 0, mx_yv = 0;
+    size_t mx_x = (size_t)16 * d->blk[0].n_in, mx_a = 0, mx_dx = 0, mx_xsin = 0, mx_xslow = 0, mx_y = 0, mx_gb = 0, mx_yv = 0, mx_m6 = 0;
     int cmax = 0;
     for (int k = 0; k < 6; ++k) {
         const Block& b = d->blk[k];
@@ -719,6 +724,9 @@ DecWs dec_ws(const i2v_dec* d, int B) {
         // conv operands: hl16 (4 B per element), or the Winograd operand V (4 values per output pair: 8 B per element)
         mx_a = std::max(mx_a, P * b.n_in * (want_wino0(d, b, l) || want_w4_0(d, b, l) ? 2 : 1));
         mx_a = std::max(mx_a, P * b.n_mid * (want_wino1(d, b, l) || want_w4_1(d, b, l) ? 2 : 1));
+        // exact-fp32 Winograd: V = 6 planes per 4 positions (1.5 x the activation), M = 6 planes per 4 outputs
+        if (want_wf_0(d, b, l)) { mx_a = std::max(mx_a, P * b.n_in * 3 / 2); mx_m6 = std::max(mx_m6, P * b.n_mid * 3 / 2); }
+        if (want_wf_1(d, b, l)) { mx_a = std::max(mx_a, P * b.n_mid * 3 / 2); mx_m6 = std::max(mx_m6, P * b.n_out * 3 / 2); }
         mx_dx = std::max(mx_dx, P * b.n_mid);
         if (b.learned) { mx_xsin = std::max(mx_xsin, Pl * b.n_in); mx_xslow = std::max(mx_xslow, Pl * b.n_out); }
         mx_y = std::max(mx_y, (size_t)l.H * l.W);
@@ -752,6 +760,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
     }
     for (int k = 0; k < 6; ++k) L.gbs[k] = take((size_t)B * d->lvl[k].H * d->lvl[k].W * 2 * d->blk[k].n_in);
     L.py0 = take(B * mx_y * 16); L.py1 = take(B * mx_y * 128); L.py1v = take(B * mx_yv * 256);
+    L.m6 = take(B * mx_m6);   // exact-fp32 Winograd: the six partial outputs M_x
     L.total = o;
     return L;
 }
@@ -852,6 +861,14 @@ int conv3(i2v_dec* d, const ConvWeights& w, const float* in, float* out, const f
     return conv_forward(w, in, w.Cin, out, res, rt, rs, B, l.T, l.H, l.W, epi, st);
 }
 
+// exact-fp32 mode, Winograd F(4,3): six 9-tap plane convs + the output transform; matrix-core FLOPs issued = 1/2 of the algorithmic
+int conv3_wf(i2v_dec* d, const Wino4F32Weights& w, const float* V, float* M, float* out, const float* res, int rt, int rs, int B,
+             const Level& l, int epi, hipStream_t st) {
+    const double fl = 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0;
+    ProfScope ps(d, st, fl, 0.5 * fl);
+    return wino4f32_forward(w, V, M, out, res, rt, rs, B, l.T, l.H, l.W, epi, st);
+}
+
 int conv3_16(i2v_dec* d, const Conv16Weights& w, const float* in_hl16, float* out, const float* res, int rt, int rs, int B,
              const Level& l, int epi, hipStream_t st, double* stats = nullptr, float* splitk = nullptr, size_t splitk_floats = 0) {
     if (stats) I2V_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * w.Cout * 16, st));
@@ -904,6 +921,10 @@ bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l) {
 bool want_w4_1(const i2v_dec* d, const Block& b, const Level& l) {
     return d->cfg.mma == 1 && d->wino && d->wino4 && (d->wino4 == 2 || w4_fills(l, b.n_out)) && wino4_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
 }
+bool want_wf_0(const i2v_dec* d, const Block& b, const Level& l) { return d->cfg.mma == 0 && d->wino32 && wino4f32_supported(b.n_mid, b.n_in, l.T, l.H, l.W); }
+bool want_wf_1(const i2v_dec* d, const Block& b, const Level& l) { return d->cfg.mma == 0 && d->wino32 && wino4f32_supported(b.n_out, b.n_mid, l.T, l.H, l.W); }
+bool use_wf_0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_wf.u[0].w.p && want_wf_0(d, b, l); }
+bool use_wf_1(const i2v_dec* d, const Block& b, const Level& l) { return b.conv1_wf.u[0].w.p && want_wf_1(d, b, l); }
 bool use_w4_0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_w4.w.p && want_w4_0(d, b, l); }
 bool use_w4_1(const i2v_dec* d, const Block& b, const Level& l) { return b.conv1_w4.w.p && want_w4_1(d, b, l); }
 bool use_wino0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_w.w.p && want_wino0(d, b, l); }
@@ -937,6 +958,7 @@ struct BlockBufs {
     size_t splitk_floats = 0;
     float* y1v = nullptr;         // Winograd operand of SPADE's 128-channel activation (2 x the size of y1; optional)
     const float* gb_ready = nullptr;   // this block's gamma | beta, already computed by i2v_dec_prepare
+    float* m6 = nullptr;          // exact-fp32 Winograd scratch (six partial outputs); null: the direct kernel is used
 };
 
 // SPADE's conditioning branch of one block (normalization_layer.py:20-23): resize(start frame) -> Conv2d(3, 128) + lrelu ->
@@ -1004,16 +1026,19 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // underflow guard: the two operand tensors of this block publish their maxima in slots 1 + 2k / 2 + 2k
     int* um0 = f16 && flag ? flag + 1 + 2 * (k % 24) : nullptr;
     int* um1 = um0 ? um0 + 1 : nullptr;
-    if (q0) rc = run_modulate_wino4(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
+    const bool f0 = w.m6 && use_wf_0(d, b, l), f1 = w.m6 && use_wf_1(d, b, l);   // exact-fp32 mode: Winograd F(4,3) on the fp32 matrix cores
+    if (f0) rc = modulate_wino4_f32(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st);
+    else if (q0) rc = run_modulate_wino4(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
     else if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
     else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true, flag, um0);
     else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16, flag, um0);
     if (rc) return rc;
-    if ((rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
+    if (!f0 && (rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
     const bool fuse = f16 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
     d->prof_cur_layer = 2 * k;
     d->prof_cur_kernel = q0 ? 3 : w0 ? 2 : (f16 ? 1 : 0);
-    if (q0) rc = conv3_w4(d, b.conv0_w4, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
+    if (f0) rc = conv3_wf(d, b.conv0_wf, a, w.m6, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
+    else if (q0) rc = conv3_w4(d, b.conv0_w4, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else if (w0) rc = conv3_w(d, b.conv0_w, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr, w.splitk, w.splitk_floats);
     else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
@@ -1022,11 +1047,12 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // ADAIN (normalization_layer.py:47-51) + leaky_relu
     if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
     if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, zstride, b.zoff, nullptr, nullptr, st))) return rc;
-    if (q1) rc = run_modulate_wino4(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
+    if (f1) rc = modulate_wino4_f32(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st);
+    else if (q1) rc = run_modulate_wino4(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
     else if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
     else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16, flag, um1);
     if (rc) return rc;
-    if ((rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
+    if (!f1 && (rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
     // shortcut (decoder.py:44-49) at low resolution
     const float* res = x;
     if (b.learned) {
@@ -1046,7 +1072,8 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     const bool fuse_out = f16 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
     d->prof_cur_layer = 2 * k + 1;
     d->prof_cur_kernel = q1 ? 3 : w1 ? 2 : (f16 ? 1 : 0);
-    if (q1) rc = conv3_w4(d, b.conv1_w4, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
+    if (f1) rc = conv3_wf(d, b.conv1_wf, a, w.m6, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
+    else if (q1) rc = conv3_w4(d, b.conv1_w4, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
     else if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
     else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr,
                                 w.splitk, w.splitk_floats);
@@ -1092,6 +1119,16 @@ int sn_pack(const StateDict& sd, const std::string& name, bool spectral, int cou
     int rc = sn_scale(sd, name, spectral, cout, (int64_t)cin * k * k * k, &w, &scale);
     if (rc) return rc;
     return out.pack(w, bias, cout, cin, k, k, k, scale);
+}
+
+int sn_pack_wf(const StateDict& sd, const std::string& name, bool spectral, int cout, int cin, Wino4F32Weights& out) {
+    const float* bias = sd.f32(name + ".bias", cout);
+    if (!bias) return I2V_E_MISSING;
+    const float* w = nullptr;
+    double scale = 1.0;
+    int rc = sn_scale(sd, name, spectral, cout, (int64_t)cin * 27, &w, &scale);
+    if (rc) return rc;
+    return out.pack(w, bias, cout, cin, scale);
 }
 
 // conv_0 of a block that sits behind a x2 temporal up-sampling: packed for the half-rate input (Conv16Weights::pack_tdup)
@@ -1172,6 +1209,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     if (const char* e = std::getenv("I2V_DEC_PW16")) d->pw16 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_WINO32")) d->wino32 = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_SUB")) d->sub = std::max(0, std::atoi(e));
     if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
@@ -1243,6 +1281,9 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         } else {
             if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
             if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
+            // from the 16x16 level on: Winograd F(4,3) on the fp32 matrix cores (half the MFMA work of the 27-tap kernel)
+            if (want_wf_0(d, b, d->lvl[k]) && (rc = sn_pack_wf(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.conv0_wf))) return rc;
+            if (want_wf_1(d, b, d->lvl[k]) && (rc = sn_pack_wf(sd, p + "conv_1", sn, b.n_out, b.n_mid, b.conv1_wf))) return rc;
         }
         if (b.learned) {
             if ((rc = sn_pack(sd, p + "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs))) return rc;
@@ -1459,7 +1500,8 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
             const int n = std::min(nsub, B - s0);
             BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, s_in + (size_t)s0 * b.n_in * 2, sums2, s_out + (size_t)s0 * b.n_out * 2,
                            F(L.splitk), L.splitk_floats, L.has_y1v ? F(L.y1v) : nullptr,
-                           prepared ? F(L.gbs[k]) + (size_t)s0 * l.H * l.W * 2 * b.n_in : nullptr};
+                           prepared ? F(L.gbs[k]) + (size_t)s0 * l.H * l.W * 2 * b.n_in : nullptr,
+                           d->cfg.mma == 0 && d->wino32 ? F(L.m6) : nullptr};
             bool ready = x_stats_ready;
             if ((rc = block_forward(d, k, d->blk[k], l, x + (size_t)s0 * Pl * b.n_in, xn + (size_t)s0 * P * b.n_out,
                                     img + (size_t)s0 * (size_t)img_bstride, img_h, img_w, zl + (size_t)s0 * d->Nz, d->Nz, n, bufs, ready, k == 5, st)))

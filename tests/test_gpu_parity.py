@@ -277,6 +277,42 @@ def test_both_matrix_core_modes_agree():
         assert rel_l2(gen.cuda().eval()(cu(g["img"]), cu(g["z"])).cpu(), g["out"]) < TOL
 
 
+@pytest.mark.parametrize("golden", ["dec_nf8_bair", "dec_nf64_bair", "dec_nf32_128"])
+def test_exact_fp32_mode_winograd_and_direct(golden, monkeypatch):
+    """mma = 0, the range-safe mode: from the 16x16 level on its 3x3x3 convs run Winograd F(4,3) on the fp32 matrix cores (round 5:
+    csrc/i2v_wino32.hip; I2V_DEC_WINO32=0 keeps the 27-tap kernel).  Both must reproduce the reference-generated golden frames;
+    the Winograd path against the direct one shows the transform's fp32 rounding (~1e-6), not a different result; the stand-alone
+    sub-batches of the last two levels and the strided in-place sequence work in this mode too."""
+    from stage1_VAE.modules.decoder import Generator
+    g, meta = load_golden(golden)
+
+    def make():
+        gen = Generator({"channel_factor": meta["synth"]["channel_factor"], "z_dim": 64, "upsample_s": meta["upsample_s"],
+                         "upsample_t": meta["upsample_t"], "spectral_norm": True, "mma": 0})
+        gen.load_state_dict(T(synth.decoder_state_dict(**meta["synth"])))
+        return gen.cuda().eval()
+
+    img, z = cu(g["img"]), cu(g["z"])
+    wino = make()(img, z)
+    monkeypatch.setenv("I2V_DEC_WINO32", "0")
+    direct = make()(img, z)
+    monkeypatch.delenv("I2V_DEC_WINO32")
+    key = "out" if "out" in g else "out_s2"
+    sl = (lambda t: t) if key == "out" else (lambda t: t[..., ::2, ::2])
+    e_w, e_d, e_wd = rel_l2(sl(wino).cpu(), g[key]), rel_l2(sl(direct).cpu(), g[key]), rel_l2(wino.cpu(), direct.cpu())
+    print(f"exact-fp32 mode ({golden}): Winograd vs golden {e_w:.2e}, direct vs golden {e_d:.2e}, Winograd vs direct {e_wd:.2e}")
+    assert e_w < TOL and e_d < TOL and e_wd < 2e-5 and not torch.equal(wino, direct)
+    # rows of a larger batch equal the small run (every op is per sample), and the decoder's in-place sequence works in this mode
+    gen = make()
+    x3 = img[:1].repeat(3, 1, 1, 1).contiguous()
+    z3 = z[:1].repeat(3, 1).contiguous()
+    big = gen(x3, z3)
+    assert torch.equal(big[2:3], wino[:1]) and torch.equal(big[0], big[1])
+    if golden == "dec_nf8_bair":
+        seq = gen.decode_sequence(img, z, 32)
+        assert torch.equal(seq[:, :16], wino) and torch.equal(seq[:, 16:], gen(wino[:, -1].contiguous(), z))
+
+
 @pytest.mark.parametrize("env", ["I2V_DEC_WINO", "I2V_DEC_WINO4", "I2V_DEC_PW16", "I2V_DEC_IMG16", "I2V_DEC_SPW"])
 def test_decoder_alternative_kernel_paths(env, monkeypatch):
     """The kernels the split-fp16 mode picks by default each have a tested fallback behind an env switch read when the
