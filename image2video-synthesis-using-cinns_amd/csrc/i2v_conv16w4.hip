@@ -1035,7 +1035,10 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     {
         int TT2 = 1, TH2 = 1;
         const char* ep_ = getenv("I2V_W4_PIPE");
-        if (BN == 32 && wts.KT != 1 && env_nth != 512 && !(ep_ && atoi(ep_) != 0) &&
+        // Default: only the layers that HAVE 32 output channels (g_4 of the 128 x 128 configs: +3 % on 32 -> 32, +-0 on 64 -> 32,
+        // profiles/r05_c_*); 64-channel layers narrowed for a small grid keep the 512-thread geometry (-2 % at B = 8 with 256).
+        // I2V_W4_NTH=256 forces the 256-thread geometry wherever the brick fits, 512 forbids it.
+        if (BN == 32 && wts.KT != 1 && env_nth != 512 && (a.CoutPad % 64 != 0 || env_nth == 256) && !(ep_ && atoi(ep_) != 0) &&
             wino4_tiling(T, H, W, wts.KT, &TT2, &TH2, W4Geo<256>::TILES, W4Geo<256>::ROWS_A, W4Geo<256>::ROWS_B)) {
             thin = true; TT = TT2; TH = TH2;
         }

@@ -657,7 +657,7 @@ struct i2v_dec {
     int img16 = 2;  // split-fp16 mode: 2 fused matrix-core kernel (i2v_convimg.hip), 1 round 2's 81-plane GEMM + gather at nf >= 64, 0 vector-ALU kernel (env I2V_DEC_IMG16)
     int wino4 = 1; // 1: F(4,3) Winograd kernel where the shape allows and one sample gives >= 32 workgroups (env I2V_DEC_WINO4=0: F(2,3); 2: wherever the shape allows)
     int spw = 1;   // 1: SPADE's gamma|beta conv uses the Winograd kernel where the shape allows (env I2V_DEC_SPW=0: direct kernel)
-    int wino32 = 1;  // exact-fp32 mode (mma = 0): 1 = 3x3x3 convs from the 16x16 level on run Winograd F(4,3) on the fp32 matrix cores (env I2V_DEC_WINO32=0: direct kernel)
+    int wino32 = 1;  // exact-fp32 mode (mma = 0): 1 = 3x3x3 convs from the 8x8 level on run Winograd F(4,3) on the fp32 matrix cores (env I2V_DEC_WINO32=0: direct kernel)
     const float* prep_img = nullptr;   // i2v_dec_prepare: the start frames whose SPADE branches are in the workspace's gbs[] ...
     int prep_B = 0;                    // ... their batch, image size and the workspace they live in (consumed by the next matching forward)
     int prep_h = 0, prep_w = 0;
@@ -1281,7 +1281,7 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         } else {
             if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
             if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
-            // from the 16x16 level on: Winograd F(4,3) on the fp32 matrix cores (half the MFMA work of the 27-tap kernel)
+            // from the 8x8 level on: Winograd F(4,3) on the fp32 matrix cores (half the MFMA work of the 27-tap kernel)
             if (want_wf_0(d, b, d->lvl[k]) && (rc = sn_pack_wf(sd, p + "conv_0", sn, b.n_mid, b.n_in, b.conv0_wf))) return rc;
             if (want_wf_1(d, b, d->lvl[k]) && (rc = sn_pack_wf(sd, p + "conv_1", sn, b.n_out, b.n_mid, b.conv1_wf))) return rc;
         }

@@ -1,5 +1,5 @@
 // 3x3x3 Conv3d in exact-fp32 mode (cfg.mma == 0) with a Winograd F(4,3) transform along W on the fp32 matrix cores.
-// Replaces conv_0 / conv_1 of GeneratorBlock (decoder.py:14-15, 37-40) from the 16x16 level on when the decoder runs with mma = 0,
+// Replaces conv_0 / conv_1 of GeneratorBlock (decoder.py:14-15, 37-40) from the 8x8 level on when the decoder runs with mma = 0,
 // the mode a checkpoint needs whose activations leave the fp16 range of the split-fp16 operands: no fp16
 // value exists anywhere on this path.  The direct fp32 kernel (i2v_conv.hip) costs 9.3x the split-fp16 step; F(4,3) halves its
 // MFMA work.
@@ -159,9 +159,9 @@ int shift_of(int f) { return f == 4 ? 2 : f == 2 ? 1 : 0; }
 
 bool wino4f32_supported(int cout, int cin, int T, int H, int W) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    // (the plane convs run conv_mfma_f32_kernel on [T][H][W/4] maps: its bricks need power-of-two dims; below 16 columns a tile row
-    //  would be 1-3 tiles wide and the 27-tap kernel on the tiny map is as fast)
-    return cout % 4 == 0 && cin % 4 == 0 && W % 4 == 0 && W >= 16 && pow2(T) && pow2(H) && pow2(W) && (long)T * H * (W / 4) >= CONV_BM;
+    // (the plane convs run conv_mfma_f32_kernel on [T][H][W/4] maps: its bricks need power-of-two dims and span samples where a
+    //  sample's map is smaller than a brick; 4x4 maps -- one tile per row, two of its six positions padding -- stay on the 27-tap kernel)
+    return cout % 4 == 0 && cin % 4 == 0 && W % 4 == 0 && W >= 8 && pow2(T) && pow2(H) && pow2(W);
 }
 
 int Wino4F32Weights::pack(const float* w_src, const float* bias_src, int cout, int cin, double scale) {
