@@ -669,9 +669,21 @@ struct i2v_dec {
     int device = 0;             // the device the packed weights live on
     int* status_dev = nullptr;  // sticky range flag of the hl16 producers (device) ...
     int* status_host = nullptr; // ... and its pinned host mirror, refreshed asynchronously at the end of every forward
+    // In-call overlap (round 5): the SPADE conditioning branches of all six blocks depend on the start frames only, so a forward
+    // that finds no prepared maps runs them on the handle's own side stream (forked from the caller's stream by an event) while the
+    // caller's stream computes fc / ADAIN linears / head_0 / g_0 ... -- the early levels' launches leave most of the chip idle
+    // (4x4 .. 16x16 maps), the branches of the late levels fill it.  Every block waits for its level's event; same kernels, same
+    // bits.  env I2V_DEC_OVERLAP=0: the branches run inline on the caller's stream (round 4).
+    int overlap = 1;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_lvl[6] = {};
     ~i2v_dec() {
         if (status_dev) (void)hipFree(status_dev);
         if (status_host) (void)hipHostFree(status_host);
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (auto& e : ev_lvl)
+            if (e) (void)hipEventDestroy(e);
     }
     int profile = 0;
     struct ProfEv { hipEvent_t e0, e1; double flops, exec_flops; int layer; };
@@ -1210,6 +1222,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_WINO32")) d->wino32 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_OVERLAP")) d->overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_SUB")) d->sub = std::max(0, std::atoi(e));
     if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
@@ -1482,8 +1495,38 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
     bool x_stats_ready = false;
     double* sums3 = reinterpret_cast<double*>(ws + L.sums3);
     // SPADE branches computed ahead by i2v_dec_prepare for exactly these start frames (same pointer, batch, size, workspace)?
-    const bool prepared = prep_img == img && d->prep_B == B && d->prep_h == img_h && d->prep_w == img_w && d->prep_ws == workspace &&
-                          d->prep_bstride == img_bstride;
+    bool prepared = prep_img == img && d->prep_B == B && d->prep_h == img_h && d->prep_w == img_w && d->prep_ws == workspace &&
+                    d->prep_bstride == img_bstride;
+    // No prepared maps: compute them on the handle's side stream, underneath the first levels (see i2v_dec::overlap).  Not while the
+    // caller captures a graph (the fork would have to be part of it), not with the debug tap on (it reads scratch of the inline path).
+    bool forked = false;
+    if (!prepared && d->overlap && !d->tap_dst) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+        if (cs == hipStreamCaptureStatusNone) {
+            if (!d->side) {
+                I2V_HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+                I2V_HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+                for (auto& e : d->ev_lvl) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            // everything the caller enqueued before this call (the start frames, the previous forward on this workspace) is complete
+            // before the side stream touches the workspace
+            I2V_HIP_CHECK(hipEventRecord(d->ev_fork, st));
+            I2V_HIP_CHECK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+            int rcs = I2V_OK;
+            for (int k = 0; k < 6 && !rcs; ++k) {
+                rcs = spade_branch(d, d->blk[k], d->lvl[k], img, img_h, img_w, B, F(L.py0), F(L.py1), L.has_y1v ? F(L.py1v) : nullptr, F(L.gbs[k]), d->side);
+                if (!rcs && hipEventRecord(d->ev_lvl[k], d->side) != hipSuccess) rcs = I2V_E_HIP;
+            }
+            // (join on every path: the caller's stream must never run ahead of work this call put on the side stream)
+            if (rcs) { (void)hipStreamSynchronize(d->side); return rcs; }
+            forked = prepared = true;
+        }
+    }
+    struct Join {   // an error return below must not leave the caller's stream ahead of the side stream's work on its buffers
+        i2v_dec* d; hipStream_t st; bool on;
+        ~Join() { if (on) (void)hipStreamWaitEvent(st, d->ev_lvl[5], 0); }
+    } join{d, st, forked};
     for (int k = 0; k < 6; ++k) {
         const Block& b = d->blk[k];
         const Level& l = d->lvl[k];
@@ -1496,6 +1539,10 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
         if (d->sub > 0 && k >= 4 && (long)l.T * l.H * l.W >= 65536) nsub = std::min(B, d->sub);
         const long Pl = (long)(l.T / l.ut) * (l.H / l.us) * (l.W / l.us), P = (long)l.T * l.H * l.W;
         bool ready_out = x_stats_ready;
+        if (forked) {   // this level's gamma | beta maps are complete
+            I2V_HIP_CHECK(hipStreamWaitEvent(st, d->ev_lvl[k], 0));
+            if (k == 5) join.on = false;
+        }
         for (int s0 = 0; s0 < B; s0 += nsub) {
             const int n = std::min(nsub, B - s0);
             BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, s_in + (size_t)s0 * b.n_in * 2, sums2, s_out + (size_t)s0 * b.n_out * 2,

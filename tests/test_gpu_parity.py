@@ -365,6 +365,34 @@ def test_f43_tile_width_switch_across_batches():
         assert torch.equal(gen(x0[lo:hi].contiguous(), z[lo:hi].contiguous()), big[lo:hi]), (lo, hi)
 
 
+@pytest.mark.parametrize("golden", ["dec_nf8_bair", "dec_nf32_128"])
+def test_decoder_in_call_spade_overlap_keeps_the_bits(golden, monkeypatch):
+    """Round 5: a forward that finds no prepared maps runs the SPADE branches of all six blocks on the handle's own side stream
+    underneath its first levels (I2V_DEC_OVERLAP=0: inline, round 4).  Same kernels: the frames must be the same bits -- also when
+    forwards with DIFFERENT start frames follow each other back to back on one handle and workspace (the next call's branches may not
+    overwrite maps the previous call still reads), on a non-default stream, and mixed with explicitly prepared calls."""
+    g, meta = load_golden(golden)
+    monkeypatch.setenv("I2V_DEC_OVERLAP", "0")
+    inline = _gen(meta)
+    monkeypatch.delenv("I2V_DEC_OVERLAP")
+    gen = _gen(meta)
+    img, z = cu(g["img"]), cu(g["z"])
+    imgs = [img, (img * 0.5 - 0.2).contiguous(), img.flip(-1).contiguous()]
+    refs = [inline(x, z) for x in imgs]
+    outs = [gen(imgs[i % 3], z) for i in range(12)]              # enqueued back to back, no host synchronisation in between
+    for i, o in enumerate(outs):
+        assert torch.equal(o, refs[i % 3]), i
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        o2 = [gen(imgs[i % 3], z) for i in range(4)]
+    torch.cuda.current_stream().wait_stream(side)
+    gen.prepare(imgs[1])
+    o3 = gen(imgs[1], z)
+    o4 = gen(imgs[2], z)
+    assert all(torch.equal(o2[i], refs[i % 3]) for i in range(4)) and torch.equal(o3, refs[1]) and torch.equal(o4, refs[2])
+
+
 def test_decoder_prepare_equals_plain_forward():
     """i2v_dec_prepare (Generator.prepare): the SPADE branches of all blocks computed ahead of the forward -- the next forward
     with the same start-frame tensor must give the same bits as a plain one; a forward with ANOTHER tensor in between must
