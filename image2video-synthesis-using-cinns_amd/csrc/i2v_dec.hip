@@ -662,6 +662,7 @@ struct i2v_dec {
     int prep_B = 0;                    // ... their batch, image size and the workspace they live in (consumed by the next matching forward)
     int prep_h = 0, prep_w = 0;
     long prep_bstride = 0;
+    bool prep_forked = false;          // the prepared maps are being computed on the handle's side stream (ev_lvl[k] mark them complete)
     const void* prep_ws = nullptr;
     long img_bstride = 0;              // floats between the samples of the current call's start frames (0: dense [B][3][H][W])
     int sub = 0;   // samples per sub-batch of the last two levels (env I2V_DEC_SUB; 0: the whole batch per launch)
@@ -1448,6 +1449,39 @@ int i2v_dec_get_layer_profile(i2v_dec* d, int32_t layer, char* name, int32_t nam
     return I2V_OK;
 }
 
+}  // extern "C"
+
+// The SPADE conditioning branches of all six blocks on the handle's side stream, forked from `st` by an event (everything the
+// caller enqueued on `st` before -- the start frames, an earlier forward on this workspace -- is complete before the side stream
+// touches the workspace); one event per level for the consumer.  *done = false: not possible here (graph capture on `st`, debug tap
+// active, overlap switched off) -- the caller runs the branches inline.
+static int fork_spade(i2v_dec* d, const DecWs& L, char* ws, const float* img, int img_h, int img_w, int B, hipStream_t st, bool* done) {
+    *done = false;
+    if (!d->overlap || d->tap_dst) return I2V_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return I2V_OK; }
+    if (cs != hipStreamCaptureStatusNone) return I2V_OK;
+    if (!d->side) {
+        I2V_HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+        I2V_HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+        for (auto& e : d->ev_lvl) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    I2V_HIP_CHECK(hipEventRecord(d->ev_fork, st));
+    I2V_HIP_CHECK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+    int rc = I2V_OK;
+    for (int k = 0; k < 6 && !rc; ++k) {
+        rc = spade_branch(d, d->blk[k], d->lvl[k], img, img_h, img_w, B, F(L.py0), F(L.py1), L.has_y1v ? F(L.py1v) : nullptr, F(L.gbs[k]), d->side);
+        if (!rc && hipEventRecord(d->ev_lvl[k], d->side) != hipSuccess) rc = I2V_E_HIP;
+    }
+    // (an error must not leave the caller's stream ahead of work this call put on the side stream)
+    if (rc) { (void)hipStreamSynchronize(d->side); return rc; }
+    *done = true;
+    return I2V_OK;
+}
+
+extern "C" {
+
 int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, const float* motion, float* out,
                     void* workspace, size_t workspace_bytes, int32_t batch, void* stream) {
     return i2v_dec_forward_strided(d, img, img_h, img_w, 0, motion, out, 0, workspace, workspace_bytes, batch, stream);
@@ -1497,31 +1531,12 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
     // SPADE branches computed ahead by i2v_dec_prepare for exactly these start frames (same pointer, batch, size, workspace)?
     bool prepared = prep_img == img && d->prep_B == B && d->prep_h == img_h && d->prep_w == img_w && d->prep_ws == workspace &&
                     d->prep_bstride == img_bstride;
-    // No prepared maps: compute them on the handle's side stream, underneath the first levels (see i2v_dec::overlap).  Not while the
-    // caller captures a graph (the fork would have to be part of it), not with the debug tap on (it reads scratch of the inline path).
-    bool forked = false;
-    if (!prepared && d->overlap && !d->tap_dst) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
-        if (cs == hipStreamCaptureStatusNone) {
-            if (!d->side) {
-                I2V_HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
-                I2V_HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
-                for (auto& e : d->ev_lvl) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
-            // everything the caller enqueued before this call (the start frames, the previous forward on this workspace) is complete
-            // before the side stream touches the workspace
-            I2V_HIP_CHECK(hipEventRecord(d->ev_fork, st));
-            I2V_HIP_CHECK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
-            int rcs = I2V_OK;
-            for (int k = 0; k < 6 && !rcs; ++k) {
-                rcs = spade_branch(d, d->blk[k], d->lvl[k], img, img_h, img_w, B, F(L.py0), F(L.py1), L.has_y1v ? F(L.py1v) : nullptr, F(L.gbs[k]), d->side);
-                if (!rcs && hipEventRecord(d->ev_lvl[k], d->side) != hipSuccess) rcs = I2V_E_HIP;
-            }
-            // (join on every path: the caller's stream must never run ahead of work this call put on the side stream)
-            if (rcs) { (void)hipStreamSynchronize(d->side); return rcs; }
-            forked = prepared = true;
-        }
+    // Prepared on the side stream (i2v_dec_prepare), or not prepared at all: then compute the maps on the handle's side stream now,
+    // underneath the first levels (see i2v_dec::overlap).  Either way every block waits for its level's event.
+    bool forked = prepared && d->prep_forked;
+    if (!prepared) {
+        if (int rcf = fork_spade(d, L, ws, img, img_h, img_w, B, st, &forked)) return rcf;
+        prepared = forked;
     }
     struct Join {   // an error return below must not leave the caller's stream ahead of the side stream's work on its buffers
         i2v_dec* d; hipStream_t st; bool on;
@@ -1593,9 +1608,15 @@ int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     d->prep_img = nullptr;
     d->img_bstride = 0;
-    for (int k = 0; k < 6; ++k)
-        if (int rc = spade_branch(d, d->blk[k], d->lvl[k], img, img_h, img_w, B, F(L.py0), F(L.py1), L.has_y1v ? F(L.py1v) : nullptr, F(L.gbs[k]), st))
-            return rc;
+    // on the handle's side stream where possible (ordered behind everything already on `st`): the caller's stream stays free for
+    // whatever it can do meanwhile, and the consuming forward waits per level; else inline on `st`
+    bool forked = false;
+    if (int rc = fork_spade(d, L, ws, img, img_h, img_w, B, st, &forked)) return rc;
+    if (!forked)
+        for (int k = 0; k < 6; ++k)
+            if (int rc = spade_branch(d, d->blk[k], d->lvl[k], img, img_h, img_w, B, F(L.py0), F(L.py1), L.has_y1v ? F(L.py1v) : nullptr, F(L.gbs[k]), st))
+                return rc;
+    d->prep_forked = forked;
     d->prep_img = img; d->prep_B = B; d->prep_h = img_h; d->prep_w = img_w; d->prep_ws = workspace;
     d->prep_bstride = (long)3 * img_h * img_w;
     return I2V_OK;

@@ -359,9 +359,9 @@ class NativeDecoder(_Handle):
 
     @_on_device
     def prepare(self, img):
-        """i2v_dec_prepare: enqueue the SPADE branches of all six blocks (they depend on the start frame only) on the current
-        stream; the next ``forward`` with the SAME tensor (same storage, batch, size) skips them.  Meant for a side stream
-        underneath the cINN pass; the caller orders the streams."""
+        """i2v_dec_prepare: enqueue the SPADE branches of all six blocks (they depend on the start frame only) on the HANDLE's side
+        stream, ordered behind everything already on the current stream; the next ``forward`` with the SAME tensor (same storage,
+        batch, size) waits for them per level instead of computing them.  The current stream stays free (e.g. for the cINN pass)."""
         _require_gpu(img)
         B = img.shape[0]
         if img.dim() != 4 or img.shape[1] != 3:

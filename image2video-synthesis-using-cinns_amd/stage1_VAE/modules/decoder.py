@@ -94,6 +94,7 @@ class Generator(NativeBacked):
 
     def prepare(self, img):
         """Not a reference method: enqueue the SPADE branches of all blocks for the start frames ``img`` (they do not depend on
-        the motion latent) on the current stream.  The next ``forward(img, z)`` with the SAME contiguous tensor skips them
+        the motion latent) on the native handle's side stream, behind what is already on the current stream.  The next
+        ``forward(img, z)`` with the SAME contiguous tensor waits for them level by level instead of computing them
         (i2v_dec_prepare); ``get_model.Model.synthesize`` uses it to fill the time the cINN pass takes."""
         self.native().prepare(img.contiguous())

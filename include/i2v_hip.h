@@ -175,7 +175,11 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
  * successful or not (I2V_E_RANGE of the previous call, bad arguments, workspace too small) -- consumes or discards it before
  * anything else.  The identity test is by address: the CONTENTS of img must not change between the prepare and its forward;
  * a caller that refills the buffer in place calls i2v_dec_prepare_cancel (the Python binding does, keyed on the tensor's
- * version counter).  Same kernels, same bits. */
+ * version counter).  Same kernels, same bits.
+ * Since round 5 the branches are enqueued on a side stream the HANDLE owns, ordered behind everything already on `stream` (an event),
+ * and the consuming forward waits per level (events): the caller's stream stays free, e.g. for the cINN pass, and needs no stream
+ * of its own for this.  (While `stream` captures a graph, with I2V_DEC_OVERLAP=0 or the debug tap on they run inline on `stream`.)
+ * A forward WITHOUT prepared maps forks its own branches the same way, underneath its first levels. */
 int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, void* workspace, size_t workspace_bytes,
                     int32_t batch, void* stream);
 /* Drops a pending prepare (no-op without one). */
