@@ -676,9 +676,18 @@ struct i2v_dec {
     // (4x4 .. 16x16 maps), the branches of the late levels fill it.  Every block waits for its level's event; same kernels, same
     // bits.  env I2V_DEC_OVERLAP=0: the branches run inline on the caller's stream (round 4).
     int overlap = 1;
+    int no_side_shortcut = 0;   // env I2V_DEC_OVERLAP=2: branches on the side stream, shortcuts inline (A/B of the two halves)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_lvl[6] = {};
+    // ... and the learned shortcut of a block (Norm3D + 1x1x1 conv at the low resolution: an HBM-bound GEMM that only conv_1 needs)
+    // runs there too, underneath the block's modulate / conv_0 chain: ev_x[k] = block input and its statistics complete (caller's
+    // stream), ev_s[k] = shortcut complete (side stream)
+    hipEvent_t ev_x[6] = {}, ev_s[6] = {};
     ~i2v_dec() {
+        for (auto& e : ev_x)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_s)
+            if (e) (void)hipEventDestroy(e);
         if (status_dev) (void)hipFree(status_dev);
         if (status_host) (void)hipHostFree(status_host);
         if (side) (void)hipStreamDestroy(side);
@@ -707,6 +716,7 @@ struct DecWs {
     size_t xA, xB, a, dx, xs_in, xs_low, y0, y1, gb, zl, sums1, sums2, sums3, coef, splitk, splitk_floats, y1v, total;
     size_t gbs[6], py0, py1, py1v;   // i2v_dec_prepare: one gamma|beta buffer per level and its own SPADE scratch
     size_t m6 = 0;                   // exact-fp32 Winograd: the six partial outputs M_x of one conv
+    size_t coef_s = 0;
     bool has_y1v = false;
 };
 
@@ -761,6 +771,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
     L.sums1 = take((size_t)B * cmax * 4); L.sums2 = take((size_t)B * cmax * 4);  // doubles: 2 per channel
     L.sums3 = take((size_t)B * cmax * 4);   // block output statistics (sums1 / sums3 alternate as a block's input / output statistics)
     L.coef = take((size_t)B * cmax * 2);
+    L.coef_s = take((size_t)B * cmax * 2);   // the shortcut's Norm3D coefficients when it runs on the side stream
     {   // split-K scratch of the direct conv kernel (the tiny feature maps of head_0 / g_0): its partial copies of the output
         size_t mx = 0;
         for (int k = 0; k < 6; ++k) {
@@ -972,6 +983,8 @@ struct BlockBufs {
     float* y1v = nullptr;         // Winograd operand of SPADE's 128-channel activation (2 x the size of y1; optional)
     const float* gb_ready = nullptr;   // this block's gamma | beta, already computed by i2v_dec_prepare
     float* m6 = nullptr;          // exact-fp32 Winograd scratch (six partial outputs); null: the direct kernel is used
+    hipStream_t side = nullptr;   // the learned shortcut runs on this stream (events ev_x / ev_s of the handle), with coef_s
+    float* coef_s = nullptr;
 };
 
 // SPADE's conditioning branch of one block (normalization_layer.py:20-23): resize(start frame) -> Conv2d(3, 128) + lrelu ->
@@ -1026,6 +1039,20 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // already in sums1 when the previous block's conv_1 accumulated them in its epilogue
     if (!x_stats_ready && (rc = run_stats(x, sums1, B, Pl, b.n_in, st))) return rc;
     if ((rc = run_coef(sums1, coef, B, b.n_in, b.groups_spade, (double)Pl, nullptr, 0, 0, nullptr, nullptr, st))) return rc;
+    // The learned shortcut depends on the block input and its statistics only: on the side stream it runs underneath the
+    // modulate / conv_0 / modulate chain below (an HBM-bound GEMM next to matrix-core-bound convs); conv_1 waits for it.
+    const bool side_shortcut = b.learned && w.side && w.coef_s && k < 6 && d->ev_x[k];
+    if (side_shortcut) {
+        I2V_HIP_CHECK(hipEventRecord(d->ev_x[k], st));
+        I2V_HIP_CHECK(hipStreamWaitEvent(w.side, d->ev_x[k], 0));
+        int rs_ = run_coef(sums1, w.coef_s, B, b.n_in, 16, (double)Pl, nullptr, 0, 0, b.gn_w.as<float>(), b.gn_b.as<float>(), w.side);
+        if (!rs_) {
+            if (b.convs16.w.p) rs_ = pointwise16_forward(b.convs16, x, xs_low, nullptr, (long)B * Pl, Pl, EPI_NONE, w.side, w.coef_s, d->status_dev);
+            else rs_ = conv_forward(b.convs, x, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, w.side, w.coef_s);
+        }
+        if (!rs_ && hipEventRecord(d->ev_s[k], w.side) != hipSuccess) rs_ = I2V_E_HIP;
+        if (rs_) { (void)hipStreamSynchronize(w.side); return rs_; }
+    }
     // SPADE branch (normalization_layer.py:20-23): depends on the start frame only -- either computed here, or already there
     // (w.gb_ready: i2v_dec_prepare ran it, typically on a side stream underneath the cINN pass)
     if (w.gb_ready) gb = const_cast<float*>(w.gb_ready);
@@ -1068,7 +1095,7 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     if (!f1 && (rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
     // shortcut (decoder.py:44-49) at low resolution
     const float* res = x;
-    if (b.learned) {
+    if (b.learned && !side_shortcut) {
         if ((rc = run_coef(sums1, coef, B, b.n_in, 16, (double)Pl, nullptr, 0, 0, b.gn_w.as<float>(), b.gn_b.as<float>(), st)))
             return rc;
         // Norm3D folded into the 1x1x1 conv's loads (no padding taps -> exact): no normalised copy of x is written
@@ -1078,6 +1105,9 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
         if (rc) return rc;
         res = xs_low;
         if ((rc = tap(k, 4, xs_low, (size_t)B * Pl * b.n_out))) return rc;
+    } else if (b.learned) {
+        res = xs_low;
+        I2V_HIP_CHECK(hipStreamWaitEvent(st, d->ev_s[k], 0));   // enqueued on the side stream at the top of the block
     }
     // g_4's output only feeds conv_img(leaky_relu(x)) (decoder.py:117): fuse the activation here
     // (the shortcut's coefficients were derived from sums1 above, so conv_1 may now overwrite sums1 with the
@@ -1223,7 +1253,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_WINO32")) d->wino32 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("I2V_DEC_OVERLAP")) d->overlap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_OVERLAP")) { d->overlap = std::atoi(e) != 0; d->no_side_shortcut = std::atoi(e) == 2; }
     if (const char* e = std::getenv("I2V_DEC_SUB")) d->sub = std::max(0, std::atoi(e));
     if (int rc = init_status(d.get())) return rc;
     const int nf = d->nf = cfg->channel_factor;
@@ -1465,6 +1495,8 @@ static int fork_spade(i2v_dec* d, const DecWs& L, char* ws, const float* img, in
         I2V_HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
         I2V_HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
         for (auto& e : d->ev_lvl) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : d->ev_x) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : d->ev_s) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     I2V_HIP_CHECK(hipEventRecord(d->ev_fork, st));
@@ -1563,7 +1595,8 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
             BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, s_in + (size_t)s0 * b.n_in * 2, sums2, s_out + (size_t)s0 * b.n_out * 2,
                            F(L.splitk), L.splitk_floats, L.has_y1v ? F(L.y1v) : nullptr,
                            prepared ? F(L.gbs[k]) + (size_t)s0 * l.H * l.W * 2 * b.n_in : nullptr,
-                           d->cfg.mma == 0 && d->wino32 ? F(L.m6) : nullptr};
+                           d->cfg.mma == 0 && d->wino32 ? F(L.m6) : nullptr,
+                           forked && nsub == B && d->overlap >= 1 && !d->no_side_shortcut ? d->side : nullptr, F(L.coef_s)};
             bool ready = x_stats_ready;
             if ((rc = block_forward(d, k, d->blk[k], l, x + (size_t)s0 * Pl * b.n_in, xn + (size_t)s0 * P * b.n_out,
                                     img + (size_t)s0 * (size_t)img_bstride, img_h, img_w, zl + (size_t)s0 * d->Nz, d->Nz, n, bufs, ready, k == 5, st)))
