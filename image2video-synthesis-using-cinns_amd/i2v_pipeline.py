@@ -11,6 +11,8 @@ runs on a high-priority side stream underneath the decoder pass(es) of batch k.
 
 Every batch still gets exactly one cINN pass and one decoder run; only the order of enqueueing changes, and the latent
 draws keep the order of the serial loop."""
+import os
+
 import torch
 
 
@@ -18,7 +20,10 @@ class LatentPrefetcher:
     def __init__(self, latent_fn, device=None, enabled=True):
         self.latent_fn = latent_fn
         self.enabled = bool(enabled) and torch.cuda.is_available()
-        self.stream = torch.cuda.Stream(device=device, priority=-1) if self.enabled else None
+        # high priority: the chain's 82 small dependent launches get their workgroups dispatched in front of the decoder's big grids
+        # (I2V_PREFETCH_PRIO=0: same priority as the caller's stream, for A/B runs)
+        prio = int(os.environ.get("I2V_PREFETCH_PRIO", "-1"))
+        self.stream = torch.cuda.Stream(device=device, priority=prio) if self.enabled else None
 
     def submit(self, *args, **kwargs):
         """Enqueue ``latent_fn(*args)`` on the side stream (after everything already enqueued on the current stream, so
