@@ -677,12 +677,6 @@ struct i2v_dec {
     // bits.  env I2V_DEC_OVERLAP=0: the branches run inline on the caller's stream (round 4).
     int overlap = 1;
     int no_side_shortcut = 0;   // env I2V_DEC_OVERLAP=2: branches on the side stream, shortcuts inline (A/B of the two halves)
-    // Dual-stream levels (env I2V_DEC_DUAL=1, round 5 experiment): at the levels whose one sample fills the chip the two HALVES of the
-    // batch run the block's launch sequence on two streams (caller's + side), the second half one operand writer behind the first:
-    // a strictly dependent chain of HBM-bound writers and matrix-core-bound convs becomes two chains that are out of phase, so a
-    // writer of one half runs next to a conv of the other.  Every op is per sample: same bits.
-    int dual = 0;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_w0 = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_lvl[6] = {};
     // ... and the learned shortcut of a block (Norm3D + 1x1x1 conv at the low resolution: an HBM-bound GEMM that only conv_1 needs)
@@ -693,8 +687,6 @@ struct i2v_dec {
         for (auto& e : ev_x)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_s)
-            if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {ev_in, ev_out, ev_w0})
             if (e) (void)hipEventDestroy(e);
         if (status_dev) (void)hipFree(status_dev);
         if (status_host) (void)hipHostFree(status_host);
@@ -725,7 +717,6 @@ struct DecWs {
     size_t gbs[6], py0, py1, py1v;   // i2v_dec_prepare: one gamma|beta buffer per level and its own SPADE scratch
     size_t m6 = 0;                   // exact-fp32 Winograd: the six partial outputs M_x of one conv
     size_t coef_s = 0;
-    size_t per_a = 0, per_dx = 0, per_xslow = 0, per_c = 0;   // floats per sample of a / dx / xs_low, channels per sample of the coef / sums buffers
     bool has_y1v = false;
 };
 
@@ -794,7 +785,6 @@ DecWs dec_ws(const i2v_dec* d, int B) {
     for (int k = 0; k < 6; ++k) L.gbs[k] = take((size_t)B * d->lvl[k].H * d->lvl[k].W * 2 * d->blk[k].n_in);
     L.py0 = take(B * mx_y * 16); L.py1 = take(B * mx_y * 128); L.py1v = take(B * mx_yv * 256);
     L.m6 = take(B * mx_m6);   // exact-fp32 Winograd: the six partial outputs M_x
-    L.per_a = mx_a; L.per_dx = mx_dx; L.per_xslow = mx_xslow; L.per_c = (size_t)cmax;
     L.total = o;
     return L;
 }
@@ -995,8 +985,6 @@ struct BlockBufs {
     float* m6 = nullptr;          // exact-fp32 Winograd scratch (six partial outputs); null: the direct kernel is used
     hipStream_t side = nullptr;   // the learned shortcut runs on this stream (events ev_x / ev_s of the handle), with coef_s
     float* coef_s = nullptr;
-    hipEvent_t rec_w0 = nullptr;  // dual-stream levels: recorded behind this half's first operand writer ...
-    hipEvent_t wait_w0 = nullptr; // ... / waited for in front of it (the second half starts one writer behind the first)
 };
 
 // SPADE's conditioning branch of one block (normalization_layer.py:20-23): resize(start frame) -> Conv2d(3, 128) + lrelu ->
@@ -1079,14 +1067,12 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     int* um0 = f16 && flag ? flag + 1 + 2 * (k % 24) : nullptr;
     int* um1 = um0 ? um0 + 1 : nullptr;
     const bool f0 = w.m6 && use_wf_0(d, b, l), f1 = w.m6 && use_wf_1(d, b, l);   // exact-fp32 mode: Winograd F(4,3) on the fp32 matrix cores
-    if (w.wait_w0) I2V_HIP_CHECK(hipStreamWaitEvent(st, w.wait_w0, 0));
     if (f0) rc = modulate_wino4_f32(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st);
     else if (q0) rc = run_modulate_wino4(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
     else if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
     else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true, flag, um0);
     else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16, flag, um0);
     if (rc) return rc;
-    if (w.rec_w0) I2V_HIP_CHECK(hipEventRecord(w.rec_w0, st));
     if (!f0 && (rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
     const bool fuse = f16 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
     d->prof_cur_layer = 2 * k;
@@ -1267,7 +1253,6 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_WINO32")) d->wino32 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("I2V_DEC_DUAL")) d->dual = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_OVERLAP")) { d->overlap = std::atoi(e) != 0; d->no_side_shortcut = std::atoi(e) == 2; }
     if (const char* e = std::getenv("I2V_DEC_SUB")) d->sub = std::max(0, std::atoi(e));
     if (int rc = init_status(d.get())) return rc;
@@ -1512,7 +1497,6 @@ static int fork_spade(i2v_dec* d, const DecWs& L, char* ws, const float* img, in
         for (auto& e : d->ev_lvl) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : d->ev_x) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : d->ev_s) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (hipEvent_t* e : {&d->ev_in, &d->ev_out, &d->ev_w0}) I2V_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     I2V_HIP_CHECK(hipEventRecord(d->ev_fork, st));
@@ -1600,13 +1584,6 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
         // two levels) is still in the 256 MB Infinity Cache when the next launch reads it.  Every op is per sample: same bits.
         int nsub = B;
         if (d->sub > 0 && k >= 4 && (long)l.T * l.H * l.W >= 65536) nsub = std::min(B, d->sub);
-        // dual-stream level (see i2v_dec::dual): two halves, the second on the side stream one operand writer behind the first
-        const bool dual = d->dual && forked && nsub == B && B >= 2 && d->cfg.mma == 1 && (long)l.T * l.H * l.W >= (d->dual >= 2 ? 8192 : 65536);
-        if (dual) {
-            nsub = (B + 1) / 2;
-            I2V_HIP_CHECK(hipEventRecord(d->ev_in, st));              // block input + statistics (both halves) complete
-            I2V_HIP_CHECK(hipStreamWaitEvent(d->side, d->ev_in, 0));
-        }
         const long Pl = (long)(l.T / l.ut) * (l.H / l.us) * (l.W / l.us), P = (long)l.T * l.H * l.W;
         bool ready_out = x_stats_ready;
         if (forked) {   // this level's gamma | beta maps are complete
@@ -1615,28 +1592,16 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
         }
         for (int s0 = 0; s0 < B; s0 += nsub) {
             const int n = std::min(nsub, B - s0);
-            // (dual: the second half has its own slice of every scratch buffer -- they are sized per sample)
-            const size_t o = dual ? (size_t)s0 : 0;
-            BlockBufs bufs{a + o * L.per_a, dx + o * L.per_dx, xs_in, xs_low + o * L.per_xslow, y0, y1, gb, coef + o * L.per_c * 2,
-                           s_in + (size_t)s0 * b.n_in * 2, sums2 + o * L.per_c * 2, s_out + (size_t)s0 * b.n_out * 2,
+            BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, s_in + (size_t)s0 * b.n_in * 2, sums2, s_out + (size_t)s0 * b.n_out * 2,
                            F(L.splitk), L.splitk_floats, L.has_y1v ? F(L.y1v) : nullptr,
                            prepared ? F(L.gbs[k]) + (size_t)s0 * l.H * l.W * 2 * b.n_in : nullptr,
                            d->cfg.mma == 0 && d->wino32 ? F(L.m6) : nullptr,
                            forked && nsub == B && d->overlap >= 1 && !d->no_side_shortcut ? d->side : nullptr, F(L.coef_s)};
-            hipStream_t bst = st;
-            if (dual) {
-                if (s0 == 0) bufs.rec_w0 = d->ev_w0;
-                else { bufs.wait_w0 = d->ev_w0; bst = d->side; }
-            }
             bool ready = x_stats_ready;
             if ((rc = block_forward(d, k, d->blk[k], l, x + (size_t)s0 * Pl * b.n_in, xn + (size_t)s0 * P * b.n_out,
-                                    img + (size_t)s0 * (size_t)img_bstride, img_h, img_w, zl + (size_t)s0 * d->Nz, d->Nz, n, bufs, ready, k == 5, bst)))
+                                    img + (size_t)s0 * (size_t)img_bstride, img_h, img_w, zl + (size_t)s0 * d->Nz, d->Nz, n, bufs, ready, k == 5, st)))
                 return rc;
             ready_out = ready;
-        }
-        if (dual) {   // join: the next level (and conv_img) read both halves
-            I2V_HIP_CHECK(hipEventRecord(d->ev_out, d->side));
-            I2V_HIP_CHECK(hipStreamWaitEvent(st, d->ev_out, 0));
         }
         x_stats_ready = ready_out;
         std::swap(x, xn);
