@@ -158,20 +158,26 @@ constexpr int CM_NP = CM_HH * CM_HW;
 constexpr int CM_NB = (CM_NP + 31) / 32;             // 11 column blocks
 constexpr int CM_LD = CM_NB * 32;                    // 352 columns per plane row
 
+// Round 5: a workgroup keeps its 8 x 32 brick for TCH consecutive output frames and walks the INPUT frames t0 - 1 .. t0 + TCH:
+// every input frame is loaded and split into fp16 hi / lo ONCE (the per-element conversion was the kernel's largest cost: ~350
+// VALU instructions per lane and temporal tap against 18 MFMAs) and multiplied with the three temporal taps' weight slabs; tap dt
+// of input frame f belongs to output frame f + 1 - dt, so three output frames are in flight per thread and frame f - 1 is
+// finished behind input frame f.  An output frame still receives its taps in the order dt = 0, 1, 2 and its nine (dh, dw) terms
+// in the same order: the bits are those of the one-frame-per-workgroup kernel.
 template <int KS>   // KS = Cin / 16 k-steps
 __global__ __launch_bounds__(256) void conv_img_mfma_kernel(const float* __restrict__ in, const ci_half8* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ out, int B, int T,
-                                                            int H, int W, int* __restrict__ range_flag, long obs) {
+                                                            int H, int W, int* __restrict__ range_flag, long obs, int TCH) {
     __shared__ float Y[32 * CM_LD];
     bool bad = false;   // an activation left the fp16 range of its hi part (sticky flag like every other hl16 producer)
     constexpr int C = 16 * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
     int brick = blockIdx.x;
-    const int nbW = W / CM_TW, nbH = H / CM_TH;
+    const int nbW = W / CM_TW, nbH = H / CM_TH, nbT = T / TCH;
     const int bw = brick % nbW; brick /= nbW;
     const int bh = brick % nbH; brick /= nbH;
-    const int t = brick % T, b = brick / T;
+    const int t0 = (brick % nbT) * TCH, b = brick / nbT;
     const int h0 = bh * CM_TH, w0 = bw * CM_TW;
     // the halo positions of this lane's column blocks (blocks wave, wave + 4, wave + 8): offset inside a frame, or -1
     int gp[3];
@@ -184,66 +190,98 @@ __global__ __launch_bounds__(256) void conv_img_mfma_kernel(const float* __restr
         gp[u] = ok ? h * W + w : -1;
     }
     const int oh = tid >> 5, ow = tid & 31;              // this thread's output position inside the brick
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    for (int dt = 0; dt < 3; ++dt) {
-        const int tt = t + dt - 1;
-        if ((unsigned)tt >= (unsigned)T) continue;       // (uniform) zero padding in time
-        // A: the tap's weight slab, fragment-major [dt][ks][hi | lo][64 lanes]
-        ci_half8 ah[KS], al[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            ah[ks] = wp[((dt * KS + ks) * 2 + 0) * 64 + lane];
-            al[ks] = wp[((dt * KS + ks) * 2 + 1) * 64 + lane];
-        }
-        const float* fr = in + ((size_t)b * T + tt) * H * W * C + 8 * kg;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            if (wave + 4 * u >= CM_NB) continue;         // (uniform: wave 3 owns two blocks)
-            ci_f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            ci_f32x4 xv[KS][2];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    xv[ks][q] = gp[u] >= 0 ? *reinterpret_cast<const ci_f32x4*>(fr + (size_t)gp[u] * C + 16 * ks + 4 * q)
-                                           : ci_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                ci_half8 bh_, bl_;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = xv[ks][j >> 2][j & 3];
-                    const _Float16 hi = (_Float16)v;
-                    bad |= !(fabsf(v) <= 65504.f);
-                    bh_[j] = hi;
-                    bl_[j] = (_Float16)(v - (float)hi);
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh_, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl_, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh_, acc, 0, 0, 0);
-            }
-            const int col = (wave + 4 * u) * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-                Y[row * CM_LD + col] = acc[r];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int dh = 0; dh < 3; ++dh)
-#pragma unroll
-            for (int dw = 0; dw < 3; ++dw) {
-                const float* y = Y + ((dh * 3 + dw) * 3) * CM_LD + (oh + dh) * CM_HW + ow + dw;
-                o0 += y[0]; o1 += y[CM_LD]; o2 += y[2 * CM_LD];
-            }
-        __syncthreads();   // Y is overwritten by the next temporal tap
-    }
     const size_t HWo = (size_t)H * W;
-    float* o = out + (size_t)b * (size_t)obs + ((size_t)t * 3) * HWo + (size_t)(h0 + oh) * W + w0 + ow;   // obs: floats between the samples of `out`
-    o[0] = tanhf(o0 + bias[0]); o[HWo] = tanhf(o1 + bias[1]); o[2 * HWo] = tanhf(o2 + bias[2]);
+    const float c0_ = bias[0], c1_ = bias[1], c2_ = bias[2];
+    // the three output frames in flight: slot (t % 3)
+    float o[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    for (int f = t0 - 1; f <= t0 + TCH; ++f) {
+        if ((unsigned)f < (unsigned)T) {                 // (uniform) zero padding in time: a missing frame contributes nothing
+            // this input frame's halo positions, split into fp16 hi / lo once
+            const float* fr = in + ((size_t)b * T + f) * H * W * C + 8 * kg;
+            ci_half8 xh[3][KS], xl[3][KS];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (wave + 4 * u >= CM_NB) continue;     // (uniform: wave 3 owns two blocks)
+                ci_f32x4 xv[KS][2];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        xv[ks][q] = gp[u] >= 0 ? *reinterpret_cast<const ci_f32x4*>(fr + (size_t)gp[u] * C + 16 * ks + 4 * q)
+                                               : ci_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = xv[ks][j >> 2][j & 3];
+                        const _Float16 hi = (_Float16)v;
+                        bad |= !(fabsf(v) <= 65504.f);
+                        xh[u][ks][j] = hi;
+                        xl[u][ks][j] = (_Float16)(v - (float)hi);
+                    }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int t = f + 1 - dt;                // the output frame this tap of this input frame belongs to
+                if (t < t0 || t >= t0 + TCH) continue;   // (uniform)
+                // A: the tap's weight slab, fragment-major [dt][ks][hi | lo][64 lanes]
+                ci_half8 ah[KS], al[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    ah[ks] = wp[((dt * KS + ks) * 2 + 0) * 64 + lane];
+                    al[ks] = wp[((dt * KS + ks) * 2 + 1) * 64 + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (wave + 4 * u >= CM_NB) continue;
+                    ci_f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xh[u][ks], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], xl[u][ks], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], xh[u][ks], acc, 0, 0, 0);
+                    }
+                    const int col = (wave + 4 * u) * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        Y[row * CM_LD + col] = acc[r];
+                    }
+                }
+                __syncthreads();
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                const int slot = t % 3;
+                // (static register indexing: pick the slot's running sums, add the nine terms in the fixed order, put them back)
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl)
+                    if (sl == slot) { a0 = o[sl][0]; a1 = o[sl][1]; a2 = o[sl][2]; }
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const float* y = Y + ((dh * 3 + dw) * 3) * CM_LD + (oh + dh) * CM_HW + ow + dw;
+                        a0 += y[0]; a1 += y[CM_LD]; a2 += y[2 * CM_LD];
+                    }
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl)
+                    if (sl == slot) { o[sl][0] = a0; o[sl][1] = a1; o[sl][2] = a2; }
+                __syncthreads();   // Y is overwritten by the next tap
+            }
+        }
+        // output frame f - 1 has received its last tap (dt = 2 of input frame f, or nothing if f lies outside the clip)
+        const int td = f - 1;
+        if (td >= t0 && td < t0 + TCH) {
+            const int slot = td % 3;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl)
+                if (sl == slot) { a0 = o[sl][0]; a1 = o[sl][1]; a2 = o[sl][2]; o[sl][0] = 0.f; o[sl][1] = 0.f; o[sl][2] = 0.f; }
+            float* op = out + (size_t)b * (size_t)obs + ((size_t)td * 3) * HWo + (size_t)(h0 + oh) * W + w0 + ow;   // obs: floats between the samples of `out`
+            op[0] = tanhf(a0 + c0_); op[HWo] = tanhf(a1 + c1_); op[2 * HWo] = tanhf(a2 + c2_);
+        }
+    }
     if (bad && range_flag) atomicOr(range_flag, 1);
 }
 
@@ -278,16 +316,26 @@ int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float*
                           int* range_flag, long out_bstride) {
     I2V_REQUIRE(wts.w.p, I2V_E_STATE, "conv_img (MFMA): weights not packed");
     I2V_REQUIRE(conv_img_mfma_supported(T, H, W, wts.Cin), I2V_E_INVALID, "conv_img (MFMA): unsupported geometry");
-    const long nblk = (long)B * T * (H / CM_TH) * (W / CM_TW);
+    // frames per workgroup: as many as still leave ~2 waves of workgroups per CU slot (3 workgroups of 45 KB LDS per CU); a chunk of
+    // TCH output frames reads TCH + 2 input frames.  Depends on the batch, which changes the schedule only (same bits: see the kernel).
+    int TCH = 1;
+    {
+        const char* e = getenv("I2V_CONVIMG_TCH");
+        const long bricks = (long)B * (H / CM_TH) * (W / CM_TW);
+        for (int c = 16; c >= 2; c /= 2)
+            if (T % c == 0 && bricks * (T / c) >= 2 * 768) { TCH = c; break; }
+        if (e && atoi(e) > 0 && T % atoi(e) == 0) TCH = atoi(e);
+    }
+    const long nblk = (long)B * (T / TCH) * (H / CM_TH) * (W / CM_TW);
     I2V_REQUIRE(nblk < (1L << 31), I2V_E_INVALID, "conv_img (MFMA): %ld workgroups", nblk);
     const dim3 grid((unsigned)nblk), block(256);
     const ci_half8* wp = wts.w.as<ci_half8>();
     const long obs = out_bstride ? out_bstride : (long)T * 3 * H * W;
     switch (wts.Cin / 16) {
-        case 1: hipLaunchKernelGGL(conv_img_mfma_kernel<1>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs); break;
-        case 2: hipLaunchKernelGGL(conv_img_mfma_kernel<2>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs); break;
-        case 3: hipLaunchKernelGGL(conv_img_mfma_kernel<3>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs); break;
-        default: hipLaunchKernelGGL(conv_img_mfma_kernel<4>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs); break;
+        case 1: hipLaunchKernelGGL(conv_img_mfma_kernel<1>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs, TCH); break;
+        case 2: hipLaunchKernelGGL(conv_img_mfma_kernel<2>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs, TCH); break;
+        case 3: hipLaunchKernelGGL(conv_img_mfma_kernel<3>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs, TCH); break;
+        default: hipLaunchKernelGGL(conv_img_mfma_kernel<4>, grid, block, 0, st, in, wp, wts.bias.as<float>(), out, B, T, H, W, range_flag, obs, TCH); break;
     }
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;

@@ -340,7 +340,7 @@ def test_f43_structure_switches_keep_the_bits(golden, monkeypatch):
     x0, z = x0.cuda(), z.cuda()
     ref = _gen(meta)(x0, z)
     assert rel_l2(ref[1:2, ..., ::2, ::2].cpu(), g["out_s2"]) < TOL
-    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_PIPE", "2"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"), ("I2V_W4_NTH", "512"), ("I2V_W4_NTH", "256"), ("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2"), ("I2V_DEC_OVERLAP", "0"), ("I2V_DEC_OVERLAP", "2")):
+    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_PIPE", "2"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"), ("I2V_W4_NTH", "512"), ("I2V_W4_NTH", "256"), ("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2"), ("I2V_DEC_OVERLAP", "0"), ("I2V_DEC_OVERLAP", "2"), ("I2V_CONVIMG_TCH", "1"), ("I2V_CONVIMG_TCH", "2"), ("I2V_CONVIMG_TCH", "16")):
         monkeypatch.setenv(env, val)
         alt = _gen(meta)(x0, z)
         monkeypatch.delenv(env)
