@@ -8,7 +8,7 @@ I2V_PMC_OUT=$out/pmc_traffic timeout 900 python bench.py --live-traffic --per-la
 rm -rf $out/pmc_traffic/fetch_size $out/pmc_traffic/write_size
 I2V_PMC_OUT=$out/pmc_traffic_land timeout 900 python bench.py --config land128 --steps 10 --warmup 3 --no-cpu-baseline --live-traffic --per-layer $out/conv16_per_layer_land128.csv 2>/dev/null | tail -1 > $out/bench_land128_b32.json
 rm -rf $out/pmc_traffic_land/fetch_size $out/pmc_traffic_land/write_size
-for b in 8 16; do timeout 200 python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_bair64_b$b.json; done
+for b in 4 8 16; do timeout 200 python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_bair64_b$b.json; done
 timeout 300 python bench.py --config dtdb128 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_dtdb128_strong_b256.json
 timeout 300 python bench.py --config iper128_t32 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_iper128_t32_strong_b128.json
 timeout 300 python bench.py --config dtdb128 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $out/bench_dtdb128_b32.json
