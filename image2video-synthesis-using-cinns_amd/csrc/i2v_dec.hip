@@ -683,7 +683,21 @@ struct i2v_dec {
     // runs there too, underneath the block's modulate / conv_0 chain: ev_x[k] = block input and its statistics complete (caller's
     // stream), ev_s[k] = shortcut complete (side stream)
     hipEvent_t ev_x[6] = {}, ev_s[6] = {};
+    // One handle = one workspace, one set of side-stream events: forwards / prepares on a handle are serialised.  A call that arrives
+    // on another stream than the previous one first waits for the previous call (event recorded behind every call), like i2v_flow.
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_done = nullptr;
+    bool have_last = false;
+    int order_entry(hipStream_t st) {
+        if (have_last && last_stream != st) I2V_HIP_CHECK(hipStreamWaitEvent(st, last_done, 0));
+        return I2V_OK;
+    }
+    void order_exit(hipStream_t st) {
+        if (!last_done && hipEventCreateWithFlags(&last_done, hipEventDisableTiming) != hipSuccess) { last_done = nullptr; return; }
+        if (hipEventRecord(last_done, st) == hipSuccess) { last_stream = st; have_last = true; }
+    }
     ~i2v_dec() {
+        if (last_done) (void)hipEventDestroy(last_done);
         for (auto& e : ev_x)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_s)
@@ -1545,6 +1559,8 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_dec_forward: workspace %zu < required %zu", workspace_bytes,
                 L.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rco = d->order_entry(st)) return rco;
+    struct Mark { i2v_dec* d; hipStream_t st; ~Mark() { d->order_exit(st); } } mark{d, st};   // (declared before Join: runs after the join)
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     float *xA = F(L.xA), *xB = F(L.xB), *a = F(L.a), *dx = F(L.dx), *xs_in = F(L.xs_in), *xs_low = F(L.xs_low);
@@ -1637,6 +1653,8 @@ int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     const DecWs L = dec_ws(d, B);
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_dec_prepare: workspace %zu < required %zu", workspace_bytes, L.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rco = d->order_entry(st)) return rco;
+    struct Mark { i2v_dec* d; hipStream_t st; ~Mark() { d->order_exit(st); } } mark{d, st};
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     d->prep_img = nullptr;

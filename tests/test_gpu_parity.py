@@ -391,6 +391,17 @@ def test_decoder_in_call_spade_overlap_keeps_the_bits(golden, monkeypatch):
     o3 = gen(imgs[1], z)
     o4 = gen(imgs[2], z)
     assert all(torch.equal(o2[i], refs[i % 3]) for i in range(4)) and torch.equal(o3, refs[1]) and torch.equal(o4, refs[2])
+    # two streams use ONE handle (one workspace) without ordering each other: the handle serialises its calls (event behind every call)
+    s2 = torch.cuda.Stream()
+    for s in (side, s2):
+        s.wait_stream(torch.cuda.current_stream())
+    res = []
+    for i in range(6):
+        with torch.cuda.stream(side if i % 2 == 0 else s2):
+            res.append(gen(imgs[i % 3], z))
+    for s in (side, s2):
+        torch.cuda.current_stream().wait_stream(s)
+    assert all(torch.equal(res[i], refs[i % 3]) for i in range(6))
 
 
 def test_decoder_prepare_equals_plain_forward():
