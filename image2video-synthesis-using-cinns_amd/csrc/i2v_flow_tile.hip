@@ -888,7 +888,9 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
 #ifdef FLOW_TIMELINE
 }  // namespace i2v
 // measurement build only: kind[launch]: 0 pre-GEMM, 1 tail, 2 hidden layer (the launch order of one pass is fixed: pre, tail, then
-// (hid x depth, tail) per half-step); prints mean phase durations per kind and the launch-to-launch gaps
+// (hid x depth, tail) per half-step; FOLDED chain (n_launches == 2 + half-steps x depth): pre, then (first = tail + hidden 0, hid x
+// (depth - 1)) per half-step, final tail -- the folded launches are reported under the tail's phase names, their stamps 1-2 =
+// requests / landed, 3-5 = the hidden layer's); prints mean phase durations per kind and the launch-to-launch gaps
 extern "C" int i2v_flow_timeline_report(int n_launches, int depth, int reset) {
     using namespace i2v;
     std::vector<unsigned long long> tl((size_t)FTL_LAUNCHES * FTL_WGS * FTL_ST), span((size_t)FTL_LAUNCHES * 2);
@@ -903,7 +905,12 @@ extern "C" int i2v_flow_timeline_report(int n_launches, int depth, int reset) {
     (void)hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(flow_tl), tl.size() * 8);
     (void)hipMemcpyFromSymbol(span.data(), HIP_SYMBOL(flow_tl_span), span.size() * 8);
     if (n_launches > FTL_LAUNCHES) n_launches = FTL_LAUNCHES;
-    auto kind = [&](int l) { return l == 0 ? 0 : ((l - 1) % (depth + 1) == 0 ? 1 : 2); };
+    const bool folded = depth > 0 && (n_launches - 2) % depth == 0 && (n_launches - 2) / depth * (depth + 1) + 2 != n_launches;
+    auto kind = [&](int l) {
+        if (l == 0) return 0;
+        if (folded) return l == n_launches - 1 ? 1 : ((l - 1) % depth == 0 ? 1 : 2);
+        return (l - 1) % (depth + 1) == 0 ? 1 : 2;
+    };
     const char* kn[3] = {"flow_pre_tile_kernel", "flow_tail_tile_kernel", "flow_hid_tile_kernel"};
     const char* ph[2][5] = {{"entry -> requests issued", "requests -> operands landed (P tiles, state, weights)", "partial sums + barrier",
                              "coupling, log-det, block boundary", "first Linear of the next half-step + store"},

@@ -30,4 +30,6 @@ for B in [int(v) for v in os.environ.get("FLOWTIME_B", "64,8").split(",")]:
     torch.cuda.synchronize()
     print(f"B = {B}: inverse pass of the INSTRUMENTED build, HIP events, median of 30: {np.median(ts):.1f} us", flush=True)
     sys.stdout.flush()
-    lib.i2v_flow_timeline_report(122, 2, 0)
+    # launches per pass: 82 = folded chain (the default for B <= 64), 122 = round 4's chain (I2V_FLOW_FOLD=0 or B > 64)
+    folded = os.environ.get("I2V_FLOW_FOLD", "1" if B <= 64 else "0") != "0"
+    lib.i2v_flow_timeline_report(82 if folded else 122, 2, 0)
