@@ -191,10 +191,18 @@ struct W4Next {
     int valid;          // there is a next brick
 };
 
-template <int NT, int WM, int VH0, int VH1, int NTH, bool PRE, bool PREL, int VXP, class Between>
+// BUF (round 5; the one-brick-per-workgroup kernels): the V requests go through a raw buffer descriptor of the brick's SAMPLE
+// (`vrsrc`: base = the sample's V tensor, num_records = its bytes < 2^31) instead of 64-bit addresses: the table holds the row index
+// inside the sample (padding rows: W4_PAD_ROW = 2^25, i.e. byte offset 2^31, out of range under any reading of the range check, and
+// an out-of-range lane of `buffer_load ... lds` writes ZEROS into LDS: tools/bufload_lds_test), the lane's offset is ONE
+// v_lshl_or_b32, the chunk goes into the scalar offset -- 5 instead of 13 instructions per load in front of the first MFMAs of
+// taps 0 / 1, where profiles/r05_n_f43_inloop_idle_analysis.md finds most of the tap loops' idle cycles.  Same loads, same order,
+// same wait counts.
+constexpr int W4_PAD_ROW = 1 << 25;
+template <int NT, int WM, int VH0, int VH1, int NTH, bool PRE, bool PREL, int VXP, bool BUF, class Between>
 __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* gpos, const int* gposN, f32x16 (&acc)[WM],
                                         int (&arow)[WM], const char* wfrag, int HH, int tid, int lane, int wave, int rb0, int rb1,
-                                        const W4Next& nxt, Between&& between, int w4_tlv_) {
+                                        const W4Next& nxt, Between&& between, int w4_tlv_, __amdgpu_buffer_rsrc_t vrsrc) {
     constexpr int RPL = NTH / 4;          // V rows staged by one load instruction of the workgroup (4 threads per 64-byte row)
     static_assert(VXP == 0 || (VH0 == VH1 && NTH == 512), "PIPE needs the 512-thread geometry");
     constexpr int VX = PRE ? VXP : 0;   // extra LDS-DMA loads per half-request (the next brick's first V brick; PREL: this brick's was preloaded)
@@ -209,6 +217,8 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     const int* gqn = gposN + (tid >> 2);
     const long vpiece = (long)((tid & 3) ^ ((tid >> 4) & 3)) * 16;
     const long vchunk = (long)6 * a.H * a.J * 64;        // bytes between the K chunks of one frame
+    const unsigned vpiece32 = (unsigned)vpiece;
+    const unsigned vchunk32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vchunk);
     const unsigned wofs = lane * 16;                     // the lane's piece of a weight fragment (the rest of the address is scalar)
     {   // the fragment base goes into the loads' scalar address operand: make its uniformity explicit
         const unsigned long w_ = (unsigned long)wfrag;
@@ -222,6 +232,12 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" W4_V_POLICY "\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                              \
     }
+#define W4_BLDS(off_, soff_, dst_)                                                                                   \
+    {                                                                                                                \
+        unsigned keep_;                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds" W4_V_POLICY "\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(off_), "s"(vrsrc), "s"(dst_), "s"(soff_) : "memory");                      \
+    }
 #define W4_REQUEST_V(ch_, VB, HF)                                                                                    \
     {                                                                                                                \
         const bool nx_ = (ch_) >= a.nchunk;              /* behind the last chunk: the hand-over table, chunk 0 */    \
@@ -229,10 +245,18 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
         constexpr int nv_ = (HF) ? VH1 : VH0, v0_ = (HF) ? VH0 : 0;   /* this half-request's load instructions */     \
         int gp_[nv_];                                                                                                \
         _Pragma("unroll") for (int u = 0; u < nv_; ++u) gp_[u] = gt_[RPL * (v0_ + u)];                               \
+        if constexpr (BUF) {                                                                                         \
+            const unsigned so_ = (unsigned)(nx_ ? 0 : (ch_)) * vchunk32;                                             \
+            _Pragma("unroll") for (int u = 0; u < nv_; ++u) {                                                        \
+                const unsigned o_ = ((unsigned)gp_[u] << 6) | vpiece32;                                              \
+                W4_BLDS(o_, so_, vdst + ((VB) ? voff1 : voff0) + (unsigned)((v0_ + u) * (NTH * 16)))                  \
+            }                                                                                                        \
+        } else {                                                                                                     \
         const char* vb_ = a.in + (long)(nx_ ? 0 : (ch_)) * vchunk + vpiece;                                          \
         _Pragma("unroll") for (int u = 0; u < nv_; ++u) {                                                            \
             const char* s_ = gp_[u] >= 0 ? vb_ + (long)gp_[u] * 64 : a.zeros;                     \
             W4_GLDS(s_, vdst + ((VB) ? voff1 : voff0) + (unsigned)((v0_ + u) * (NTH * 16)))                           \
+        }                                                                                                            \
         }                                                                                                            \
         if constexpr (VX > 0) {   /* the next brick's first V brick, pieces (chunk parity, half, u); real in chunks 0, 1 */ \
             constexpr int pc_ = ((1 - (VB)) * 2 + (HF)) * 2;   /* (the requesting chunk's parity is 1 - VB) */         \
@@ -441,6 +465,7 @@ __device__ __forceinline__ void w4_pass(const W4Args& a, char* smem, const int* 
     }
 #endif
 #undef W4_GLDS
+#undef W4_BLDS
 #undef W4_REQUEST_V
 #undef W4_LOAD_A
 #undef W4_ADDR_A
@@ -503,7 +528,9 @@ __host__ __device__ __forceinline__ W4Brick w4_decode(const W4Args& a, int v) {
 
 // index tables of one brick: gposA [1024] (planes 0..3), gposB [1024] (planes 4, 5 in rows 0..511, -1 = zero page behind),
 // tpos [128] (output position of a tile's first column), tres [128][4] (residual rows of the tile's four columns)
-template <int KT, int NTH>
+// REL: V rows relative to the brick's sample and W4_PAD_ROW for padding (the buffer-descriptor requests of the one-brick kernels);
+// else global row indices and -1
+template <int KT, int NTH, bool REL>
 __device__ __forceinline__ void w4_tables(const W4Args& a, const W4Brick& k, int* gposA, int tid) {
     constexpr int ROWS_A = W4Geo<NTH>::ROWS_A, TILES = W4Geo<NTH>::TILES;
     int* gposB = gposA + ROWS_A;
@@ -534,7 +561,8 @@ __device__ __forceinline__ void w4_tables(const W4Args& a, const W4Brick& k, int
         const int t = k.t0 + q - pt, h = k.h0 + ih - 1, j = k.j0 + ij;
         const bool ok = x < (pb ? 2 : 4) && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H;
         const int xg = pb ? 4 + x : x;
-        (pb ? gposB : gposA)[rr] = ok ? ((((k.b0 * a.T + t) * a.nchunk * 6 + xg) * a.H + h) * a.J + j) : -1;  // chunk 0; 64-byte rows
+        if constexpr (REL) (pb ? gposB : gposA)[rr] = ok ? (((t * a.nchunk * 6 + xg) * a.H + h) * a.J + j) : W4_PAD_ROW;   // chunk 0; 64-byte rows
+        else (pb ? gposB : gposA)[rr] = ok ? ((((k.b0 * a.T + t) * a.nchunk * 6 + xg) * a.H + h) * a.J + j) : -1;
     }
 }
 
@@ -561,6 +589,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
     constexpr bool FULL = PIPE == 1, LITE = PIPE == 2, PERSIST = PIPE != 0;
     static_assert(NTH == 512 || (NTH == 256 && BN == 32 && PIPE == 0), "the 256-thread geometry exists for 32-channel one-brick workgroups");
     using Geo = W4Geo<NTH>;
+    constexpr bool BUF = PIPE == 0;   // V requests through a buffer descriptor of the brick's sample (see w4_pass)
     constexpr int NW = NTH / 64;
     constexpr int WMA = BN == 64 ? 4 : 2, WMB = BN == 64 ? 2 : 1;
     constexpr int KT = NT / 3;
@@ -580,7 +609,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         const int tid = tid0;
         W4_STAMP(0)
     }
-    w4_tables<KT, NTH>(a, bk, reinterpret_cast<int*>(smem + a.tofs), tid0);
+    w4_tables<KT, NTH, BUF>(a, bk, reinterpret_cast<int*>(smem + a.tofs), tid0);
     // a brick's first V brick (pass A, chunk 0) into the first region: 8 LDS-DMA loads per thread from the table gq0
     auto request_chunk0 = [&](const int* gq0, int tid) {
         const int* gq = gq0 + (tid >> 2);
@@ -616,6 +645,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
         const int* tres = tpos + Geo::TILES;
         const int n0 = bk.ntile * BN, b0 = bk.b0;
         const char* wbase = a.wp + (long)bk.par * a.wset_stride;   // wave-uniform; the lane's 16 bytes are added by the load
+        // (BUF) descriptor of this brick's sample of V: base + b0 * bytes per sample, num_records = bytes per sample (< 2^31, checked by the launcher)
+        const long vsample = (long)a.T * a.nchunk * 6 * a.H * a.J * 64;
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.in) + (BUF ? (long)b0 * vsample : 0), 0,
+                                                                               BUF ? (int)vsample : 0, 0x00020000);
         const int vn = v + (int)gridDim.x;
         const bool more = PERSIST && vn < a.nvirt;
         const W4Brick bn_ = more ? w4_decode<BN>(a, vn) : bk;
@@ -640,8 +673,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
                 for (int r = 0; r < 16; ++r) accA[wm][r] = 0.f;
             }
             const W4Next none{gposA, 0u, 0u, 0};
-            w4_pass<NT, WMA, Geo::VA0, Geo::VA1, NTH, false, PERSIST, 0>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid,
-                                             lane, wave, rA0, rA1, none, [] {}, w4_tlv_);
+            w4_pass<NT, WMA, Geo::VA0, Geo::VA1, NTH, false, PERSIST, 0, BUF>(a, smem, gposA, gposB, accA, arow, wbase + ((long)xa * nblk + (n0 >> 5) + nha) * 2048, HH, tid,
+                                             lane, wave, rA0, rA1, none, [] {}, w4_tlv_, vrsrc);
         }
         W4_STAMP(2)
         // ---- pass B: planes 4, 5, wave = (plane, 32-channel half, tile half)   [BN = 32: (plane, tile quarter)]
@@ -663,12 +696,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_f16x3_kernel(W4Args a) {
             const W4Next nxt{(more ? gposAn : gposA) + (tid >> 2),
                              (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(flip ^ 1) * 65536u + (unsigned)wave * 1024u)),
                              (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)flip * 65536u + 30720u)), more ? 1 : 0};   // dump: rows 480..495 of pass B's first buffer (zero padding, never read)
-            w4_pass<NT, WMB, Geo::VB0, Geo::VB1, NTH, true, PERSIST, FULL ? 2 : 0>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid,
+            w4_pass<NT, WMB, Geo::VB0, Geo::VB1, NTH, true, PERSIST, FULL ? 2 : 0, BUF>(a, smem, gposB, gposB, accB, arow, wbase + ((long)(4 + xb) * nblk + (n0 >> 5) + nhb) * 2048, HH, tid,
                                             lane, wave, rB0, rB1, nxt, [&] {
                                                 // (PIPE) the next brick's tables, built while this pass's first weight fragments
                                                 // travel; published by the barrier in front of the loop
-                                                if constexpr (PERSIST) { if (more) w4_tables<KT, NTH>(a, bn_, gposAn, tid); }
-                                            }, w4_tlv_);
+                                                if constexpr (PERSIST) { if (more) w4_tables<KT, NTH, BUF>(a, bn_, gposAn, tid); }
+                                            }, w4_tlv_, vrsrc);
         }
         W4_STAMP(4)
 
@@ -1054,6 +1087,7 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
     // the kernel's index tables (gpos: V rows, tpos / tres: output and residual positions) are 32-bit
+    I2V_REQUIRE((long)T * a.nchunk * 6 * H * a.J * 64 < (1L << 31), I2V_E_INVALID, "wino4: the V operand of one sample ([%d,%d,%d] x %d chunks) exceeds the 2 GB a buffer descriptor offset can address", T, H, W, a.nchunk);
     I2V_REQUIRE((long)B * T * a.nchunk * 6 * H * a.J < (1L << 31) && (long)B * (wts.tdup ? 2 * T : T) * H * W < (1L << 31), I2V_E_INVALID,
                 "wino4: batch %d too large for the 32-bit row indices of this kernel ([%d,%d,%d] x %d chunks)", B, T, H, W, a.nchunk);
     if (getenv("I2V_W4_TRACE")) {

@@ -86,8 +86,8 @@ def check_loop(loop_text, iterations=3):
             touched = regs(rest)
             if touched & pending:
                 bad.append(f"iteration {it}, line {ln}: '{l}' touches v{sorted(touched & pending)} while a load may still write them")
-            if op.startswith("global_load_lds"):
-                queue.append(("lds", None))
+            if op.startswith("global_load_lds") or (op.startswith("buffer_load") and re.search(r"\blds\b", rest)):
+                queue.append(("lds", None))     # LDS-DMA: no VGPR destination (a buffer form's first operand is the OFFSET register)
             elif op.startswith(("global_load", "buffer_load", "flat_load")):
                 queue.append(("reg", regs(rest.split(",")[0])))
     return bad
