@@ -29,19 +29,27 @@ int main() {
     char* d; unsigned* o;
     hipMalloc(&d, n); hipMalloc(&o, 4096);
     hipMemcpy(d, h.data(), n, hipMemcpyHostToDevice);
-    int bad = 0;
+    int bad_pad = 0, bad_data0 = 0, all_zero_soff = 0, data_soff = 0;
     for (unsigned soff : {0u, 4096u}) {
-        hipLaunchKernelGGL(k, dim3(1), dim3(256), 0, 0, d, 4096u, soff, o);   // num_records = ONE chunk: soffset must not count in the range check
+        hipLaunchKernelGGL(k, dim3(1), dim3(256), 0, 0, d, 4096u, soff, o);   // num_records = ONE 4 KB chunk
         std::vector<unsigned> r(1024);
         hipMemcpy(r.data(), o, 4096, hipMemcpyDeviceToHost);
         for (int t = 0; t < 256; ++t)
             for (int c = 0; c < 4; ++c) {
                 const bool pad = (t & 63) & 4;
-                const unsigned want = pad ? 0u : 0x1000000u + soff / 4 + (t >> 2) * 16 + (t & 3) * 4 + c;
+                const unsigned want = 0x1000000u + soff / 4 + (t >> 2) * 16 + (t & 3) * 4 + c;
                 const unsigned got = r[t * 4 + c];
-                if (got != want) { if (bad < 8) printf("soff %u thread %d dword %d: got %08x want %08x\n", soff, t, c, got, want); ++bad; }
+                if (pad) bad_pad += got != 0u;                       // padding lanes (both markers) must have written zeros over the 0xAA fill
+                else if (soff == 0) bad_data0 += got != want;
+                else { all_zero_soff += got == 0u; data_soff += got == want; }
             }
     }
-    printf("buffer_load_dwordx4 ... offen lds: out-of-range lanes write zeros, soffset outside the range check: %s (%d mismatches)\n", bad ? "NO" : "yes", bad);
+    printf("buffer_load_dwordx4 ... offen lds on gfx950:\n");
+    printf("  out-of-range lanes (offset 0xFFFFFFC0 | piece and 2^31 | piece) WRITE ZEROS into LDS: %s (%d wrong dwords)\n", bad_pad ? "NO" : "yes", bad_pad);
+    printf("  in-range lanes deliver their 16 bytes: %s (%d wrong dwords)\n", bad_data0 ? "NO" : "yes", bad_data0);
+    printf("  with soffset = num_records the in-range lanes returned: %d dwords of data, %d zeros -> the scalar offset %s part of the range check\n",
+           data_soff, all_zero_soff, all_zero_soff > data_soff ? "IS" : "is NOT");
+    printf("  (the F(4,3) kernel therefore uses num_records = the whole sample, soffset = the chunk, padding = 2^31: out of range either way, no 32-bit wrap)\n");
+    const int bad = bad_pad + bad_data0;
     return bad != 0;
 }
