@@ -22,6 +22,11 @@ I2V_DEC_OVERLAP=0 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-bas
 I2V_DEC_OVERLAP=0 timeout 300 python bench.py --config land128 --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_land128_overlap0.json
 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact --small-batch 0 2>/dev/null | tail -1 > $out/bench_bair64_overlap1.json
 timeout 300 python bench.py --config land128 --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_land128_overlap1.json
+# same box, the library built from the sources one commit before the buffer-descriptor V requests (tools/_tl/libi2v_hip_prebuf.so, if present)
+if [ -f tools/_tl/libi2v_hip_prebuf.so ]; then
+  I2V_LIB_PATH=tools/_tl/libi2v_hip_prebuf.so timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact --small-batch 0 2>/dev/null | tail -1 > $out/bench_bair64_prebuf.json
+  I2V_LIB_PATH=tools/_tl/libi2v_hip_prebuf.so timeout 300 python bench.py --config land128 --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_land128_prebuf.json
+fi
 I2V_DEC_WINO32=0 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --sustain 0 --small-batch 0 2>/dev/null | tail -1 > $out/bench_bair64_exact_direct.json
 I2V_FLOW_FOLD=0 timeout 300 python tools/flowtime.py 2>&1 | grep -v amdgpu.ids > $out/flowtime_unfolded.txt
 # cINN chain: latencies (fp32 and fp16-operand mode), per-kernel stats
