@@ -69,7 +69,7 @@ class Model(torch.nn.Module):
     @torch.no_grad()
     def synthesize(self, x_0, cond=None, residual=None, embed=None):
         """[B,3,H,W] -> [B, 16*ceil(vid_length/16), 3, H, W]; no batch slice.
-        ONE call overlaps its own two halves where they are independent: the cINN pass (a 122-launch dependent chain that leaves
+        ONE call overlaps its own two halves where they are independent: the cINN pass (an 82-launch dependent chain that leaves
         most of the chip idle) runs on a high-priority side stream while the current stream already computes the decoder's
         SPADE branches, which depend on the start frame only (``overlap = False`` restores the strictly serial order; the
         frames are the same bits either way)."""

@@ -1,5 +1,5 @@
 """Two-stage pipelining of the sampling path over a stream of batches (generate_samples.py:44-54 loops over batches of
-start frames): the cINN inverse pass of batch k+1 -- a 122-launch dependent chain that leaves most of the chip idle --
+start frames): the cINN inverse pass of batch k+1 -- an 82-launch dependent chain that leaves most of the chip idle --
 runs on a high-priority side stream underneath the decoder pass(es) of batch k.
 
     pf = LatentPrefetcher(lambda res, emb: flow(res, emb, reverse=True))
