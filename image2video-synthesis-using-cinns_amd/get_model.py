@@ -70,9 +70,10 @@ class Model(torch.nn.Module):
     def synthesize(self, x_0, cond=None, residual=None, embed=None):
         """[B,3,H,W] -> [B, 16*ceil(vid_length/16), 3, H, W]; no batch slice.
         ONE call overlaps its own two halves where they are independent: the cINN pass (an 82-launch dependent chain that leaves
-        most of the chip idle) runs on a high-priority side stream while the current stream already computes the decoder's
-        SPADE branches, which depend on the start frame only (``overlap = False`` restores the strictly serial order; the
-        frames are the same bits either way)."""
+        most of the chip idle) runs on a high-priority side stream, the decoder's SPADE branches -- they depend on the start frame
+        only -- on the decoder handle's own side stream (``Generator.prepare``), and the decoder proper starts as soon as the latent
+        is there, its blocks waiting for their level's maps (``overlap = False`` restores the strictly serial order; the frames are
+        the same bits either way)."""
         # (single-stream semantics are kept while the caller captures a graph: a side stream cannot be forked inside a capture here)
         if not (self.overlap and x_0.is_cuda) or torch.cuda.is_current_stream_capturing():
             return self.decode(x_0, self.sample_latent(x_0, cond, residual, embed))
