@@ -92,6 +92,45 @@ struct DevBuf {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Is `st` capturing a graph right now?  (Errors of the query -- a stream of another context, an old runtime -- count as "no".)
+inline bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+// Cross-stream serialisation of the calls on ONE handle (one workspace, one set of device-side pointer blocks): an event is
+// recorded behind every call, and a call that arrives on another stream than the previous one first waits for it.
+// Graph capture (round 5 advisor finding): an event recorded OUTSIDE a capture must not be waited on inside it ("dependency
+// created on uncaptured work in another stream" -- the usual torch.cuda.graph recipe warms up on stream A and captures on stream
+// B), and an event recorded INSIDE a capture must not be waited on by later eager work.  While `st` captures, the helper
+// therefore neither waits nor records and forgets the previous call: ordering a graph against earlier eager work on other
+// streams is the capturing caller's job (torch.cuda.graph synchronises before it begins the capture).
+struct StreamOrder {
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_done = nullptr;
+    bool have_last = false;
+    StreamOrder() = default;
+    StreamOrder(const StreamOrder&) = delete;
+    StreamOrder& operator=(const StreamOrder&) = delete;
+    ~StreamOrder() { if (last_done) (void)hipEventDestroy(last_done); }
+    int entry(hipStream_t st) {
+        if (stream_is_capturing(st)) { have_last = false; return I2V_OK; }
+        if (have_last && last_stream != st) I2V_HIP_CHECK(hipStreamWaitEvent(st, last_done, 0));
+        return I2V_OK;
+    }
+    void exit(hipStream_t st) {
+        if (stream_is_capturing(st)) { have_last = false; return; }
+        if (!last_done && hipEventCreateWithFlags(&last_done, hipEventDisableTiming) != hipSuccess) { last_done = nullptr; return; }
+        if (hipEventRecord(last_done, st) == hipSuccess) { last_stream = st; have_last = true; }
+    }
+};
+// records the end of a call on its stream when the scope is left (also on the error paths: whatever was enqueued is ordered)
+struct StreamOrderMark {
+    StreamOrder* o; hipStream_t st;
+    ~StreamOrderMark() { o->exit(st); }
+};
+
 // hipFuncAttributeMaxDynamicSharedMemorySize has to be raised once PER DEVICE (every device has its own copy of the code
 // object); `done` = the call site's static bool[I2V_MAX_DEV].
 // A handle owns device memory (packed weights) on the device that was current when it was created; every call that

@@ -685,19 +685,25 @@ struct i2v_dec {
     hipEvent_t ev_x[6] = {}, ev_s[6] = {};
     // One handle = one workspace, one set of side-stream events: forwards / prepares on a handle are serialised.  A call that arrives
     // on another stream than the previous one first waits for the previous call (event recorded behind every call), like i2v_flow.
-    hipStream_t last_stream = nullptr;
-    hipEvent_t last_done = nullptr;
-    bool have_last = false;
-    int order_entry(hipStream_t st) {
-        if (have_last && last_stream != st) I2V_HIP_CHECK(hipStreamWaitEvent(st, last_done, 0));
+    StreamOrder order;   // (capture-aware: i2v_common.h)
+    // A forked prepare (or an in-call fork that failed half-way) leaves work on the side stream that nothing on a caller's stream has
+    // waited for yet: `side_unjoined`.  Whoever DROPS such a prepare (i2v_dec_prepare_cancel followed by a forward, a forward with other
+    // start frames / another workspace, i2v_dec_join, the destructor) joins the side stream first, so that the lifetime of the
+    // caller-owned workspace and start frames is bounded by the caller's stream again (round-5 advisor finding).
+    bool side_unjoined = false;
+    // `st` waits for everything enqueued on the side stream so far (a fresh record of ev_fork on the side stream: covers the SPADE
+    // branches of every level AND the shortcut GEMMs).  Not while `st` captures: an event recorded outside a capture cannot be waited
+    // on inside it; the flag then stays set for the next eager call.
+    int join_side(hipStream_t st) {
+        if (!side || !ev_fork) { side_unjoined = false; return I2V_OK; }
+        if (stream_is_capturing(st)) return I2V_OK;
+        I2V_HIP_CHECK(hipEventRecord(ev_fork, side));
+        I2V_HIP_CHECK(hipStreamWaitEvent(st, ev_fork, 0));
+        side_unjoined = false;
         return I2V_OK;
     }
-    void order_exit(hipStream_t st) {
-        if (!last_done && hipEventCreateWithFlags(&last_done, hipEventDisableTiming) != hipSuccess) { last_done = nullptr; return; }
-        if (hipEventRecord(last_done, st) == hipSuccess) { last_stream = st; have_last = true; }
-    }
     ~i2v_dec() {
-        if (last_done) (void)hipEventDestroy(last_done);
+        if (side) (void)hipStreamSynchronize(side);   // nothing of this handle may still write the caller's workspace once it is gone
         for (auto& e : ev_x)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_s)
@@ -1502,9 +1508,7 @@ int i2v_dec_get_layer_profile(i2v_dec* d, int32_t layer, char* name, int32_t nam
 static int fork_spade(i2v_dec* d, const DecWs& L, char* ws, const float* img, int img_h, int img_w, int B, hipStream_t st, bool* done) {
     *done = false;
     if (!d->overlap || d->tap_dst) return I2V_OK;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return I2V_OK; }
-    if (cs != hipStreamCaptureStatusNone) return I2V_OK;
+    if (stream_is_capturing(st)) return I2V_OK;
     if (!d->side) {
         I2V_HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
         I2V_HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
@@ -1522,6 +1526,7 @@ static int fork_spade(i2v_dec* d, const DecWs& L, char* ws, const float* img, in
     }
     // (an error must not leave the caller's stream ahead of work this call put on the side stream)
     if (rc) { (void)hipStreamSynchronize(d->side); return rc; }
+    d->side_unjoined = true;
     *done = true;
     return I2V_OK;
 }
@@ -1559,8 +1564,8 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_dec_forward: workspace %zu < required %zu", workspace_bytes,
                 L.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (int rco = d->order_entry(st)) return rco;
-    struct Mark { i2v_dec* d; hipStream_t st; ~Mark() { d->order_exit(st); } } mark{d, st};   // (declared before Join: runs after the join)
+    if (int rco = d->order.entry(st)) return rco;
+    StreamOrderMark mark{&d->order, st};   // (declared before Join: runs after the join)
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     float *xA = F(L.xA), *xB = F(L.xB), *a = F(L.a), *dx = F(L.dx), *xs_in = F(L.xs_in), *xs_low = F(L.xs_low);
@@ -1581,14 +1586,21 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
                     d->prep_bstride == img_bstride;
     // Prepared on the side stream (i2v_dec_prepare), or not prepared at all: then compute the maps on the handle's side stream now,
     // underneath the first levels (see i2v_dec::overlap).  Either way every block waits for its level's event.
+    // While `st` captures a graph the per-level events of a prepare forked BEFORE the capture cannot be waited on (they were recorded
+    // outside it): the prepared maps are dropped and the branches run inline, inside the capture (fork_spade refuses to fork there).
+    if (prepared && d->prep_forked && stream_is_capturing(st)) prepared = false;
     bool forked = prepared && d->prep_forked;
+    // A forked prepare this call does NOT consume (other frames / batch / workspace, cancelled, capture): its side-stream work still
+    // writes gbs / py0 / py1 of the workspace it was given -- join it before anything of this call touches a workspace.
+    if (!forked && d->side_unjoined)
+        if (int rcj = d->join_side(st)) return rcj;
     if (!prepared) {
         if (int rcf = fork_spade(d, L, ws, img, img_h, img_w, B, st, &forked)) return rcf;
         prepared = forked;
     }
     struct Join {   // an error return below must not leave the caller's stream ahead of the side stream's work on its buffers
-        i2v_dec* d; hipStream_t st; bool on;
-        ~Join() { if (on) (void)hipStreamWaitEvent(st, d->ev_lvl[5], 0); }
+        i2v_dec* d; hipStream_t st; bool on;   // (branches of every level and the shortcut GEMMs: join_side covers both)
+        ~Join() { if (on) (void)d->join_side(st); }
     } join{d, st, forked};
     for (int k = 0; k < 6; ++k) {
         const Block& b = d->blk[k];
@@ -1604,7 +1616,7 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
         bool ready_out = x_stats_ready;
         if (forked) {   // this level's gamma | beta maps are complete
             I2V_HIP_CHECK(hipStreamWaitEvent(st, d->ev_lvl[k], 0));
-            if (k == 5) join.on = false;
+            if (k == 5) d->side_unjoined = false;   // every branch has been waited for (a shortcut enqueued below keeps join.on)
         }
         for (int s0 = 0; s0 < B; s0 += nsub) {
             const int n = std::min(nsub, B - s0);
@@ -1622,6 +1634,7 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
         x_stats_ready = ready_out;
         std::swap(x, xn);
     }
+    join.on = false;   // every level's maps and every shortcut have been waited for by their consumers
     {
         const Level& l = d->lvl[5];
         if (d->conv_img_m.w.p) rc = conv_img_mfma_forward(d->conv_img_m, x, out, B, l.T, l.H, l.W, st, d->status_dev, out_bstride);
@@ -1653,10 +1666,14 @@ int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     const DecWs L = dec_ws(d, B);
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_dec_prepare: workspace %zu < required %zu", workspace_bytes, L.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (int rco = d->order_entry(st)) return rco;
-    struct Mark { i2v_dec* d; hipStream_t st; ~Mark() { d->order_exit(st); } } mark{d, st};
+    if (int rco = d->order.entry(st)) return rco;
+    StreamOrderMark mark{&d->order, st};
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    // an earlier forked prepare that was never consumed may have been given ANOTHER workspace (or start frames the caller has
+    // released since): `st` joins it before this prepare replaces it
+    if (d->side_unjoined && (d->prep_img == nullptr || d->prep_ws != workspace))
+        if (int rcj = d->join_side(st)) return rcj;
     d->prep_img = nullptr;
     d->img_bstride = 0;
     // on the handle's side stream where possible (ordered behind everything already on `st`): the caller's stream stays free for
@@ -1675,8 +1692,17 @@ int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
 
 int i2v_dec_prepare_cancel(i2v_dec* d) {
     I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_prepare_cancel: null handle");
-    d->prep_img = nullptr;
+    d->prep_img = nullptr;   // (a forked prepare keeps side_unjoined: the next forward / prepare / i2v_dec_join joins it)
     return I2V_OK;
+}
+
+int i2v_dec_join(i2v_dec* d, void* stream) {
+    I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_join: null handle");
+    I2V_REQUIRE_DEVICE(d->device, "i2v_dec_join");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    I2V_REQUIRE(!stream_is_capturing(st), I2V_E_STATE, "i2v_dec_join: the stream is capturing a graph (join before the capture begins)");
+    d->prep_img = nullptr;
+    return d->join_side(st);
 }
 
 int i2v_dec_status(i2v_dec* d, int32_t* flags, int32_t reset, void* stream) {

@@ -128,10 +128,7 @@ struct i2v_embedder {
     // One handle = (normally) one workspace: forwards on a handle are serialised.  A call that arrives on another stream than the
     // previous one (LatentPrefetcher's side stream next to the main stream) first waits for the previous forward (event recorded
     // behind every forward), like i2v_flow: a direct call on the main stream cannot race a ticket outstanding on the side stream.
-    hipStream_t last_stream = nullptr;
-    hipEvent_t last_done = nullptr;
-    bool have_last = false;
-    ~i2v_embedder() { if (last_done) (void)hipEventDestroy(last_done); }
+    StreamOrder order;   // (capture-aware: see i2v_common.h)
 };
 
 namespace {
@@ -277,14 +274,8 @@ int i2v_embedder_forward(i2v_embedder* e, const float* img, int32_t h, int32_t w
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_embedder_forward: workspace %zu < required %zu", workspace_bytes,
                 L.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (e->have_last && e->last_stream != st) I2V_HIP_CHECK(hipStreamWaitEvent(st, e->last_done, 0));
-    struct Mark {   // records the end of this forward on its stream (also on the error paths: whatever was enqueued is ordered)
-        i2v_embedder* e; hipStream_t st;
-        ~Mark() {
-            if (!e->last_done && hipEventCreateWithFlags(&e->last_done, hipEventDisableTiming) != hipSuccess) { e->last_done = nullptr; return; }
-            if (hipEventRecord(e->last_done, st) == hipSuccess) { e->last_stream = st; e->have_last = true; }
-        }
-    } mark{e, st};
+    if (int rco = e->order.entry(st)) return rco;
+    StreamOrderMark mark{&e->order, st};   // records the end of this forward on its stream (also on the error paths)
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     float* buf[5];

@@ -251,9 +251,7 @@ struct i2v_flow {
     // One handle = one FlowIo block + (normally) one workspace: passes on a handle are serialised.  A call that arrives on
     // another stream than the previous one (LatentPrefetcher's side stream next to the main stream) first waits for the
     // previous pass (event recorded behind every pass), so that its set_io kernel / state buffers cannot overtake it.
-    hipStream_t last_stream = nullptr;
-    hipEvent_t last_done = nullptr;
-    bool have_last = false;
+    StreamOrder order;   // (capture-aware: see i2v_common.h)
     void drop_graphs() {
         for (auto& g : gexec) {
             if (g) (void)hipGraphExecDestroy(g);
@@ -264,7 +262,6 @@ struct i2v_flow {
     ~i2v_flow() {
         drop_graphs();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
-        if (last_done) (void)hipEventDestroy(last_done);
     }
 };
 
@@ -441,14 +438,8 @@ int run_pass(i2v_flow* f, bool reverse, const float* xin, const float* embed, fl
     I2V_REQUIRE(workspace_bytes >= L.total, I2V_E_WORKSPACE, "i2v_flow: workspace %zu < required %zu",
                 workspace_bytes, L.total);
     char* ws = static_cast<char*>(workspace);
-    if (f->have_last && f->last_stream != st) I2V_HIP_CHECK(hipStreamWaitEvent(st, f->last_done, 0));
-    struct Mark {   // records the end of this pass on its stream (also on the error paths: whatever was enqueued is ordered)
-        i2v_flow* f; hipStream_t st;
-        ~Mark() {
-            if (!f->last_done && hipEventCreateWithFlags(&f->last_done, hipEventDisableTiming) != hipSuccess) { f->last_done = nullptr; return; }
-            if (hipEventRecord(f->last_done, st) == hipSuccess) { f->last_stream = st; f->have_last = true; }
-        }
-    } mark{f, st};
+    if (int rco = f->order.entry(st)) return rco;
+    StreamOrderMark mark{&f->order, st};   // records the end of this pass on its stream (also on the error paths)
     if (f->tile.ok) return run_pass_tile(f, reverse, xin, embed, xout, logdet, ws, B, st);
     {
         const int na = B * 64, nb = B * f->E;

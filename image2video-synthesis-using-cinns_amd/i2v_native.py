@@ -101,6 +101,7 @@ SYMBOLS = {
                                           c_int32, c_void_p]),
     "i2v_dec_prepare": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_int32, c_void_p]),
     "i2v_dec_prepare_cancel": (c_int32, [c_void_p]),
+    "i2v_dec_join": (c_int32, [c_void_p, c_void_p]),
     "i2v_dec_set_profile": (c_int32, [c_void_p, c_int32]),
     "i2v_dec_debug_tap": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t]),
     "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
@@ -357,25 +358,48 @@ class NativeDecoder(_Handle):
         else:
             _check(lib().i2v_dec_debug_tap(self._h, block, which, dst.data_ptr(), dst.numel()), "i2v_dec_debug_tap")
 
+    def _workspace(self, nbytes, device):
+        """The handle's workspace; before it is REPLACED by a larger one, the current stream joins the handle's side stream (a forked
+        prepare may still be writing the old buffer: i2v_dec_join), so the caching allocator's stream-ordered free is safe."""
+        buf = self._ws.buf
+        if buf is not None and (buf.numel() < nbytes or buf.device != device):
+            _check(lib().i2v_dec_join(self._h, _stream()), "i2v_dec_join")
+            self._prep = None
+        return self._ws.get(nbytes, device)
+
+    @staticmethod
+    def _version(t):
+        """Version counter of a tensor, None for inference tensors (they do not track one: RuntimeError on access)."""
+        try:
+            return t._version
+        except RuntimeError:
+            return None
+
     @_on_device
     def prepare(self, img):
         """i2v_dec_prepare: enqueue the SPADE branches of all six blocks (they depend on the start frame only) on the HANDLE's side
         stream, ordered behind everything already on the current stream; the next ``forward`` with the SAME tensor (same storage,
-        batch, size) waits for them per level instead of computing them.  The current stream stays free (e.g. for the cINN pass)."""
+        batch, size) waits for them per level instead of computing them.  The current stream stays free (e.g. for the cINN pass).
+        Inference tensors (``torch.inference_mode``) carry no version counter, so an in-place refill between the prepare and its
+        forward could not be detected: for them this is a no-op and the forward computes the branches itself (same bits)."""
+        # every check BEFORE any state changes: a raise must leave the Python side and the C side agreeing (nothing prepared)
+        if getattr(self, "_prep", None) is not None:
+            self._prep = None
+            _check(lib().i2v_dec_prepare_cancel(self._h), "i2v_dec_prepare_cancel")
         _require_gpu(img)
         B = img.shape[0]
         if img.dim() != 4 or img.shape[1] != 3:
             raise I2VError(f"decoder: expected img [B,3,H,W], got {tuple(img.shape)}")
+        ver = self._version(img)
+        if ver is None:
+            return
         nbytes = lib().i2v_dec_workspace_bytes(self._h, B, img.shape[2], img.shape[3])
-        ws = self._ws.get(nbytes, img.device)
-        self._prep = None
-        if not img.is_contiguous():
-            raise I2VError("decoder.prepare: the start frames must be contiguous")
+        ws = self._workspace(nbytes, img.device)
         _check(lib().i2v_dec_prepare(self._h, img.data_ptr(), img.shape[2], img.shape[3], ws.data_ptr(), ws.numel(), B, _stream()),
                "i2v_dec_prepare")
         # the C side recognises the prepared frames by ADDRESS; a caching allocator hands the same address to the next same-size
         # tensor and a buffer refilled in place keeps it, so the binding also remembers WHICH tensor (weak) and its version
-        self._prep = (weakref.ref(img), img._version)
+        self._prep = (weakref.ref(img), ver)
 
     @staticmethod
     def _sample_strided(t, inner_shape):
@@ -401,7 +425,7 @@ class NativeDecoder(_Handle):
             if t.dtype != torch.float32:
                 raise I2VError(f"expected float32 tensors, got {t.dtype}")
         prep, self._prep = getattr(self, "_prep", None), None
-        if prep is not None and (prep[0]() is not img or prep[1] != img._version):
+        if prep is not None and (prep[0]() is not img or prep[1] != self._version(img)):
             _check(lib().i2v_dec_prepare_cancel(self._h), "i2v_dec_prepare_cancel")   # another tensor, or this one was written since
         B = img.shape[0]
         if img.dim() != 4 or img.shape[1] != 3 or motion.shape != (B, self.z_dim):
@@ -413,7 +437,7 @@ class NativeDecoder(_Handle):
         if not motion.is_contiguous():
             motion = motion.contiguous()
         nbytes = lib().i2v_dec_workspace_bytes(self._h, B, img.shape[2], img.shape[3])
-        ws = self._ws.get(nbytes, img.device)
+        ws = self._workspace(nbytes, img.device)
         T, H, W = self.out_shape
         if out is None:
             out = torch.empty(B, T, 3, H, W, dtype=torch.float32, device=img.device)

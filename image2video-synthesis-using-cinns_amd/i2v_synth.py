@@ -137,8 +137,12 @@ def _block(sd, rng, name, n_in, n_out, z_dim, spectral, negative_sigma):
         sd[f"{name}.norm_s.bn.bias"] = _uniform(rng, (n_in,), 0.2)
 
 
-def decoder_state_dict(seed=7, channel_factor=64, z_dim=64, spectral_norm=True, negative_sigma=()):
+def decoder_state_dict(seed=7, channel_factor=64, z_dim=64, spectral_norm=True, negative_sigma=(), conv_img_gain=1.0):
     """state_dict of ``Generator`` (decoder.py:55-83) as {key: np.ndarray}.
+
+    ``conv_img_gain``: factor on ``conv_img`` (weight and bias) applied AFTER the draw, so the random stream -- and every
+    other tensor -- is the one of gain 1; fixtures whose latents come out of the cINN (|z| larger than a unit normal) use it
+    to keep the frames out of tanh saturation.
 
     ``negative_sigma``: iterable of conv names (e.g. "g_1.conv_0") whose ``weight_u`` is
     negated so that sigma < 0 (quirk D6: the reference divides by the signed value).
@@ -155,6 +159,9 @@ def decoder_state_dict(seed=7, channel_factor=64, z_dim=64, spectral_norm=True, 
     fan_in = nf * 27
     sd["conv_img.weight"] = _uniform(rng, (3, nf, 3, 3, 3), 1.2 / np.sqrt(fan_in))
     sd["conv_img.bias"] = _uniform(rng, (3,), 0.1)
+    if conv_img_gain != 1.0:
+        sd["conv_img.weight"] = (sd["conv_img.weight"] * np.float32(conv_img_gain)).astype(np.float32)
+        sd["conv_img.bias"] = (sd["conv_img.bias"] * np.float32(conv_img_gain)).astype(np.float32)
     return sd
 
 

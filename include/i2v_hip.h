@@ -179,11 +179,22 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
  * Since round 5 the branches are enqueued on a side stream the HANDLE owns, ordered behind everything already on `stream` (an event),
  * and the consuming forward waits per level (events): the caller's stream stays free, e.g. for the cINN pass, and needs no stream
  * of its own for this.  (While `stream` captures a graph, with I2V_DEC_OVERLAP=0 or the debug tap on they run inline on `stream`.)
- * A forward WITHOUT prepared maps forks its own branches the same way, underneath its first levels. */
+ * A forward WITHOUT prepared maps forks its own branches the same way, underneath its first levels.
+ * LIFETIME CONTRACT of a prepare that ran on the side stream: `workspace` and `img` must stay allocated and unmodified until the
+ * NEXT i2v_dec_forward* / i2v_dec_prepare / i2v_dec_join call on the handle has been enqueued -- each of them either consumes the
+ * prepared maps (waiting per level) or makes its stream wait for the whole side stream before it does anything else, so from then
+ * on synchronising THAT stream bounds the lifetime of both buffers again.  A caller that wants to release or reuse them without
+ * another forward calls i2v_dec_join(d, stream) and orders the release behind `stream`.  i2v_dec_destroy synchronises the side
+ * stream.  Graph capture: a forward captured on `stream` runs everything inline (no side stream, no cross-stream events); a prepare
+ * that was forked BEFORE the capture began is dropped by it (join it with i2v_dec_join before capturing). */
 int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, void* workspace, size_t workspace_bytes,
                     int32_t batch, void* stream);
 /* Drops a pending prepare (no-op without one). */
 int i2v_dec_prepare_cancel(i2v_dec* d);
+/* Makes `stream` wait for everything the handle has enqueued on its own side stream (a forked i2v_dec_prepare that no forward has
+ * consumed) and drops the pending prepare: behind this call `stream` bounds the lifetime of the workspace / start frames again.
+ * No reference counterpart (the reference has one stream: generate_samples.py:47-54). */
+int i2v_dec_join(i2v_dec* d, void* stream);
 /* Roofline instrumentation.  With profiling on, every 3x3x3 Conv3d launch (the dominant kernel) is bracketed by HIP
  * events recorded on the launch stream -- no synchronisation is added to the forward.  After the caller has
  * synchronised, i2v_dec_get_profile resolves the pending pairs and returns the totals since set_profile(d, 1):

@@ -168,8 +168,8 @@ def dec_units():
     save("dec_units", dict(synth=args, sigma_g1_conv0=sig), **out)
 
 
-def _gen(nf, ups, upt, seed):
-    args = dict(seed=seed, channel_factor=nf)
+def _gen(nf, ups, upt, seed, **extra):
+    args = dict(seed=seed, channel_factor=nf, **extra)
     sd = T(synth.decoder_state_dict(**args))
     g = ref_dec.Generator({"channel_factor": nf, "z_dim": 64, "upsample_s": ups, "upsample_t": upt,
                            "spectral_norm": True}).eval()
@@ -230,8 +230,10 @@ def dec_full():
 
 def model_small():
     # F11: Model.forward semantics (get_model.py:51-75) with the reference flow + decoder modules,
-    # residual and embed supplied.  nf = 8, n_flows = 20.
-    g, dargs = _gen(8, [2, 1], [2, 1], 5)
+    # residual and embed supplied.  nf = 8, n_flows = 20.  The latents come out of the cINN (|z| ~ 5, not a unit normal), which
+    # drives dec_small()'s weights into tanh saturation (21 % of yq3 above 0.99: a numeric check is blind there); conv_img is
+    # therefore scaled by 0.25 (SURVEY 8c fixture requirement ii: < 1 % of the stored frames above 0.99).
+    g, dargs = _gen(8, [2, 1], [2, 1], 5, conv_img_gain=0.25)
     fargs = dict(seed=7, n_flows=20, embedding_dim=64, control=False)
     flow = ref_fb.ConditionalFlow(64, 64, 512, 2, 20, conditioning_option="None").eval()
     flow.load_state_dict(T(synth.flow_state_dict(**fargs)))
@@ -254,7 +256,10 @@ def model_small():
     assert tuple(yq3.shape) == (2, 16, 3, 64, 64)
     y20 = forward(x1, r1, e1, 20)         # B=1 <= 20: T is NOT trimmed -> 32 frames
     assert tuple(y20.shape) == (1, 32, 3, 64, 64)
-    save("model_nf8", dict(synth_dec=dargs, synth_flow=fargs, upsample_s=[2, 1], upsample_t=[2, 1]),
+    sat = {k: [float((v.abs() > 0.99).float().mean()), float((v.abs() > 0.999).float().mean())] for k, v in (("y32", y32), ("yq3", yq3))}
+    print("   model_nf8 saturation (fraction above 0.99 / 0.999):", sat)
+    assert all(v[0] < 0.01 for v in sat.values()), sat
+    save("model_nf8", dict(synth_dec=dargs, synth_flow=fargs, upsample_s=[2, 1], upsample_t=[2, 1], saturation=sat),
          x1=x1, r1=r1, e1=e1, y32=y32.contiguous(), x3=x3, r3=r3, e3=e3,
          yq3_shape=np.array(yq3.shape), yq3_t4=yq3[:, ::4].contiguous(), y20_shape=np.array(y20.shape))
 

@@ -464,6 +464,89 @@ def test_decoder_prepare_never_outlives_its_start_frames():
     assert torch.equal(gen(buf, z), ref_other)
 
 
+def test_decoder_and_embedder_under_graph_capture():
+    """Round-5 advisor finding: the usual torch.cuda.graph recipe warms up on stream A and captures on stream B; the handle's
+    cross-stream ordering events (recorded behind the warm-up) and a prepare forked before the capture must not leak into the
+    capture ("dependency created on uncaptured work in another stream").  Captured Generator.forward / ResnetEncoder.encode:
+    everything inline, replays with refilled static inputs equal the eager results bit for bit, and eager calls on other streams
+    after the capture still work."""
+    from stage2_cINN.AE.modules.AE import ResnetEncoder
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    img, z = cu(g["img"]), cu(g["z"])
+    img2, z2 = (img * 0.5 - 0.2).contiguous(), (z * 0.7).contiguous()
+    s_warm = torch.cuda.Stream()
+    s_warm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_warm):                      # warm-up on stream A (allocates the workspace, records the ordering event)
+        ref, ref2 = gen(img, z), gen(img2, z2)
+        gen.prepare(img)                                  # ... and leaves a FORKED prepare pending on the handle's side stream
+    torch.cuda.current_stream().wait_stream(s_warm)
+    torch.cuda.synchronize()
+    x_s, z_s = img.clone(), z.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):                         # capture on torch's capture stream B
+        y_s = gen(x_s, z_s)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_s, ref)
+    x_s.copy_(img2); z_s.copy_(z2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_s, ref2)
+    with torch.cuda.stream(s_warm):                       # eager again, on another stream than the capture: nothing waits on a captured event
+        again = gen(img, z)
+    torch.cuda.synchronize()
+    assert torch.equal(again, ref) and gen.native().status() == 0
+    # the embedder's handle orders its calls the same way
+    sd = T(synth.embedder_state_dict(seed=3, z_dim=64, norm="in"))
+    enc = ResnetEncoder({"z_dim": 64, "deterministic": False, "in_size": 64, "encoder_type": "resnet50", "norm": "in"})
+    enc.load_state_dict(sd)
+    enc = enc.cuda().eval()
+    with torch.cuda.stream(s_warm):
+        e_ref = enc.encode(img).mode()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        e_s = enc.encode(x_s).mode()
+    x_s.copy_(img)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(e_s, e_ref)
+
+
+def test_decoder_side_stream_lifetime_and_inference_mode():
+    """Round-5 advisor findings: (1) a forked prepare that is never consumed must not outlive its workspace: a forward at a LARGER
+    batch replaces the binding's workspace -- the binding joins the handle's side stream first (i2v_dec_join) -- and destroying the
+    handle synchronises the side stream; (2) i2v_dec_join through the C ABI; (3) under torch.inference_mode tensors carry no version
+    counter: prepare() is a no-op there and Model.synthesize-style use keeps working with the same bits."""
+    import ctypes
+    import i2v_native
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    img, z = cu(g["img"]), cu(g["z"])
+    ref = gen(img, z)
+    big_img, big_z = img.repeat(3, 1, 1, 1).contiguous(), z.repeat(3, 1).contiguous()
+    for _ in range(3):
+        gen2 = _gen(meta)
+        gen2.prepare(img)                                 # forked on gen2's side stream, writes gen2's (small) workspace
+        big = gen2(big_img, big_z)                        # needs a larger workspace: join, then replace
+        assert torch.equal(big[:2], ref) and torch.equal(big[4:], ref)
+        gen2.prepare(img)
+        del gen2                                          # destroyed with a prepare in flight: the destructor synchronises the side stream
+    nat = gen.native()
+    gen.prepare(img)
+    assert i2v_native.lib().i2v_dec_join(nat._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    assert torch.equal(gen(img, z), ref)
+    with torch.inference_mode():
+        xi, zi = img.clone(), z.clone()                   # inference tensors: no version counter
+        gen.prepare(xi)
+        assert getattr(nat, "_prep", None) is None
+        assert torch.equal(gen(xi, zi), ref)
+    with pytest.raises(i2v_native.I2VError):
+        nat.prepare(img[:, :, ::2])                       # not contiguous: raises BEFORE any state changes
+    assert torch.equal(gen(img, z), ref)
+
+
 def test_decoder_strided_in_place_sequence():
     """i2v_dec_forward_strided / Generator.decode_sequence: the autoregressive loop of get_model.py:68-73 decoded in place into ONE
     [B, 32, 3, H, W] buffer (pass 2 reads its start frames from the strided view seq[:, 15] and writes frames 16..31) must give
@@ -552,12 +635,23 @@ def test_model_from_pixels_with_embedder(tmp_path):
     x0, residual, _ = synth.bench_inputs(2, 64, 64)
     out = model(x0.cuda(), residual=residual.cuda())
     esd = T(synth.embedder_state_dict(seed=3, z_dim=64, norm="in"))
-    embed = embedder_ref.encode_mode(esd, x0, "in").reshape(2, -1)
-    ref = model_ref.model_forward(T(synth.flow_state_dict(**meta["synth_flow"])),
-                                  decoder_ref.fold_spectral_norm(T(synth.decoder_state_dict(**meta["synth_dec"]))), x0, residual,
-                                  embed, 16, upsample_s=meta["upsample_s"], upsample_t=meta["upsample_t"], faithful=False)
-    # (the 64x64 InstanceNorm embedder is ill-conditioned, see test_embedder_vs_oracle: its fp32 noise propagates)
-    assert out.shape == (2, 16, 3, 64, 64) and rel_l2(out.cpu(), ref) < 2e-3
+    esd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in esd.items()}
+    fsd = T(synth.flow_state_dict(**meta["synth_flow"]))
+    dsd = decoder_ref.fold_spectral_norm(T(synth.decoder_state_dict(**meta["synth_dec"])))
+
+    def chain(embed):
+        return model_ref.model_forward(fsd, dsd, x0, residual, embed.float().reshape(2, -1), 16, upsample_s=meta["upsample_s"],
+                                       upsample_t=meta["upsample_t"], faithful=False)
+
+    ref32 = chain(embedder_ref.encode_mode(esd, x0, "in"))
+    ref64 = chain(embedder_ref.encode_mode(esd64, x0.double(), "in"))
+    # The 64x64 InstanceNorm embedder is ill-conditioned (test_embedder_vs_oracle): the fp32 oracle embedding sits ~3e-4 from its
+    # fp64 evaluation, and the cINN + decoder carry that to the frames.  Same rule as there: 1e-4, or 3x the oracle's OWN
+    # fp32-vs-fp64 noise measured on the frames -- not a flat bound.
+    noise = rel_l2(ref32, ref64)
+    err = rel_l2(out.cpu(), ref64)
+    print(f"from pixels: HIP vs oracle(fp64 embedder) {err:.2e}; oracle fp32-vs-fp64 embedder noise on the frames {noise:.2e}")
+    assert out.shape == (2, 16, 3, 64, 64) and err < max(TOL, 3 * noise), (err, noise)
 
 
 def test_generate_samples_cli(tmp_path, monkeypatch):
