@@ -76,7 +76,7 @@ __device__ unsigned long long w4_tt[2 * 8 * 18 * 2];   // [pass][wave][tap slot]
 #else
 #define W4_TT(U)
 #endif
-// Structure of the kernel (I2V_W4_PIPE): 0 one workgroup per brick (round 3's structure, the default); 1 the software-pipelined
+// Structure of the kernel (I2V_W4_PIPE, measurement build only -- see w4_switches): 0 one workgroup per brick (round 3's structure, the default); 1 the software-pipelined
 // persistent kernel; 2 its "lite" form (see the kernel's comment).  All three give the same bits and pass the static checks.
 // Measured (profiles/r04_b_*, r04_l_*): 1 removes 1.9 us of prologue and 1.0 us of pass A per workgroup of the 128 -> 128 layer
 // and pays 0.7 us (tables under pass B's prologue), 1.5 us (pass B with the extra loads) and 1.4 us (four-quarter epilogue):
@@ -998,19 +998,33 @@ static int launch_wino4_thin(W4Args& a, unsigned nblk, hipStream_t st) {
     return launch_wino4_<NT, 32, 0, 256>(a, (unsigned)a.nvirt, (size_t)a.tofs + (size_t)w4_table_bytes<256>(), st);
 }
 
+// Measurement switches of this kernel.  The PRODUCTION library (no -DI2V_MEASURE) reads no environment variable on a launch path
+// and carries only the one-workgroup-per-brick kernels; the structure switches -- the software-pipelined persistent kernels
+// (I2V_W4_PIPE), the start skew of their workgroups (I2V_W4_SKEW), forced tile widths / workgroup sizes (I2V_W4_BN, I2V_W4_NTH),
+// the brick -> XCD order (I2V_W4_ORDER) and the launch trace (I2V_W4_TRACE) -- exist in the measurement build only
+// (tools/build_measurement_libs.sh measure -> tools/_tl/libi2v_hip_measure.so, loaded through I2V_LIB_PATH; tools/conv16w_check*
+// are built with the flag too), where they are read per launch so that tests and A/B runs can flip them inside one process.
+struct W4Switches { int pipe, bn, order, nth, skew, trace; };
+static W4Switches w4_switches() {
+    W4Switches w{W4_DEFAULT_PIPE, 0, W4_DEFAULT_ORDER, 0, 0, 0};
+#ifdef I2V_MEASURE
+    if (const char* e = getenv("I2V_W4_PIPE")) w.pipe = atoi(e);
+    if (const char* e = getenv("I2V_W4_BN")) w.bn = atoi(e);
+    if (const char* e = getenv("I2V_W4_ORDER")) w.order = atoi(e);
+    if (const char* e = getenv("I2V_W4_NTH")) w.nth = atoi(e);
+    if (const char* e = getenv("I2V_W4_SKEW")) w.skew = atoi(e);
+    w.trace = getenv("I2V_W4_TRACE") != nullptr;
+#endif
+    return w;
+}
+
 template <int NT, int BN>
-static int launch_wino4(W4Args& a, unsigned nblk, hipStream_t st) {
+static int launch_wino4(W4Args& a, unsigned nblk, hipStream_t st, int env_pipe) {
     a.nvirt = (int)(a.tdup ? 2 * nblk : nblk);
-    const char* ep_ = getenv("I2V_W4_PIPE");   // (read per launch: tests and A/B runs switch it inside one process)
-    const int env_pipe = ep_ ? atoi(ep_) : W4_DEFAULT_PIPE;
     const int body = 2 * W4_ROWS_A * 64;   // two V regions (pass B and the epilogue's exchange buffer reuse them)
     a.tofs = body;
-#ifdef W4_TAPTIME
-    const bool pipe = false;
-#else
-    const bool pipe = env_pipe != 0;
-#endif
-    if (pipe) {
+#if defined(I2V_MEASURE) && !defined(W4_TAPTIME)
+    if (env_pipe != 0) {
         // one workgroup per CU, a multiple of 8 so that a virtual workgroup keeps its XCD
         int grid = std::min(a.nvirt, device_cus());
         if (grid >= 8) grid &= ~7;
@@ -1018,6 +1032,9 @@ static int launch_wino4(W4Args& a, unsigned nblk, hipStream_t st) {
         if (env_pipe == 2) return launch_wino4_<NT, BN, 2>(a, (unsigned)grid, lds, st);
         return launch_wino4_<NT, BN, 1>(a, (unsigned)grid, lds, st);
     }
+#else
+    (void)env_pipe;
+#endif
 #ifdef W4_TAPTIME
     const size_t lds = 160 * 1024;
 #else
@@ -1052,10 +1069,8 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     int TT = 1, TH = 1;
     (void)wino4_tiling(T, H, W, wts.KT, &TT, &TH);
     int BN = a.CoutPad % 64 == 0 ? 64 : 32;  // output channels per workgroup
-    const char* eb_ = getenv("I2V_W4_BN");        // measurement switches (read per launch)
-    const char* eo_ = getenv("I2V_W4_ORDER");
-    const char* en_ = getenv("I2V_W4_NTH");
-    const int env_bn = eb_ ? atoi(eb_) : 0, env_order = eo_ ? atoi(eo_) : W4_DEFAULT_ORDER, env_nth = en_ ? atoi(en_) : 0;
+    const W4Switches sw = w4_switches();      // (defaults unless built with -DI2V_MEASURE)
+    const int env_bn = sw.bn, env_order = sw.order, env_nth = sw.nth;
     // 64-channel workgroups that would leave CUs idle (16x16 maps at small batches) become twice as many 32-channel ones: the
     // accumulation order of every output does not depend on the tile width, so the bits are the same
     if (BN == 64 && wts.KT != 1 && (long)B * (T / TT) * (H / TH) * (a.J / 4) * (a.CoutPad / 64) * (wts.tdup ? 2 : 1) < device_cus()) BN = 32;
@@ -1067,11 +1082,10 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     bool thin = false;
     {
         int TT2 = 1, TH2 = 1;
-        const char* ep_ = getenv("I2V_W4_PIPE");
         // Default: only the layers that HAVE 32 output channels (g_4 of the 128 x 128 configs: +3 % on 32 -> 32, +-0 on 64 -> 32,
         // profiles/r05_c_*); 64-channel layers narrowed for a small grid keep the 512-thread geometry (-2 % at B = 8 with 256).
         // I2V_W4_NTH=256 forces the 256-thread geometry wherever the brick fits, 512 forbids it.
-        if (BN == 32 && wts.KT != 1 && env_nth != 512 && (a.CoutPad % 64 != 0 || env_nth == 256) && !(ep_ && atoi(ep_) != 0) &&
+        if (BN == 32 && wts.KT != 1 && env_nth != 512 && (a.CoutPad % 64 != 0 || env_nth == 256) && sw.pipe == 0 &&
             wino4_tiling(T, H, W, wts.KT, &TT2, &TH2, W4Geo<256>::TILES, W4Geo<256>::ROWS_A, W4Geo<256>::ROWS_B)) {
             thin = true; TT = TT2; TH = TH2;
         }
@@ -1083,29 +1097,29 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     a.hh_magic = ((1 << 20) + TH + 1) / (TH + 2);
     I2V_REQUIRE(!stats || (long)TT * TH * 4 <= (long)T * H * a.J, I2V_E_INVALID, "wino4: fused statistics need bricks inside one sample");
     a.order = env_order;
-    { const char* es_ = getenv("I2V_W4_SKEW"); a.skew = es_ ? atoi(es_) : 0; }
+    a.skew = sw.skew;
     const long nblk = (long)B * a.nbT * a.nbH * a.nbJ * (a.CoutPad / BN);
     I2V_REQUIRE(nblk > 0 && nblk < (1L << 30), I2V_E_INVALID, "wino4: grid of %ld workgroups", nblk);
     // the kernel's index tables (gpos: V rows, tpos / tres: output and residual positions) are 32-bit
     I2V_REQUIRE((long)T * a.nchunk * 6 * H * a.J * 64 < (1L << 31), I2V_E_INVALID, "wino4: the V operand of one sample ([%d,%d,%d] x %d chunks) exceeds the 2 GB a buffer descriptor offset can address", T, H, W, a.nchunk);
     I2V_REQUIRE((long)B * T * a.nchunk * 6 * H * a.J < (1L << 31) && (long)B * (wts.tdup ? 2 * T : T) * H * W < (1L << 31), I2V_E_INVALID,
                 "wino4: batch %d too large for the 32-bit row indices of this kernel ([%d,%d,%d] x %d chunks)", B, T, H, W, a.nchunk);
-    if (getenv("I2V_W4_TRACE")) {
+    if (sw.trace) {
         fprintf(stderr, "wino4: B %d T %d H %d W %d Cin %d Cout %d pad %d KT %d tdup %d TT %d TH %d res %p rt %d rs %d stats %p epi %d nblk %ld\n", B, T, H, W,
                 a.Cin, a.Cout, a.CoutPad, wts.KT, a.tdup, TT, TH, (const void*)res, a.rt, a.rs, (void*)stats, epi, nblk);
         (void)hipDeviceSynchronize();
     }
     if (BN == 64) {
-        if (wts.KT == 3) return launch_wino4<9, 64>(a, (unsigned)nblk, st);
-        if (wts.KT == 2) return launch_wino4<6, 64>(a, (unsigned)nblk, st);
-        return launch_wino4<3, 64>(a, (unsigned)nblk, st);   // one time slice: SPADE's 2-D convs
+        if (wts.KT == 3) return launch_wino4<9, 64>(a, (unsigned)nblk, st, sw.pipe);
+        if (wts.KT == 2) return launch_wino4<6, 64>(a, (unsigned)nblk, st, sw.pipe);
+        return launch_wino4<3, 64>(a, (unsigned)nblk, st, sw.pipe);   // one time slice: SPADE's 2-D convs
     }
     I2V_REQUIRE(wts.KT != 1, I2V_E_INVALID, "wino4: the 1x3x3 variant exists for 64-channel tiles only");
 #ifndef W4_TAPTIME
     if (thin) return wts.KT == 3 ? launch_wino4_thin<9>(a, (unsigned)nblk, st) : launch_wino4_thin<6>(a, (unsigned)nblk, st);
 #endif
-    if (wts.KT == 3) return launch_wino4<9, 32>(a, (unsigned)nblk, st);
-    return launch_wino4<6, 32>(a, (unsigned)nblk, st);
+    if (wts.KT == 3) return launch_wino4<9, 32>(a, (unsigned)nblk, st, sw.pipe);
+    return launch_wino4<6, 32>(a, (unsigned)nblk, st, sw.pipe);
 }
 
 #ifdef W4_TAPTIME

@@ -320,7 +320,11 @@ int conv_img_mfma_forward(const ConvImgMfmaWeights& wts, const float* in, float*
     // TCH output frames reads TCH + 2 input frames.  Depends on the batch, which changes the schedule only (same bits: see the kernel).
     int TCH = 1;
     {
+#ifdef I2V_MEASURE   // (measurement build only: the production library reads no environment variable on a launch path)
         const char* e = getenv("I2V_CONVIMG_TCH");
+#else
+        const char* e = nullptr;
+#endif
         const long bricks = (long)B * (H / CM_TH) * (W / CM_TW);
         for (int c = 16; c >= 2; c /= 2)
             if (T % c == 0 && bricks * (T / c) >= 2 * 768) { TCH = c; break; }

@@ -33,6 +33,9 @@ struct FlowTilePack {
     // half the streamed parameter bytes), activations rounded to fp16 per layer in registers, fp32 accumulation, bias / LeakyReLU /
     // coupling / log-det in fp32.  One MFMA per 16 x 16 x 16 block instead of four.
     bool f16 = false;
+    // A/B switches, read ONCE when the weights are packed (i2v_flow_load), never on a launch path: I2V_FLOW_NS = sample tiles per
+    // hidden-layer workgroup (0: by batch), I2V_FLOW_FOLD = 0 | 1 forces the unfolded / folded chain (-1: by batch)
+    int force_ns = 0, force_fold = -1;
 };
 
 // geometry the tile chain covers (every shipped config: 64 channels, hidden 512, depth 2); anything else runs the generic

@@ -646,6 +646,8 @@ static int upload_frags(DevBuf& dst, const std::vector<float>& w, bool f16) {
 int flow_tile_pack(FlowTilePack& p, int S, int H, int depth, int E, const float* W0, const float* Wmid, const float* W3T, bool f16) {
     p.ok = false;
     p.f16 = f16;
+    p.force_ns = env_int("I2V_FLOW_NS", 0);
+    p.force_fold = env_int("I2V_FLOW_FOLD", -1);
     p.S = S; p.H = H; p.depth = depth; p.E = E;
     p.HB = H / 16; p.NRT = 2 * p.HB; p.KE16 = (E + 15) / 16;
     const int HB = p.HB, NRT = p.NRT, KE16 = p.KE16, N2 = 2 * H, ld0 = 32 + E;
@@ -734,13 +736,13 @@ int flow_tile_enqueue(const FlowTileChain& c, bool reverse, char* ws, int B, hip
     float* Pbuf[2] = {reinterpret_cast<float*>(ws + L.P), reinterpret_cast<float*>(ws + L.P2)};   // half-step `it` writes Pbuf[it & 1]
     const FlowIo* io = p.io.as<FlowIo>();
     int ns = NST <= 4 ? 1 : NST <= 8 ? 2 : 4;   // sample tiles per hidden-layer workgroup: keep ~256 workgroups
-    if (const int e = env_int("I2V_FLOW_NS", 0)) ns = e >= 4 ? 4 : e >= 2 ? 2 : 1;
+    if (const int e = p.force_ns) ns = e >= 4 ? 4 : e >= 2 ? 2 : 1;
     const int groups = (NST + ns - 1) / ns;
     // Folded chain (the tail travels with the first hidden layer's launch: 82 launches per pass) or round 4's 122-launch chain.
     // Same bits either way (test_flow_fold_keeps_the_bits).  Every workgroup of a folded launch redoes the tail of its own sample
     // tiles (128 KB of partial tiles each), so it pays while a workgroup holds ONE sample tile (B <= 64: 508 -> 473 us at B = 64,
-    // 460 -> 439 at B = 8) and loses with four (B = 256: 765 -> 1083 us): default = folded iff ns == 1.  I2V_FLOW_FOLD=0|1 forces.
-    const bool fold = env_int("I2V_FLOW_FOLD", ns == 1 ? 1 : 0) != 0;
+    // 460 -> 439 at B = 8) and loses with four (B = 256: 765 -> 1083 us): default = folded iff ns == 1.  I2V_FLOW_FOLD=0|1 (read when the weights are packed) forces.
+    const bool fold = (p.force_fold >= 0 ? p.force_fold : (ns == 1 ? 1 : 0)) != 0;
     int seq = 0;   // launch number inside the pass
     const size_t fb = p.f16 ? 512 : 1024;   // bytes per weight fragment
 

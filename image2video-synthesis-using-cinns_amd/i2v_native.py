@@ -121,6 +121,18 @@ def build(force=False):
     return LIB_PATH
 
 
+MEASURE_LIB_PATH = os.path.join(_PKG, "lib", "libi2v_hip_measure.so")
+
+
+def build_measure():
+    """Compile the MEASUREMENT build of the library (``make measure``: -DI2V_MEASURE, the F(4,3) kernel's structure switches and
+    persistent instantiations).  Only tests and A/B runs load it, through ``I2V_LIB_PATH`` in a process of their own."""
+    subprocess.run(["make", "-C", CSRC, "-j4", "measure"], check=True)
+    if not os.path.exists(MEASURE_LIB_PATH):
+        raise I2VError(f"build did not produce {MEASURE_LIB_PATH}")
+    return MEASURE_LIB_PATH
+
+
 def lib():
     """The loaded shared library.  Fails loudly when it has not been built -- there is no fallback path."""
     global _lib

@@ -328,28 +328,46 @@ def test_decoder_alternative_kernel_paths(env, monkeypatch):
 
 
 @pytest.mark.parametrize("golden", ["dec_nf64_bair", "dec_nf32_128"])
-def test_f43_structure_switches_keep_the_bits(golden, monkeypatch):
+def test_f43_structure_switches_keep_the_bits(golden, monkeypatch, tmp_path):
     """The F(4,3) kernel's measurement switches change WHERE and WHEN a brick is computed, never the arithmetic of an output:
-    the software-pipelined persistent kernel (I2V_W4_PIPE=1: next brick's tables and first V brick fetched under the current
-    brick's pass B, four-quarter epilogue), the brick -> XCD orders and 32-channel workgroups must reproduce the default
-    kernel's frames bit for bit, on the 64-channel (BAIR nf = 64) and the 32-channel (128x128 nf = 32) instantiations; so must
-    the decoder's sub-batching of its last two levels (I2V_DEC_SUB)."""
+    the software-pipelined persistent kernels (I2V_W4_PIPE=1|2), their start skew, the brick -> XCD orders, 32-channel workgroups,
+    the 512- / 256-thread geometries and conv_img's frames per workgroup must reproduce the default kernel's frames bit for bit, on
+    the 64-channel (BAIR nf = 64) and the 32-channel (128x128 nf = 32) instantiations.  Since round 6 those switches exist only in the
+    MEASUREMENT build of the library (-DI2V_MEASURE, lib/libi2v_hip_measure.so): the production library reads no environment variable
+    on a launch path.  So the frames of the production library (this process) are handed to tests/measure_worker.py, which runs in
+    a process of its own with I2V_LIB_PATH on the measurement build.  The decoder's own switches (read when a handle is created:
+    sub-batching of the last two levels, in-call overlap) are flipped in this process."""
+    import json
+    import subprocess
+    import sys
+    import i2v_native
     g, meta = load_golden(golden)
     x0, z, _ = synth.bench_inputs(3, g["img"].shape[-1], 64)     # 3 samples: grids that are not a multiple of the CU count
     x0[1], z[1] = torch.from_numpy(g["img"][0]), torch.from_numpy(g["z"][0])
     x0, z = x0.cuda(), z.cuda()
     ref = _gen(meta)(x0, z)
     assert rel_l2(ref[1:2, ..., ::2, ::2].cpu(), g["out_s2"]) < TOL
-    for env, val in (("I2V_W4_PIPE", "1"), ("I2V_W4_PIPE", "2"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"), ("I2V_W4_NTH", "512"), ("I2V_W4_NTH", "256"), ("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2"), ("I2V_DEC_OVERLAP", "0"), ("I2V_DEC_OVERLAP", "2"), ("I2V_CONVIMG_TCH", "1"), ("I2V_CONVIMG_TCH", "2"), ("I2V_CONVIMG_TCH", "16")):
+    for env, val in (("I2V_DEC_SUB", "1"), ("I2V_DEC_SUB", "2"), ("I2V_DEC_OVERLAP", "0"), ("I2V_DEC_OVERLAP", "2")):
         monkeypatch.setenv(env, val)
         alt = _gen(meta)(x0, z)
         monkeypatch.delenv(env)
         assert torch.equal(alt, ref), (env, val, float((alt - ref).abs().max()))
-    for pipe in ("1", "2"):
-        monkeypatch.setenv("I2V_W4_PIPE", pipe)
-        gen = _gen(meta)
-        big = gen(x0.repeat(6, 1, 1, 1), z.repeat(6, 1))              # 18 samples: several bricks per persistent workgroup
-        assert torch.equal(big[:3], ref) and torch.equal(big[15:], ref), pipe
+    # the production library ignores the measurement switches altogether (no getenv on a launch path)
+    monkeypatch.setenv("I2V_W4_BN", "32")
+    monkeypatch.setenv("I2V_W4_PIPE", "1")
+    assert torch.equal(_gen(meta)(x0, z), ref)
+    monkeypatch.delenv("I2V_W4_BN")
+    monkeypatch.delenv("I2V_W4_PIPE")
+    if not os.path.exists(i2v_native.MEASURE_LIB_PATH):
+        i2v_native.build_measure()                               # (hipcc is on the GPU box; normally built by __graft_entry__.build())
+    blob = tmp_path / "case.npz"
+    np.savez(blob, x0=x0.cpu().numpy(), z=z.cpu().numpy(), ref=ref.cpu().numpy(), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    env = dict(os.environ, I2V_LIB_PATH=os.path.join("image2video-synthesis-using-cinns_amd", "lib", "libi2v_hip_measure.so"))   # relative to the repo root
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "measure_worker.py"), str(blob)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["checked"] >= 14 and res["bad"] == [], res
 
 
 def test_f43_tile_width_switch_across_batches():

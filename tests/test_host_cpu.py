@@ -29,6 +29,42 @@ def test_library_exports_every_declared_symbol():
     assert i2v_native.lib().i2v_version() >= 1
 
 
+def test_production_library_has_no_launch_path_environment_switches():
+    """Round-5 review item: an environment variable silently changing the production kernel is not a drop-in property.  The F(4,3)
+    kernel's structure switches (I2V_W4_*) and conv_img's frames-per-workgroup switch exist in the measurement build only
+    (`make measure`, -DI2V_MEASURE); the production library neither contains their names nor the persistent-kernel instantiations,
+    and every `getenv` left in csrc/ sits in a handle-creation / weight-packing function or inside `#ifdef I2V_MEASURE`."""
+    import i2v_native
+    if not os.path.exists(i2v_native.LIB_PATH):
+        i2v_native.build()
+    blob = open(i2v_native.LIB_PATH, "rb").read()
+    for name in (b"I2V_W4_PIPE", b"I2V_W4_BN", b"I2V_W4_ORDER", b"I2V_W4_NTH", b"I2V_W4_SKEW", b"I2V_W4_TRACE", b"I2V_CONVIMG_TCH"):
+        assert name not in blob, name
+    assert b"conv_wino4_f16x3_kernelILi9ELi64ELi0ELi512E" in blob
+    for pipe in (1, 2):
+        assert b"conv_wino4_f16x3_kernelILi9ELi64ELi%dELi512E" % pipe not in blob
+    if os.path.exists(i2v_native.MEASURE_LIB_PATH):
+        mblob = open(i2v_native.MEASURE_LIB_PATH, "rb").read()
+        assert b"I2V_W4_PIPE" in mblob and b"conv_wino4_f16x3_kernelILi9ELi64ELi1ELi512E" in mblob
+    # source level: getenv only at creation / pack time (functions named below) or under I2V_MEASURE
+    allowed = {"i2v_dec.hip": ("i2v_dec_create", "i2v_gblock_create"), "i2v_flow.hip": ("i2v_flow_create",),
+               "i2v_flow_tile.hip": ("env_int",), "i2v_conv16w4.hip": ("w4_switches",), "i2v_convimg.hip": ("conv_img_mfma_forward",)}
+    import glob
+    for f in glob.glob(os.path.join(PKG, "csrc", "*.hip")):
+        text = open(f).read()
+        if "getenv" not in text:
+            continue
+        assert os.path.basename(f) in allowed, f
+    w4 = open(os.path.join(PKG, "csrc", "i2v_conv16w4.hip")).read()
+    body = w4[w4.index("static W4Switches w4_switches()"):]
+    body = body[:body.index("\n}\n")]
+    assert w4.count("getenv(") == body.count("getenv(") and body.index("#ifdef I2V_MEASURE") < body.index("getenv(") < body.index("#endif")
+    ci = open(os.path.join(PKG, "csrc", "i2v_convimg.hip")).read()
+    assert ci.count("getenv(") == 1 and ci.index("#ifdef I2V_MEASURE") < ci.index("getenv(")
+    ft = open(os.path.join(PKG, "csrc", "i2v_flow_tile.hip")).read()
+    assert len(re.findall(r'env_int\("', ft)) == 2 and all(m.start() > ft.index("int flow_tile_pack(FlowTilePack& p") for m in re.finditer(r'env_int\("', ft))
+
+
 def test_state_dict_layout_matches_reference_keys():
     from stage1_VAE.modules.decoder import Generator
     from stage2_cINN.modules.flow_blocks import ConditionalFlow
@@ -312,10 +348,13 @@ def test_winograd_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     assert caw.check_scalar_operands(text, "conv_wino_f16x3_kernel") == []
 
 
-def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
+@pytest.mark.parametrize("measure", [False, True])
+def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path, measure):
     """The same static checks for the Winograd F(4,3) kernel (csrc/i2v_conv16w4.hip): every instantiation has TWO tap loops
     (pass A: planes 0..3, pass B: planes 4, 5), no scratch, exactly the loads the macros issue, and the replay of each
-    compiled loop against the in-order VMEM queue finds no hazard while a wait relaxed by one does."""
+    compiled loop against the in-order VMEM queue finds no hazard while a wait relaxed by one does.  Both builds: the production
+    library (7 one-workgroup-per-brick instantiations, no `getenv` in the object) and the measurement build (-DI2V_MEASURE: + the
+    ten persistent-kernel instantiations behind I2V_W4_PIPE)."""
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -323,7 +362,7 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     src = os.path.join(PKG, "csrc", "i2v_conv16w4.hip")
     asm = tmp_path / "w4.s"
     subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", src,
-                    "-o", str(asm)], check=True, capture_output=True, timeout=900)
+                    "-o", str(asm)] + (["-DI2V_MEASURE"] if measure else []), check=True, capture_output=True, timeout=900)
     text = asm.read_text()
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import check_asm_waits as caw
@@ -332,7 +371,8 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path):
     # <9,64> <6,64> <3,64> (SPADE's 2-D convs) <9,32> <6,32>, each as round 3's one-workgroup-per-brick kernel (PIPE = 0), as the
     # software-pipelined persistent kernel (PIPE = 1) and as its "lite" form (PIPE = 2); round 5: <9,32> <6,32> as 256-thread
     # workgroups of 64 tiles (two per CU), whose half-requests are 5 + 4 (pass A) and 3 + 2 (pass B) load instructions
-    assert len(kernels) == 17, [k[0] for k in kernels]
+    assert len(kernels) == (17 if measure else 7), [k[0] for k in kernels]
+    assert measure or all(k[3] == "0" for k in kernels)   # production: PIPE = 0 only
     assert sorted(k[0] for k in kernels if k[4] == "256") == sorted(
         "_ZN3i2v23conv_wino4_f16x3_kernelILi%dELi32ELi0ELi256EEEvNS_6W4ArgsE" % n for n in (9, 6))
     for name, nt, bn, pipe, nth, whole in kernels:

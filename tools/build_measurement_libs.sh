@@ -3,11 +3,15 @@
 #   tools/_tl/libi2v_hip_nopreload.so the library without -amdgpu-kernarg-preload-count
 #   tools/_tl/libi2v_hip_flowtl.so   the library with -DFLOW_TIMELINE (per-launch / per-phase stamps of the cINN tile chain,
 #                                    read by tools/flow_timeline.py)
-#   tools/conv16w_check[_tl|_tt]     the conv check tool: plain, -DW4_TIMELINE, -DW4_TAPTIME
+#   tools/conv16w_check[_tl|_tt]     the conv check tool: plain, -DW4_TIMELINE, -DW4_TAPTIME (all with -DI2V_MEASURE: the I2V_W4_* switches)
+# The build that reads the F(4,3) structure switches (I2V_W4_PIPE / SKEW / ORDER / BN / NTH / TRACE, I2V_CONVIMG_TCH) is
+#   image2video-synthesis-using-cinns_amd/lib/libi2v_hip_measure.so   (make -C .../csrc measure; also built by __graft_entry__.build())
+# -- the production library reads no environment variable on a launch path.
 set -e
 cd "$(dirname "$0")/.."
 CS=image2video-synthesis-using-cinns_amd/csrc
 mkdir -p tools/_tl
+make -C $CS -j4 measure
 if [ "$1" != "conv" ]; then
   ALL="$CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_wino32.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip"
   # the shipped library WITHOUT kernarg preload (A/B of that flag: FLOWTIME_LIB=tools/_tl/libi2v_hip_nopreload.so python tools/flowtime.py)
@@ -26,9 +30,9 @@ if [ "$1" = "nt" ]; then
 fi
 if [ "$1" != "flow" ]; then
   SRC="tools/conv16w_check.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_conv16.hip $CS/i2v_common.hip"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$CS -Iinclude $SRC -o tools/conv16w_check &
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DW4_TIMELINE -I$CS -Iinclude $SRC -o tools/conv16w_check_tl &
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DW4_TAPTIME -I$CS -Iinclude $SRC -o tools/conv16w_check_tt &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -I$CS -Iinclude $SRC -o tools/conv16w_check &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -DW4_TIMELINE -I$CS -Iinclude $SRC -o tools/conv16w_check_tl &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -DW4_TAPTIME -I$CS -Iinclude $SRC -o tools/conv16w_check_tt &
 fi
 wait
 ls -la tools/_tl tools/conv16w_check*
