@@ -99,6 +99,14 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="1 (default): the cINN pass of step k+1 runs on a side stream underneath the decoder of step k "
                          "(i2v_pipeline.LatentPrefetcher; every step still has its own pass, the first one is exposed); 0: serial")
+    ap.add_argument("--side-stream", default="shared", choices=["shared", "own"],
+                    help="shared (default): the decoder handle runs its side work (SPADE branches, learned shortcuts) on the SAME stream "
+                         "as the cINN prefetch -- main + ONE side stream (+ the collation stream for N > 1) -- the configuration every N "
+                         "runs; own: a side stream of the handle's own next to the prefetch stream (round 5)")
+    ap.add_argument("--lean", action="store_true",
+                    help="timed steps, checksums, single_call and the per-layer roofline only (no sustained / exact-fp32 / cINN / probe / "
+                         "embedder legs): what the default run's `config_128` child leg uses")
+    ap.add_argument("--no-config-128", action="store_true", help="skip the Landscape 128x128 child leg of the default line")
     ap.add_argument("--dry", action="store_true",
                     help="CPU / gloo rehearsal of the launch path (self-launch, sharding, collation, JSON line); the step is a "
                          "stand-in without kernels and the line says so")
@@ -128,9 +136,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         # N > 1 adds RCCL's own streams and the collation stream to the main and the cINN stream; HIP multiplexes streams onto four
-        # hardware queues and streams sharing a queue serialise, so the decoder's in-call side stream (measured on ONE GPU only:
-        # -1.1 % / -1.9 % per step) stays off where it could not be measured
-        os.environ.setdefault("I2V_DEC_OVERLAP", "0")
+        # hardware queues and streams sharing a queue serialise.  Round 5 switched the decoder's in-call side stream off here (and
+        # thereby measured `small_batch` in a configuration the N > 1 job did not run); since round 6 the decoder's side work shares
+        # the cINN prefetch stream (--side-stream shared: main + one side + collation), the SAME configuration at every N.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         # the job must really be N ranks over RCCL on N distinct GPUs -- not N replicas that never met
@@ -171,6 +179,9 @@ def main():
 
     import i2v_pipeline
     prefetch = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True), device=dev, enabled=bool(args.pipeline))
+    shared = args.side_stream == "shared" and prefetch.enabled
+    if shared:
+        gen.share_side_stream(prefetch.stream)
 
     last_z = {}
     step_sums = []   # one device-side checksum per step (see checksum())
@@ -199,6 +210,14 @@ def main():
         ticket = prefetch.submit(res_d, emb_d)
         for k in range(n):
             z = prefetch.get(ticket)
+            if shared:
+                # one side stream, in order: the decoder's side work of step k first, the pass of step k+1 behind it (its inputs
+                # are complete at `ev`, it does not wait for the decoder's launches)
+                ev = prefetch.mark()
+                decode(z)
+                if k + 1 < n:
+                    ticket = prefetch.submit(res_d, emb_d, _ready=ev)
+                continue
             if k + 1 < n:
                 ticket = prefetch.submit(res_d, emb_d)
             decode(z)
@@ -286,6 +305,10 @@ def main():
 
     nb = hi - lo
     single_ms = None if args.no_extras else single_call_ms()   # (every rank: the collation inside is a collective)
+    if args.lean:
+        args.sustain, args.no_exact, args.small_batch, args.no_cpu_baseline, args.no_config_128 = 0.0, True, 0, True, True
+        if args.live_traffic is None:
+            args.live_traffic = False
     # steady state: >= 10 s of back-to-back steps (a fresh box clocks higher for the first seconds than under sustained load)
     sustained = None
     if not args.no_extras and args.sustain > 0:
@@ -321,6 +344,8 @@ def main():
                           "spectral_norm": True, "mma": 0})
         gen0.load_state_dict(dsd)
         gen0 = gen0.to(dev).eval()
+        if shared:
+            gen0.share_side_stream(prefetch.stream)
         single_call_ms(gen0, 1)                        # warm-up
         gen0.native().set_profile(True)
         ms0 = single_call_ms(gen0, 3)
@@ -340,7 +365,7 @@ def main():
         del gen0
     # cINN pass latency (device-timed, median of 100 after 10 warm-ups: SURVEY §8d), rank 0 only
     cinn = {}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and not args.lean:
         for direction in ("inv", "fwd"):
             fn = (lambda: flow(res_d, emb_d, reverse=True)) if direction == "inv" else (lambda: flow(res_d, emb_d))
             for _ in range(10):
@@ -408,11 +433,12 @@ def main():
                 "inv_latency_us": cinn["inv_us"], "fwd_latency_us": cinn["fwd_us"],
                 "inv_latency_us_min": cinn["inv_us_min"], "fwd_latency_us_min": cinn["fwd_us_min"],
                 "latency_method": "HIP events, median of 100 passes after 10 warm-ups", "batch": nb,
+                **cinn_latency_floor(flow, nb, cinn["inv_us"]),
                 "measured_hbm_bytes_per_pass": measured, "measured_hbm_bytes_source": msrc,
             }
-        if gen.mma == 1 and result.get("roofline") and not args.no_extras and world == 1:
+        if gen.mma == 1 and result.get("roofline") and not args.no_extras and world == 1 and not args.lean:
             result["roofline"]["undisturbed"] = undisturbed_roofline(cfg, dsd, dev, x0_d, last_z["z"], vid_length, result["roofline"])
-        if gen.mma == 1 and result.get("roofline") and not args.no_extras:
+        if gen.mma == 1 and result.get("roofline") and not args.no_extras and not args.lean:
             # the data-sheet peak assumes 2.4 GHz; with live operands the matrix cores sustain less (power management).
             # An MFMA-only loop of the conv kernel's shape, measured here on this box, gives the sustained rate.
             sustained = i2v_native.probe_mfma_f16(dev)
@@ -424,13 +450,21 @@ def main():
                 "frac_of_data_sheet_peak": sustained / PEAK_F16_MFMA_TFLOPS,
                 "dominant_kernel_issue_frac_of_sustained": r["mfma_issue_frac"] * PEAK_F16_MFMA_TFLOPS / sustained,
             }
-        if not args.no_extras:
+        if not args.no_extras and not args.lean:
             result["embedder"] = embedder_latency(cfg, x0_d)
             result["encoder"] = encoder_latency(cfg, x0_d)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+        result["streams"] = {"side_stream": args.side_stream if prefetch.enabled else "none",
+                             "what": ("main + ONE side stream: the cINN prefetch and the decoder handle's side work (SPADE branches, learned "
+                                      "shortcuts) share it" if shared else "main + the cINN prefetch stream + the decoder handle's own side stream") +
+                                     ("; + the collation stream and RCCL's" if world > 1 else ""),
+                             "dec_overlap_env": os.environ.get("I2V_DEC_OVERLAP"),
+                             "same_configuration_for_every_n": True}
         if small is not None:
             result["small_batch"] = small
+        if world == 1 and default_workload and not args.no_extras and not args.no_config_128:
+            result["config_128"] = config_128_leg(args)
         live = args.live_traffic if args.live_traffic is not None else (not args.no_extras)
         if live and world == 1:
             live_traffic(result, args)
@@ -602,10 +636,18 @@ def small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, nb, result, pf):
         gen.prepare(x)
         return gen.decode_sequence(x, pf.get(tk).view(nb, -1), vid_length)
 
+    shared = getattr(gen, "_shared_side", None) is not None and pf.enabled
+
     def stream(n):
         tk = pf.submit(r, e)
         for k in range(n):
             z = pf.get(tk)
+            if shared:   # (one side stream: decoder of step k first, the pass of step k+1 behind it -- as run_steps does)
+                ev = pf.mark()
+                gen.decode_sequence(x, z.view(nb, -1), vid_length)
+                if k + 1 < n:
+                    tk = pf.submit(r, e, _ready=ev)
+                continue
             if k + 1 < n:
                 tk = pf.submit(r, e)
             gen.decode_sequence(x, z.view(nb, -1), vid_length)
@@ -631,11 +673,58 @@ def small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, nb, result, pf):
     return {"what": f"the same step at batch {nb} = the per-GPU share of the B = 64 job on {64 // nb} GPUs, measured on this one GPU",
             "batch": nb, "single_call_ms": single, "single_call_frames_per_s": frames / (single * 1e-3),
             "pipelined_ms_per_step": piped, "pipelined_frames_per_s": frames / (piped * 1e-3),
-            "projected_strong_scaling": {"gpus": 64 // nb,
-                                         "single_call": None if not big_single else big_single / single,
-                                         "pipelined": result["ms_per_step"] / piped,
-                                         "note": "PROJECTION from one-GPU runs: T(B = 64) / T(B = %d), before the all-gather of the "
-                                                 "[B/N,16,3,64,64] blocks (0.8 MB per rank and step); not a multi-GPU measurement" % nb}}
+            "projected_strong_scaling": projected_scaling(64 // nb, nb, frames // nb, big_single, single, result["ms_per_step"], piped)}
+
+
+XGMI_LINK_GBS = 153.0   # MI355X_MICROARCH.md: one xGMI link, per direction (7 links per GPU, point to point)
+
+
+def projected_scaling(n, nb, frames_per_sample, big_single_ms, single_ms, big_piped_ms, piped_ms):
+    """T(64) / T(64 / n) from one-GPU runs in the stream configuration EVERY N runs (--side-stream), with an explicit term for the
+    one collective of the path: the all-gather of the [B/N, T, 3, 64, 64] fp32 blocks as a ring over ONE xGMI link per hop
+    ((n - 1) hops of one rank's block) plus one launch.  A single call waits for it; the pipelined stream overlaps it with the next
+    step (i2v_dist.OverlappedCollator), so there it is reported next to the ratio, not inside it."""
+    block = nb * frames_per_sample * 3 * 64 * 64 * 4
+    ag_ms = (n - 1) * block / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.02
+    return {"gpus": n,
+            "single_call": None if not big_single_ms else big_single_ms / (single_ms + ag_ms),
+            "single_call_before_collation": None if not big_single_ms else big_single_ms / single_ms,
+            "pipelined": big_piped_ms / piped_ms,
+            "all_gather_ms_model": ag_ms, "all_gather_bytes_per_rank": block,
+            "all_gather_model": f"ring: (N - 1) x one rank's block over one {XGMI_LINK_GBS:.0f} GB/s xGMI link + 20 us launch; exposed in a "
+                                "single call, overlapped with the next step in the pipelined stream (where it has to stay under the step time)",
+            "note": "PROJECTION from one-GPU runs: T(B = 64) / T(B = %d) measured in the same stream configuration the N > 1 job runs; "
+                    "not a multi-GPU measurement" % nb}
+
+
+def config_128_leg(args):
+    """Second workload of the default line (round-5 review: three of five BASELINE configs had never been timed by the driver):
+    BASELINE configs[2], Landscape 128x128x16 nf = 32 E = 128, batch 32 -- run as a CHILD `bench.py --config land128 --lean` (its own
+    process: its own handles and streams, this process idles meanwhile), 10 timed steps after 3 warm-ups, every step checksummed
+    against a serial call, single call, dominant-kernel roofline and the g_4 rows of the per-layer table."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "land128", "--steps", "10", "--warmup", "3", "--lean",
+           "--side-stream", args.side_stream, "--pipeline", str(args.pipeline)]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=float(os.environ.get("I2V_CONFIG128_TIMEOUT", "240")))
+        if p.returncode != 0:
+            raise RuntimeError(f"rc {p.returncode}: {p.stderr[-300:]}")
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+    except (OSError, subprocess.SubprocessError, ValueError, RuntimeError, IndexError) as e:
+        return {"error": repr(e)[:400], "seconds": time.perf_counter() - t0}
+    ro = r["roofline"] or {}
+    return {"workload": r["config"]["workload"], "command": "bench.py " + " ".join(cmd[2:]),
+            "ms_per_step": r["ms_per_step"], "frames_per_s": r["value"], "steps": r["steps"], "warmup": r["warmup"],
+            "single_call": r.get("single_call"), "steps_check": r["steps_check"],
+            "roofline": {k: ro.get(k) for k in ("kernel_name", "bound", "achieved", "peak", "unit", "frac", "mfma_issue_frac", "ms_per_step",
+                                                "avg_launch_ms", "launches", "time_share")},
+            "roofline_all_conv3_frac": (r.get("roofline_all_conv3") or {}).get("frac"),
+            "per_layer_g4": [L for L in (r.get("roofline_all_conv3") or {}).get("per_layer", []) if L["layer"].startswith("g_4.")],
+            "per_layer": (r.get("roofline_all_conv3") or {}).get("per_layer"),
+            "output_check": {k: r["output_check"].get(k) for k in ("finite", "max_abs", "shape", "status_flags")},
+            "seconds": time.perf_counter() - t0}
+
 
 
 def live_traffic(result, args):
@@ -688,6 +777,24 @@ def live_traffic(result, args):
     if passes and "roofline_cinn" in result:
         result["roofline_cinn"]["measured_hbm_bytes_per_pass"] = sum(v["read_bytes"] + v["write_bytes"] for v in flow.values()) / passes
         result["roofline_cinn"]["measured_hbm_bytes_source"] = "measured by this run (same child passes)"
+
+
+BOUNDARY_US = 1.45      # MI355X_MICROARCH.md: dependent kernel boundary, same stream (eager == hipGraph), between trivial 256-WG kernels
+L2_ROUND_TRIP_US = 0.11  # MI355X_MICROARCH.md: global_load L2-hit latency ~180-225 cycles (200 cycles at the 1.8 GHz these small launches clock at)
+
+
+def cinn_latency_floor(flow, nb, inv_us):
+    """What the 160-deep dependent exchange of one pass cannot go below AS A CHAIN OF LAUNCHES: every launch pays the dependent
+    kernel boundary and, inside, at least one dependent trip to L2 for the activations the previous launch left there plus one for
+    its weight fragments (issued together: one trip), and the HBM time of the parameters it streams.  `frac_of_floor` = floor /
+    measured: how much of the pass is explained by the launch structure, next to `frac` (bytes / time against 8 TB/s), which a
+    latency chain cannot approach."""
+    launches = 82 if nb <= 64 else 122   # folded chain while a workgroup holds one sample tile (csrc/i2v_flow_tile.hip)
+    stream_us = flow.native().param_bytes / (PEAK_HBM_GBS * 1e9) * 1e6
+    floor = launches * (BOUNDARY_US + L2_ROUND_TRIP_US) + stream_us
+    return {"launches_per_pass": launches, "latency_floor_us": floor, "frac_of_floor": floor / inv_us,
+            "latency_floor_model": f"{launches} launches x ({BOUNDARY_US} us dependent boundary + {L2_ROUND_TRIP_US} us L2 round trip) + "
+                                   f"{stream_us:.1f} us to stream the parameters once at {PEAK_HBM_GBS:.0f} GB/s (MI355X_MICROARCH.md figures)"}
 
 
 def _latest_traffic_file():

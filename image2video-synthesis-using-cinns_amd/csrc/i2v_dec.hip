@@ -678,6 +678,7 @@ struct i2v_dec {
     int overlap = 1;
     int no_side_shortcut = 0;   // env I2V_DEC_OVERLAP=2: branches on the side stream, shortcuts inline (A/B of the two halves)
     hipStream_t side = nullptr;
+    bool side_owned = true;   // false: `side` is a caller's stream (i2v_dec_set_side_stream), e.g. the one its cINN prefetch runs on
     hipEvent_t ev_fork = nullptr, ev_lvl[6] = {};
     // ... and the learned shortcut of a block (Norm3D + 1x1x1 conv at the low resolution: an HBM-bound GEMM that only conv_1 needs)
     // runs there too, underneath the block's modulate / conv_0 chain: ev_x[k] = block input and its statistics complete (caller's
@@ -710,7 +711,7 @@ struct i2v_dec {
             if (e) (void)hipEventDestroy(e);
         if (status_dev) (void)hipFree(status_dev);
         if (status_host) (void)hipHostFree(status_host);
-        if (side) (void)hipStreamDestroy(side);
+        if (side && side_owned) (void)hipStreamDestroy(side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (auto& e : ev_lvl)
             if (e) (void)hipEventDestroy(e);
@@ -1509,8 +1510,12 @@ static int fork_spade(i2v_dec* d, const DecWs& L, char* ws, const float* img, in
     *done = false;
     if (!d->overlap || d->tap_dst) return I2V_OK;
     if (stream_is_capturing(st)) return I2V_OK;
+    if (d->side && d->side == st) return I2V_OK;   // the caller runs this call ON the shared side stream: nothing to fork to
     if (!d->side) {
         I2V_HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+        d->side_owned = true;
+    }
+    if (!d->ev_fork) {
         I2V_HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
         for (auto& e : d->ev_lvl) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : d->ev_x) I2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1693,6 +1698,23 @@ int i2v_dec_prepare(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
 int i2v_dec_prepare_cancel(i2v_dec* d) {
     I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_prepare_cancel: null handle");
     d->prep_img = nullptr;   // (a forked prepare keeps side_unjoined: the next forward / prepare / i2v_dec_join joins it)
+    return I2V_OK;
+}
+
+int i2v_dec_set_side_stream(i2v_dec* d, void* side_stream) {
+    I2V_REQUIRE(d, I2V_E_INVALID, "i2v_dec_set_side_stream: null handle");
+    I2V_REQUIRE_DEVICE(d->device, "i2v_dec_set_side_stream");
+    hipStream_t ns = static_cast<hipStream_t>(side_stream);
+    if (d->side && d->side == ns && !d->side_owned) return I2V_OK;
+    // whatever the old side stream still carries for this handle completes first (rare: a host wait at configuration time)
+    if (d->side) {
+        I2V_HIP_CHECK(hipStreamSynchronize(d->side));
+        if (d->side_owned) (void)hipStreamDestroy(d->side);
+    }
+    d->side_unjoined = false;
+    d->prep_img = nullptr;
+    d->side = ns;                 // null: the handle creates its own stream again at the next fork
+    d->side_owned = ns == nullptr;
     return I2V_OK;
 }
 

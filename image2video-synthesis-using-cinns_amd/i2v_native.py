@@ -102,6 +102,7 @@ SYMBOLS = {
     "i2v_dec_prepare": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_int32, c_void_p]),
     "i2v_dec_prepare_cancel": (c_int32, [c_void_p]),
     "i2v_dec_join": (c_int32, [c_void_p, c_void_p]),
+    "i2v_dec_set_side_stream": (c_int32, [c_void_p, c_void_p]),
     "i2v_dec_set_profile": (c_int32, [c_void_p, c_int32]),
     "i2v_dec_debug_tap": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t]),
     "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
@@ -317,8 +318,9 @@ class NativeDecoder(_Handle):
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
-            _lib.i2v_dec_destroy(self._h)
+            _lib.i2v_dec_destroy(self._h)     # (synchronises the side stream; a shared one is still alive: _side_stream is released below)
             self._h = None
+        self._side_stream = None
 
     @_on_device
     def load(self, state_dict):
@@ -369,6 +371,18 @@ class NativeDecoder(_Handle):
             _check(lib().i2v_dec_debug_tap(self._h, -1, -1, None, 0), "i2v_dec_debug_tap")
         else:
             _check(lib().i2v_dec_debug_tap(self._h, block, which, dst.data_ptr(), dst.numel()), "i2v_dec_debug_tap")
+
+    @_on_device
+    def set_side_stream(self, stream):
+        """i2v_dec_set_side_stream: run the handle's side work (SPADE branches, learned shortcuts, ``prepare``) on ``stream`` (a
+        ``torch.cuda.Stream``, e.g. ``LatentPrefetcher.stream``) instead of a stream of the handle's own; ``None`` restores that.
+        The binding keeps the stream object alive for as long as the handle uses it."""
+        if stream is not None and stream.device != self.device:
+            raise I2VError(f"side stream on {stream.device} for a handle on {self.device}")
+        _check(lib().i2v_dec_set_side_stream(self._h, c_void_p(stream.cuda_stream) if stream is not None else None),
+               "i2v_dec_set_side_stream")
+        self._side_stream = stream
+        self._prep = None
 
     def _workspace(self, nbytes, device):
         """The handle's workspace; before it is REPLACED by a larger one, the current stream joins the handle's side stream (a forked

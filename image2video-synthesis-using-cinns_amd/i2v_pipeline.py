@@ -25,13 +25,31 @@ class LatentPrefetcher:
         prio = int(os.environ.get("I2V_PREFETCH_PRIO", "-1"))
         self.stream = torch.cuda.Stream(device=device, priority=prio) if self.enabled else None
 
-    def submit(self, *args, **kwargs):
+    def mark(self):
+        """An event on the current stream: "everything enqueued so far is complete".  Pass it to ``submit(..., _ready=ev)`` when the
+        arguments of the next pass are complete NOW but the submit itself comes later (behind the decoder's launches, see the
+        shared-side-stream order below) -- the pass then does not wait for those launches."""
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def submit(self, *args, _ready=None, **kwargs):
         """Enqueue ``latent_fn(*args)`` on the side stream (after everything already enqueued on the current stream, so
-        the arguments are complete).  Returns a ticket for ``get``."""
+        the arguments are complete; or after the event ``_ready`` of an earlier ``mark()``).  Returns a ticket for ``get``.
+
+        When the decoder shares this stream for its own side work (``Generator.share_side_stream(pf.stream)``: ONE side stream per
+        job), enqueue the decoder of batch k FIRST and the pass of batch k+1 behind it -- the side stream runs in order, and a pass
+        enqueued in front would delay the decoder's first SPADE maps by its 0.45 ms:
+
+            ev = pf.mark(); frames_k = decoder(x0_k, z_k); t = pf.submit(res_{k+1}, emb_{k+1}, _ready=ev)"""
         if not self.enabled:
             return (self.latent_fn(*args, **kwargs), None)
-        ready = torch.cuda.Event()
-        ready.record()
+        ready = _ready
+        if ready is None:
+            ready = torch.cuda.Event()
+            ready.record()
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
             z = self.latent_fn(*args, **kwargs)

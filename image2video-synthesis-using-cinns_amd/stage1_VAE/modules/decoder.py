@@ -70,6 +70,8 @@ class Generator(NativeBacked):
         h = native.NativeDecoder(self.channel_factor, self.z_dim, self.upsample_s, self.upsample_t, self.use_spectral,
                                  mma=self.mma, device=self.module_device())
         h.load(self.state_dict())
+        if getattr(self, "_shared_side", None) is not None and self._shared_side.device == h.device:
+            h.set_side_stream(self._shared_side)
         return h
 
     def forward(self, img, motion, out=None):
@@ -91,6 +93,13 @@ class Generator(NativeBacked):
         for k in range(1, n):
             self.forward(seq[:, k * T - 1], z, out=seq[:, k * T:(k + 1) * T])
         return seq
+
+    def share_side_stream(self, stream):
+        """Not a reference method: run the decoder's side work (SPADE branches, learned shortcuts, ``prepare``) on ``stream`` -- the
+        stream the caller's cINN prefetch runs on (``i2v_pipeline.LatentPrefetcher.stream``) -- instead of a stream the native handle
+        creates: one side stream per job (``None``: the handle's own again).  Survives a rebuild of the native handle."""
+        object.__setattr__(self, "_shared_side", stream)
+        self.native().set_side_stream(stream)
 
     def prepare(self, img):
         """Not a reference method: enqueue the SPADE branches of all blocks for the start frames ``img`` (they do not depend on

@@ -195,6 +195,12 @@ int i2v_dec_prepare_cancel(i2v_dec* d);
  * consumed) and drops the pending prepare: behind this call `stream` bounds the lifetime of the workspace / start frames again.
  * No reference counterpart (the reference has one stream: generate_samples.py:47-54). */
 int i2v_dec_join(i2v_dec* d, void* stream);
+/* The handle's side work (SPADE conditioning branches, learned shortcuts, i2v_dec_prepare) runs on `side_stream` instead of a stream
+ * the handle creates -- typically the stream the caller's cINN prefetch already runs on, so that a job uses main + ONE side stream
+ * (+ its collation stream) next to RCCL's: HIP multiplexes streams onto four hardware queues, and streams that share a queue
+ * serialise.  `side_stream` stays the caller's (it must outlive the handle or be reset with NULL: the handle then creates its own
+ * again).  Same kernels, same events, same bits.  No reference counterpart (the reference has one stream). */
+int i2v_dec_set_side_stream(i2v_dec* d, void* side_stream);
 /* Roofline instrumentation.  With profiling on, every 3x3x3 Conv3d launch (the dominant kernel) is bracketed by HIP
  * events recorded on the launch stream -- no synchronisation is added to the forward.  After the caller has
  * synchronised, i2v_dec_get_profile resolves the pending pairs and returns the totals since set_profile(d, 1):

@@ -422,6 +422,49 @@ def test_decoder_in_call_spade_overlap_keeps_the_bits(golden, monkeypatch):
     assert all(torch.equal(res[i], refs[i % 3]) for i in range(6))
 
 
+def test_decoder_shared_side_stream_keeps_the_bits():
+    """Round 6: the decoder handle can run its side work (SPADE branches, learned shortcuts, prepare) on a stream the CALLER owns --
+    the cINN prefetch stream (i2v_dec_set_side_stream / Generator.share_side_stream): one side stream per job, the configuration
+    bench.py runs at every N.  Same kernels, same events: the pipelined loop in the shared order (decoder of batch k first, the pass
+    of batch k+1 behind it on the same stream) must give the frames of the serial loop bit for bit, single calls with a prepare
+    too, and handing the stream back (None) must work while work is still queued."""
+    import i2v_pipeline
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    flow = ConditionalFlow(64, 64, 512, 2, 20, conditioning_option="None")
+    flow.load_state_dict(T(synth.flow_state_dict(seed=7, embedding_dim=64)))
+    flow = flow.cuda().eval()
+    xs, rs, es = [], [], []
+    for k in range(4):
+        x0, r, e = synth.bench_inputs(3, 64, 64)
+        xs.append((x0 * (1.0 - 0.2 * k)).cuda().contiguous()); rs.append((r + 0.1 * k).cuda().contiguous()); es.append(e.cuda().contiguous())
+    refs = [gen(xs[k], flow(rs[k], es[k], reverse=True).view(3, -1)) for k in range(4)]
+    torch.cuda.synchronize()
+    pf = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True))
+    gen.share_side_stream(pf.stream)
+    for rep in range(3):
+        outs = []
+        tk = pf.submit(rs[0], es[0])
+        for k in range(4):
+            z = pf.get(tk)
+            ev = pf.mark()
+            outs.append(gen(xs[k], z.view(3, -1)))
+            if k + 1 < 4:
+                tk = pf.submit(rs[k + 1], es[k + 1], _ready=ev)
+        for k in range(4):
+            assert torch.equal(outs[k], refs[k]), (rep, k)
+    # single calls: pass on the side stream, prepare behind it on the same stream, then the decoder
+    for k in (2, 0):
+        tk = pf.submit(rs[k], es[k])
+        gen.prepare(xs[k])
+        assert torch.equal(gen(xs[k], pf.get(tk).view(3, -1)), refs[k])
+    gen.prepare(xs[1])                       # a prepare is pending on the shared stream when the handle gets its own stream back
+    gen.share_side_stream(None)
+    assert torch.equal(gen(xs[1], flow(rs[1], es[1], reverse=True).view(3, -1)), refs[1])
+    assert gen.native().status() == 0
+
+
 def test_decoder_prepare_equals_plain_forward():
     """i2v_dec_prepare (Generator.prepare): the SPADE branches of all blocks computed ahead of the forward -- the next forward
     with the same start-frame tensor must give the same bits as a plain one; a forward with ANOTHER tensor in between must
