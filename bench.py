@@ -99,10 +99,15 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="1 (default): the cINN pass of step k+1 runs on a side stream underneath the decoder of step k "
                          "(i2v_pipeline.LatentPrefetcher; every step still has its own pass, the first one is exposed); 0: serial")
-    ap.add_argument("--side-stream", default="shared", choices=["shared", "own"],
-                    help="shared (default): the decoder handle runs its side work (SPADE branches, learned shortcuts) on the SAME stream "
-                         "as the cINN prefetch -- main + ONE side stream (+ the collation stream for N > 1) -- the configuration every N "
-                         "runs; own: a side stream of the handle's own next to the prefetch stream (round 5)")
+    ap.add_argument("--side-stream", default="auto", choices=["auto", "shared", "own"],
+                    help="own: the decoder handle runs its side work (SPADE branches, learned shortcuts) on a stream of its own next to the "
+                         "cINN prefetch stream (best on ONE GPU: 3 streams); shared: on the SAME stream as the cINN prefetch, so that a job "
+                         "with a collation stream still has three side streams at most -- HIP multiplexes streams onto four hardware queues, "
+                         "and with the collation stream as the FOURTH the `own` form loses 7 % at B = 64 and 46 % at B = 8 "
+                         "(profiles/r06_c_stream_configurations.txt); auto (default): own for N = 1, shared for N > 1 / --emulate-collation")
+    ap.add_argument("--emulate-collation", action="store_true",
+                    help="N = 1 measurement: run the collation side stream with a device copy standing in for the RCCL all-gather -- the "
+                         "stream count of an N > 1 job on one GPU (what does the extra stream cost on HIP's four hardware queues?)")
     ap.add_argument("--lean", action="store_true",
                     help="timed steps, checksums, single_call and the per-layer roofline only (no sustained / exact-fp32 / cINN / probe / "
                          "embedder legs): what the default run's `config_128` child leg uses")
@@ -175,11 +180,12 @@ def main():
     x0, residual, embed = synth.bench_inputs(total, cfg["img"], cfg["emb"])
     lo, hi = i2v_dist.shard_bounds(total, world, rank)
     x0_d, res_d, emb_d = x0[lo:hi].to(dev), residual[lo:hi].to(dev), embed[lo:hi].to(dev)
-    collator = i2v_dist.OverlappedCollator(total)
+    collator = i2v_dist.OverlappedCollator(total, emulate=args.emulate_collation and world == 1)
 
     import i2v_pipeline
     prefetch = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True), device=dev, enabled=bool(args.pipeline))
-    shared = args.side_stream == "shared" and prefetch.enabled
+    side_mode = args.side_stream if args.side_stream != "auto" else ("shared" if (world > 1 or args.emulate_collation) else "own")
+    shared = side_mode == "shared" and prefetch.enabled
     if shared:
         gen.share_side_stream(prefetch.stream)
 
@@ -211,12 +217,14 @@ def main():
         for k in range(n):
             z = prefetch.get(ticket)
             if shared:
-                # one side stream, in order: the decoder's side work of step k first, the pass of step k+1 behind it (its inputs
-                # are complete at `ev`, it does not wait for the decoder's launches)
+                # ONE side stream, in order: the SPADE branches of step k (an explicit prepare), the cINN pass of step k + 1 behind
+                # them (its inputs are complete at `ev`: it does not wait for anything of step k), then the learned shortcuts the
+                # decoder of step k enqueues as it goes -- the first of which is only needed by conv_1 of g_1
                 ev = prefetch.mark()
-                decode(z)
+                gen.prepare(x0_d)
                 if k + 1 < n:
                     ticket = prefetch.submit(res_d, emb_d, _ready=ev)
+                decode(z)
                 continue
             if k + 1 < n:
                 ticket = prefetch.submit(res_d, emb_d)
@@ -455,12 +463,12 @@ def main():
             result["encoder"] = encoder_latency(cfg, x0_d)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
-        result["streams"] = {"side_stream": args.side_stream if prefetch.enabled else "none",
+        result["streams"] = {"side_stream": side_mode if prefetch.enabled else "none",
                              "what": ("main + ONE side stream: the cINN prefetch and the decoder handle's side work (SPADE branches, learned "
                                       "shortcuts) share it" if shared else "main + the cINN prefetch stream + the decoder handle's own side stream") +
                                      ("; + the collation stream and RCCL's" if world > 1 else ""),
-                             "dec_overlap_env": os.environ.get("I2V_DEC_OVERLAP"),
-                             "same_configuration_for_every_n": True}
+                             "dec_overlap_env": os.environ.get("I2V_DEC_OVERLAP"), "collation_stream_emulated": bool(args.emulate_collation and world == 1),
+                             "rule": "own for N = 1, shared for N > 1 (--side-stream auto); `small_batch` is measured in BOTH and projects from the N > 1 one"}
         if small is not None:
             result["small_batch"] = small
         if world == 1 and default_workload and not args.no_extras and not args.no_config_128:
@@ -625,55 +633,81 @@ def undisturbed_roofline(cfg, dsd, dev, x0_d, z, vid_length, ro):
 
 def small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, nb, result, pf):
     """The per-GPU share of the default job on 8 GPUs (BASELINE north_star: >= 6x at 8 GPUs for BAIR 64x64x16): the same step at
-    batch `nb` on THIS GPU -- one serial call (median of 5) and the pipelined stream rate (30 steps) -- and the strong-scaling
-    figure they PROJECT: T(64) / T(nb) before collation.  A projection from one GPU, labelled so; no multi-GPU claim."""
+    batch `nb` on THIS GPU -- one serial call (median of 5) and the pipelined stream rate (30 steps) -- in TWO stream configurations:
+    `n1` = what a one-GPU job runs (the decoder's side work on the handle's own stream), and `multi_gpu` = what every rank of an
+    N > 1 job runs (ONE shared side stream + the collation stream, here with a device copy of the rank's block standing in for the
+    RCCL all-gather).  The strong-scaling figure is PROJECTED from the second: T(64 on one GPU) / T(nb in the N > 1 configuration),
+    with an explicit all-gather term.  A projection from one GPU, labelled so; no multi-GPU claim."""
+    import i2v_dist
     x, r, e = x0_d[:nb].contiguous(), res_d[:nb].contiguous(), emb_d[:nb].contiguous()
     # (pf: the run's own LatentPrefetcher -- a second high-priority stream would be one stream too many: HIP multiplexes streams
     #  onto four hardware queues, and streams that share a queue serialise)
+    frames = nb * 16 * max(1, -(-vid_length // 16))
+    was_shared = getattr(gen, "_shared_side", None)
 
-    def one_call():
-        tk = pf.submit(r, e)
-        gen.prepare(x)
-        return gen.decode_sequence(x, pf.get(tk).view(nb, -1), vid_length)
+    def measure(shared, collator):
+        gen.share_side_stream(pf.stream if shared else None)
 
-    shared = getattr(gen, "_shared_side", None) is not None and pf.enabled
+        def one_call():
+            tk = pf.submit(r, e)
+            gen.prepare(x)
+            seq = gen.decode_sequence(x, pf.get(tk).view(nb, -1), vid_length)
+            if collator is not None:
+                collator.submit(seq)
+                collator.result()
+            return seq
 
-    def stream(n):
-        tk = pf.submit(r, e)
-        for k in range(n):
-            z = pf.get(tk)
-            if shared:   # (one side stream: decoder of step k first, the pass of step k+1 behind it -- as run_steps does)
-                ev = pf.mark()
-                gen.decode_sequence(x, z.view(nb, -1), vid_length)
-                if k + 1 < n:
-                    tk = pf.submit(r, e, _ready=ev)
-                continue
-            if k + 1 < n:
-                tk = pf.submit(r, e)
-            gen.decode_sequence(x, z.view(nb, -1), vid_length)
+        def stream(n):
+            tk = pf.submit(r, e)
+            for k in range(n):
+                z = pf.get(tk)
+                if shared:   # (one side stream: branches of step k, the pass of step k + 1, then step k's shortcuts -- as run_steps does)
+                    ev = pf.mark()
+                    gen.prepare(x)
+                    if k + 1 < n:
+                        tk = pf.submit(r, e, _ready=ev)
+                else:
+                    if k + 1 < n:
+                        tk = pf.submit(r, e)
+                seq = gen.decode_sequence(x, z.view(nb, -1), vid_length)
+                if collator is not None:
+                    collator.submit(seq)
+            if collator is not None:
+                collator.result()
 
-    for _ in range(2):
-        one_call()
-    ts = []
-    for _ in range(5):
+        for _ in range(2):
+            one_call()
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            one_call()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
+        single = float(np.median(ts))
+        stream(3)
         torch.cuda.synchronize()
         t = time.perf_counter()
-        one_call()
+        stream(30)
         torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t) * 1e3)
-    single = float(np.median(ts))
-    stream(3)
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    stream(30)
-    torch.cuda.synchronize()
-    piped = (time.perf_counter() - t) / 30 * 1e3
+        piped = (time.perf_counter() - t) / 30 * 1e3
+        return {"single_call_ms": single, "single_call_frames_per_s": frames / (single * 1e-3),
+                "pipelined_ms_per_step": piped, "pipelined_frames_per_s": frames / (piped * 1e-3)}
+
+    try:
+        n1 = measure(False, None)
+        multi = measure(True, i2v_dist.OverlappedCollator(nb, emulate=True))
+    finally:
+        gen.share_side_stream(was_shared)
     big_single = (result.get("single_call") or {}).get("ms")
-    frames = nb * 16 * max(1, -(-vid_length // 16))
-    return {"what": f"the same step at batch {nb} = the per-GPU share of the B = 64 job on {64 // nb} GPUs, measured on this one GPU",
-            "batch": nb, "single_call_ms": single, "single_call_frames_per_s": frames / (single * 1e-3),
-            "pipelined_ms_per_step": piped, "pipelined_frames_per_s": frames / (piped * 1e-3),
-            "projected_strong_scaling": projected_scaling(64 // nb, nb, frames // nb, big_single, single, result["ms_per_step"], piped)}
+    out = {"what": f"the same step at batch {nb} = the per-GPU share of the B = 64 job on {64 // nb} GPUs, measured on this one GPU in the "
+                   "stream configuration of a one-GPU job (`n1`) and in the one every rank of an N > 1 job runs (`multi_gpu`: one shared side "
+                   "stream + the collation stream, the all-gather replaced by a device copy of the block)",
+           "batch": nb, "n1": n1, "multi_gpu": multi,
+           "projected_strong_scaling": projected_scaling(64 // nb, nb, frames // nb, big_single, multi["single_call_ms"], result["ms_per_step"],
+                                                         multi["pipelined_ms_per_step"])}
+    out.update({k: multi[k] for k in multi})   # (top-level figures = the N > 1 configuration, the one the projection uses)
+    return out
 
 
 XGMI_LINK_GBS = 153.0   # MI355X_MICROARCH.md: one xGMI link, per direction (7 links per GPU, point to point)
@@ -693,8 +727,8 @@ def projected_scaling(n, nb, frames_per_sample, big_single_ms, single_ms, big_pi
             "all_gather_ms_model": ag_ms, "all_gather_bytes_per_rank": block,
             "all_gather_model": f"ring: (N - 1) x one rank's block over one {XGMI_LINK_GBS:.0f} GB/s xGMI link + 20 us launch; exposed in a "
                                 "single call, overlapped with the next step in the pipelined stream (where it has to stay under the step time)",
-            "note": "PROJECTION from one-GPU runs: T(B = 64) / T(B = %d) measured in the same stream configuration the N > 1 job runs; "
-                    "not a multi-GPU measurement" % nb}
+            "note": "PROJECTION from one-GPU runs: T(B = 64, one-GPU job) / T(B = %d, measured in the stream configuration every rank of the "
+                    "N > 1 job runs); not a multi-GPU measurement" % nb}
 
 
 def config_128_leg(args):

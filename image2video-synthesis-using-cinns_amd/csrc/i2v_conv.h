@@ -147,6 +147,16 @@ bool wino4_supported(int cout, int cin, int T, int H, int W, int KT);
 int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const float* res, int rt, int rs, int B, int T,
                   int H, int W, int epi, hipStream_t st, double* stats = nullptr);
 
+// The same conv with the operand GENERATED in the kernel (conv_wino4g_f16x3_kernel: 8 MFMA waves + 4 producer waves per workgroup):
+// x = the conv's fp32 input BEFORE normalisation / activation, channels-last [B][T][H / us][W / us][Cin]; coef = per-(b,c) (A, B)
+// pairs; gb = SPADE's gamma' | beta maps [B][H][W][2 Cin] (with us = 2) or null (ADAIN, us = 1); the operand is lrelu((x A + B) gamma'
+// + beta) read through the nearest up-sampling map -- what modulate_wino4_kernel would have written, bit for bit.  32 output channels,
+// 3x3x3, no temporal up-sampling in front (g_4 of the 128 x 128 configs).
+bool wino4g_supported(int cout, int cin, int T, int H, int W, int us);
+int wino4g_forward(const Wino4Weights& wts, const float* x, const float* coef, const float* gb, int us, float* out, const float* res, int rt,
+                   int rs, int B, int T, int H, int W, int epi, hipStream_t st, double* stats = nullptr, int* range_flag = nullptr,
+                   int* umax = nullptr);
+
 // ---- helpers implemented in i2v_dec.hip, shared with the embedder (i2v_embed.hip)
 // per-(b,c) sum / sum of squares (fp64) of a channels-last tensor [B][P][C]
 int stats_forward(const float* x, double* sums, int B, long P, int C, hipStream_t st);

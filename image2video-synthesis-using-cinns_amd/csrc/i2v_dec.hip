@@ -132,7 +132,9 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 // (before the Winograd transform) into its own slot (float bits, atomicMax); status_finish_kernel turns "non-zero tensor whose
 // maximum is below I2V_UNDERFLOW_MAX" into status bit 1 (value 2) at the end of the forward.
 constexpr float I2V_UNDERFLOW_MAX = 0x1p-10f;
-constexpr int I2V_STATUS_WORDS = 64;   // [0] flag word, [1 ..] per-writer maxima
+constexpr float I2V_OVERFLOW_MAX = 6400.f;   // |V| <= 10 max|d| (F(4,3): 4 + 5 + 1): below this no transformed value can leave the fp16 range
+constexpr int I2V_STATUS_WORDS = 64;   // [0] flag word, [1 .. 31] per-writer maxima of the running forward, [32 + i] the last forward's (snapshot)
+constexpr int I2V_STATUS_SNAP = 32;
 
 __device__ __forceinline__ void publish_umax(int* slot, float m) {
     if (!slot) return;
@@ -146,9 +148,10 @@ __device__ __forceinline__ void publish_umax(int* slot, float m) {
 
 __global__ void status_finish_kernel(int* __restrict__ status) {
     int f = 0;
-    for (int i = 1; i < I2V_STATUS_WORDS; ++i) {
+    for (int i = 1; i < I2V_STATUS_SNAP; ++i) {
         const int v = status[i];
         if (v != 0 && __int_as_float(v) < I2V_UNDERFLOW_MAX) f = 2;
+        status[I2V_STATUS_SNAP + i] = v;   // kept for the host (mma = auto decides per layer from these)
         status[i] = 0;
     }
     if (f) atomicOr(status, f);
@@ -686,6 +689,19 @@ struct i2v_dec {
     hipEvent_t ev_x[6] = {}, ev_s[6] = {};
     // One handle = one workspace, one set of side-stream events: forwards / prepares on a handle are serialised.  A call that arrives
     // on another stream than the previous one first waits for the previous call (event recorded behind every call), like i2v_flow.
+    // Matrix-core mode (i2v_dec_cfg.mma): 0 exact fp32, 1 split-fp16, 2 AUTO = split-fp16 with a per-layer fallback behind the range
+    // guard: both weight sets are packed; every forward ends with a stream synchronisation and a look at the operand maxima the
+    // writers published -- a 3x3x3 conv whose operand tensor left the window the split format holds 1e-4 in (max |activation| below
+    // 2^-10 or above 6400) is switched to the exact-fp32 kernels (Winograd F(4,3) on the fp32 matrix cores where the shape allows,
+    // i2v_wino32.hip) for the rest of the handle's life and the forward is run again; an overflow no slot explains (SPADE's own
+    // activation, the shortcut GEMM, conv_img) switches the whole handle.  In-range checkpoints run exactly the mma = 1 launches.
+    bool fp32_layer[12] = {};   // layer = 2 * block + (0: conv_0, 1: conv_1)
+    bool fp32_all = false;
+    int auto_reruns = 0;        // forwards that had to be run again (reporting)
+    bool has16() const { return cfg.mma != 0; }                       // split-fp16 weights are packed
+    bool has32() const { return cfg.mma != 1; }                       // exact-fp32 weights are packed
+    bool aux16() const { return has16() && !fp32_all; }               // SPADE branch, shortcut GEMM, conv_img, resize on the split-fp16 path
+    bool layer16(int layer) const { return aux16() && !fp32_layer[layer]; }
     StreamOrder order;   // (capture-aware: i2v_common.h)
     // A forked prepare (or an in-call fork that failed half-way) leaves work on the side stream that nothing on a caller's stream has
     // waited for yet: `side_unjoined`.  Whoever DROPS such a prepare (i2v_dec_prepare_cancel followed by a forward, a forward with other
@@ -751,10 +767,10 @@ bool want_wf_1(const i2v_dec* d, const Block& b, const Level& l);
 // SPADE's gamma|beta Conv2d(128, 2C, 3) on a Winograd kernel (F(4,3) 1x3x3 variant, else F(2,3)): the predicate of
 // i2v_dec_load's packing and of the y1v workspace
 bool spade_w4_wanted(const i2v_dec* d, const Block& b, const Level& l) {
-    return d->cfg.mma == 1 && d->wino && d->spw && d->wino4 && (2 * b.n_in) % 64 == 0 && wino4_supported(2 * b.n_in, 128, 1, l.H, l.W, 1);
+    return d->has16() && d->wino && d->spw && d->wino4 && (2 * b.n_in) % 64 == 0 && wino4_supported(2 * b.n_in, 128, 1, l.H, l.W, 1);
 }
 bool spade_wino_wanted(const i2v_dec* d, const Block& b, const Level& l) {
-    return spade_w4_wanted(d, b, l) || (d->cfg.mma == 1 && d->wino && d->spw && wino16_supported(2 * b.n_in, 128, 1, l.H, l.W, 1));
+    return spade_w4_wanted(d, b, l) || (d->has16() && d->wino && d->spw && wino16_supported(2 * b.n_in, 128, 1, l.H, l.W, 1));
 }
 
 DecWs dec_ws(const i2v_dec* d, int B) {
@@ -778,7 +794,7 @@ DecWs dec_ws(const i2v_dec* d, int B) {
         mx_gb = std::max(mx_gb, (size_t)l.H * l.W * 2 * b.n_in);
         cmax = std::max(cmax, std::max(b.n_in, b.n_mid));
     }
-    if (d->cfg.mma == 1 && d->img16 == 1 && d->nf >= 64) mx_a = std::max(mx_a, (size_t)d->lvl[5].T * d->lvl[5].H * d->lvl[5].W * 81);  // conv_img's Y
+    if (d->has16() && d->img16 == 1 && d->nf >= 64) mx_a = std::max(mx_a, (size_t)d->lvl[5].T * d->lvl[5].H * d->lvl[5].W * 81);  // conv_img's Y
     DecWs L;
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o = align_up(o + floats * 4, 256); return r; };
@@ -946,10 +962,10 @@ int conv3_w4(i2v_dec* d, const Wino4Weights& w, const float* v_hl16, float* out,
 // which kernel conv_0 / conv_1 of a block use at this geometry (want_*: by shape; use_*: and the weights are packed for it)
 bool want_wino0(const i2v_dec* d, const Block& b, const Level& l) {
     const bool tdup = l.ut == 2;   // conv_0 behind a x2 temporal up-sampling: pair kernels on the half-rate tensor (Block::tdup0)
-    return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_mid, b.n_in, tdup ? l.T / 2 : l.T, l.H, l.W, tdup ? 2 : 3);
+    return d->has16() && d->wino && wino16_supported(b.n_mid, b.n_in, tdup ? l.T / 2 : l.T, l.H, l.W, tdup ? 2 : 3);
 }
 bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
-    return d->cfg.mma == 1 && d->wino && wino16_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
+    return d->has16() && d->wino && wino16_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
 }
 // F(4,3): its bricks hold 512 output positions x 64 or 32 channels (the launcher picks 32-channel workgroups when 64-channel ones
 // would not fill the chip; both give the same bits) -- wherever one SAMPLE gives >= 16 workgroups of 32 channels, i.e. from the
@@ -960,14 +976,14 @@ bool want_wino1(const i2v_dec* d, const Block& b, const Level& l) {
 bool w4_fills(const Level& l, int cout) { return (long)l.T * l.H * l.W / 512 * std::max(cout / 32, 1) >= 16; }
 bool want_w4_0(const i2v_dec* d, const Block& b, const Level& l) {
     const bool tdup = l.ut == 2;
-    return d->cfg.mma == 1 && d->wino && d->wino4 && (d->wino4 == 2 || w4_fills(l, b.n_mid)) &&
+    return d->has16() && d->wino && d->wino4 && (d->wino4 == 2 || w4_fills(l, b.n_mid)) &&
            wino4_supported(b.n_mid, b.n_in, tdup ? l.T / 2 : l.T, l.H, l.W, tdup ? 2 : 3);
 }
 bool want_w4_1(const i2v_dec* d, const Block& b, const Level& l) {
-    return d->cfg.mma == 1 && d->wino && d->wino4 && (d->wino4 == 2 || w4_fills(l, b.n_out)) && wino4_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
+    return d->has16() && d->wino && d->wino4 && (d->wino4 == 2 || w4_fills(l, b.n_out)) && wino4_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 3);
 }
-bool want_wf_0(const i2v_dec* d, const Block& b, const Level& l) { return d->cfg.mma == 0 && d->wino32 && wino4f32_supported(b.n_mid, b.n_in, l.T, l.H, l.W); }
-bool want_wf_1(const i2v_dec* d, const Block& b, const Level& l) { return d->cfg.mma == 0 && d->wino32 && wino4f32_supported(b.n_out, b.n_mid, l.T, l.H, l.W); }
+bool want_wf_0(const i2v_dec* d, const Block& b, const Level& l) { return d->has32() && d->wino32 && wino4f32_supported(b.n_mid, b.n_in, l.T, l.H, l.W); }
+bool want_wf_1(const i2v_dec* d, const Block& b, const Level& l) { return d->has32() && d->wino32 && wino4f32_supported(b.n_out, b.n_mid, l.T, l.H, l.W); }
 bool use_wf_0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_wf.u[0].w.p && want_wf_0(d, b, l); }
 bool use_wf_1(const i2v_dec* d, const Block& b, const Level& l) { return b.conv1_wf.u[0].w.p && want_wf_1(d, b, l); }
 bool use_w4_0(const i2v_dec* d, const Block& b, const Level& l) { return b.conv0_w4.w.p && want_w4_0(d, b, l); }
@@ -1017,20 +1033,20 @@ int spade_branch(i2v_dec* d, Block& b, const Level& l, const float* img, int img
     {
         const long tot = (long)B * l.H * l.W;
         hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65536)), dim3(256), 0, st, img, y0,
-                           B, img_h, img_w, l.H, l.W, d->cfg.mma == 1 ? 1 : 0, d->status_dev, d->img_bstride ? d->img_bstride : (long)3 * img_h * img_w);
+                           B, img_h, img_w, l.H, l.W, d->aux16() ? 1 : 0, d->status_dev, d->img_bstride ? d->img_bstride : (long)3 * img_h * img_w);
         I2V_HIP_CHECK(hipGetLastError());
     }
-    if (d->cfg.mma == 1 && b.sp_gb_w4.w.p && w.y1v) {
+    if (d->aux16() && b.sp_gb_w4.w.p && w.y1v) {
         if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
         if ((rc = run_modulate_wino4(y1, nullptr, nullptr, w.y1v, B, 1, l.H, l.W, 128, 1, 1, 0, st, d->status_dev))) return rc;
         if ((rc = wino4_forward(b.sp_gb_w4, w.y1v, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st, nullptr))) return rc;
-    } else if (d->cfg.mma == 1 && b.sp_gb_w.w.p && w.y1v) {
+    } else if (d->aux16() && b.sp_gb_w.w.p && w.y1v) {
         // gamma | beta conv on the Winograd kernel: the 128-channel activation goes through fp32 once more (the operand
         // writer needs the w-neighbours of every position, which the producing conv's epilogue does not hold)
         if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU, st))) return rc;
         if ((rc = run_modulate_wino(y1, nullptr, nullptr, w.y1v, B, 1, l.H, l.W, 128, 1, 1, 0, st, d->status_dev))) return rc;
         if ((rc = wino16_forward(b.sp_gb_w, w.y1v, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st, nullptr))) return rc;
-    } else if (d->cfg.mma == 1) {
+    } else if (d->aux16()) {
         if ((rc = conv16_forward(b.sp_conv16, y0, y1, nullptr, 1, 1, B, 1, l.H, l.W, EPI_LRELU | EPI_HL16, st, nullptr, d->status_dev)))
             return rc;
         if ((rc = conv16_forward(b.sp_gb16, y1, gb, nullptr, 1, 1, B, 1, l.H, l.W, EPI_NONE, st))) return rc;
@@ -1068,7 +1084,7 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
         I2V_HIP_CHECK(hipStreamWaitEvent(w.side, d->ev_x[k], 0));
         int rs_ = run_coef(sums1, w.coef_s, B, b.n_in, 16, (double)Pl, nullptr, 0, 0, b.gn_w.as<float>(), b.gn_b.as<float>(), w.side);
         if (!rs_) {
-            if (b.convs16.w.p) rs_ = pointwise16_forward(b.convs16, x, xs_low, nullptr, (long)B * Pl, Pl, EPI_NONE, w.side, w.coef_s, d->status_dev);
+            if (d->aux16() && b.convs16.w.p) rs_ = pointwise16_forward(b.convs16, x, xs_low, nullptr, (long)B * Pl, Pl, EPI_NONE, w.side, w.coef_s, d->status_dev);
             else rs_ = conv_forward(b.convs, x, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, w.side, w.coef_s);
         }
         if (!rs_ && hipEventRecord(d->ev_s[k], w.side) != hipSuccess) rs_ = I2V_E_HIP;
@@ -1079,29 +1095,30 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     if (w.gb_ready) gb = const_cast<float*>(w.gb_ready);
     else if ((rc = spade_branch(d, b, l, img, img_h, img_w, B, y0, y1, w.y1v, gb, st))) return rc;
     if ((rc = tap(k, 0, gb, (size_t)B * l.H * l.W * 2 * b.n_in))) return rc;
-    const bool f16 = d->cfg.mma == 1;
-    const bool tdup = f16 && b.tdup0;  // a0 is kept at the half temporal rate (its frames 2i and 2i+1 coincide)
-    const bool q0 = use_w4_0(d, b, l), q1 = use_w4_1(d, b, l);          // F(4,3)
-    const bool w0 = !q0 && use_wino0(d, b, l), w1 = !q1 && use_wino1(d, b, l);   // F(2,3)
+    // per conv: split-fp16 or exact fp32 (mma = 0: all fp32; mma = auto: the layers the range guard switched, i2v_dec::fp32_layer)
+    const bool f16_0 = d->layer16((2 * k) % 12), f16_1 = d->layer16((2 * k + 1) % 12);
+    const bool tdup = f16_0 && b.tdup0;  // a0 is kept at the half temporal rate (its frames 2i and 2i+1 coincide)
+    const bool q0 = f16_0 && use_w4_0(d, b, l), q1 = f16_1 && use_w4_1(d, b, l);          // F(4,3)
+    const bool w0 = f16_0 && !q0 && use_wino0(d, b, l), w1 = f16_1 && !q1 && use_wino1(d, b, l);   // F(2,3)
     int* flag = d->status_dev;
-    // underflow guard: the two operand tensors of this block publish their maxima in slots 1 + 2k / 2 + 2k
-    int* um0 = f16 && flag ? flag + 1 + 2 * (k % 24) : nullptr;
-    int* um1 = um0 ? um0 + 1 : nullptr;
-    const bool f0 = w.m6 && use_wf_0(d, b, l), f1 = w.m6 && use_wf_1(d, b, l);   // exact-fp32 mode: Winograd F(4,3) on the fp32 matrix cores
+    // range guard: the two operand tensors of this block publish their maxima in slots 1 + 2k / 2 + 2k
+    int* um0 = f16_0 && flag ? flag + 1 + 2 * (k % 12) : nullptr;
+    int* um1 = f16_1 && flag ? flag + 2 + 2 * (k % 12) : nullptr;
+    const bool f0 = !f16_0 && w.m6 && use_wf_0(d, b, l), f1 = !f16_1 && w.m6 && use_wf_1(d, b, l);   // exact fp32: Winograd F(4,3) on the fp32 matrix cores
     if (f0) rc = modulate_wino4_f32(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st);
     else if (q0) rc = run_modulate_wino4(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
     else if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
     else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true, flag, um0);
-    else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16, flag, um0);
+    else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16_0, flag, um0);
     if (rc) return rc;
     if (!f0 && (rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
-    const bool fuse = f16 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
+    const bool fuse = f16_0 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
     d->prof_cur_layer = 2 * k;
-    d->prof_cur_kernel = q0 ? 3 : w0 ? 2 : (f16 ? 1 : 0);
+    d->prof_cur_kernel = q0 ? 3 : w0 ? 2 : (f16_0 ? 1 : 0);
     if (f0) rc = conv3_wf(d, b.conv0_wf, a, w.m6, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
     else if (q0) rc = conv3_w4(d, b.conv0_w4, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else if (w0) rc = conv3_w(d, b.conv0_w, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
-    else if (f16) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr, w.splitk, w.splitk_floats);
+    else if (f16_0) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr, w.splitk, w.splitk_floats);
     else rc = conv3(d, b.conv0, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
     if (rc) return rc;
     if ((rc = tap(k, 2, dx, (size_t)B * P * b.n_mid))) return rc;
@@ -1111,7 +1128,7 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     if (f1) rc = modulate_wino4_f32(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st);
     else if (q1) rc = run_modulate_wino4(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
     else if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
-    else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16, flag, um1);
+    else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16_1, flag, um1);
     if (rc) return rc;
     if (!f1 && (rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
     // shortcut (decoder.py:44-49) at low resolution
@@ -1121,7 +1138,7 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
             return rc;
         // Norm3D folded into the 1x1x1 conv's loads (no padding taps -> exact): no normalised copy of x is written
         (void)xs_in;
-        if (b.convs16.w.p) rc = pointwise16_forward(b.convs16, x, xs_low, nullptr, (long)B * Pl, Pl, EPI_NONE, st, coef, d->status_dev);
+        if (d->aux16() && b.convs16.w.p) rc = pointwise16_forward(b.convs16, x, xs_low, nullptr, (long)B * Pl, Pl, EPI_NONE, st, coef, d->status_dev);
         else rc = conv_forward(b.convs, x, b.n_in, xs_low, nullptr, 1, 1, B, Tl, Hl, Wl, EPI_NONE, st, coef);
         if (rc) return rc;
         res = xs_low;
@@ -1133,13 +1150,13 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // g_4's output only feeds conv_img(leaky_relu(x)) (decoder.py:117): fuse the activation here
     // (the shortcut's coefficients were derived from sums1 above, so conv_1 may now overwrite sums1 with the
     // statistics of the block OUTPUT = the next block's input)
-    const bool fuse_out = f16 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
+    const bool fuse_out = f16_1 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
     d->prof_cur_layer = 2 * k + 1;
-    d->prof_cur_kernel = q1 ? 3 : w1 ? 2 : (f16 ? 1 : 0);
+    d->prof_cur_kernel = q1 ? 3 : w1 ? 2 : (f16_1 ? 1 : 0);
     if (f1) rc = conv3_wf(d, b.conv1_wf, a, w.m6, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
     else if (q1) rc = conv3_w4(d, b.conv1_w4, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
     else if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
-    else if (f16) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr,
+    else if (f16_1) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr,
                                 w.splitk, w.splitk_floats);
     else rc = conv3(d, b.conv1, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
     if (rc) return rc;
@@ -1212,8 +1229,8 @@ int init_status(i2v_dec* d) {
     { const char* zp = nullptr; if (int rcz = zero_page(&zp)) return rcz; }  // the conv kernels' zero page: allocated here, not inside a forward
     I2V_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->status_dev), I2V_STATUS_WORDS * sizeof(int)));   // [0] flags, [1..] underflow maxima
     I2V_HIP_CHECK(hipMemset(d->status_dev, 0, I2V_STATUS_WORDS * sizeof(int)));
-    I2V_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->status_host), sizeof(int), hipHostMallocDefault));
-    *d->status_host = 0;
+    I2V_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->status_host), I2V_STATUS_WORDS * sizeof(int), hipHostMallocDefault));   // [0] flags, [32 + i] the last forward's maxima
+    std::memset(d->status_host, 0, I2V_STATUS_WORDS * sizeof(int));
     return I2V_OK;
 }
 
@@ -1262,7 +1279,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
         I2V_REQUIRE((s == 1 || s == 2 || s == 4) && (t == 1 || t == 2 || t == 4), I2V_E_INVALID,
                     "i2v_dec_create: upsample factors must be 1, 2 or 4");
     }
-    I2V_REQUIRE(cfg->mma == 0 || cfg->mma == 1, I2V_E_INVALID, "i2v_dec_create: unknown mma mode %d", cfg->mma);
+    I2V_REQUIRE(cfg->mma == 0 || cfg->mma == 1 || cfg->mma == 2, I2V_E_INVALID, "i2v_dec_create: unknown mma mode %d (0 fp32, 1 split-fp16, 2 auto)", cfg->mma);
     int ndev = 0;
     I2V_HIP_CHECK(hipGetDeviceCount(&ndev));
     I2V_REQUIRE(ndev > 0, I2V_E_HIP, "i2v_dec_create: no HIP device");
@@ -1329,7 +1346,7 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
     for (int k = 0; k < 6; ++k) {
         Block& b = d->blk[k];
         const std::string p = b.name + ".";
-        if (d->cfg.mma == 1) {
+        if (d->has16()) {
             // behind a x2 up-sampling in time, SPADE's output is identical for frames 2i and 2i+1 (gamma/beta do not depend
             // on t): conv_0 runs on the half-rate tensor with two pre-summed 2-tap temporal kernels (-1/3 of its MACs)
             b.tdup0 = d->lvl[k].ut == 2;
@@ -1343,7 +1360,8 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
             else if (want_wino1(d, b, d->lvl[k])) rc = sn_pack_wino(sd, p + "conv_1", sn, b.n_out, b.n_mid, false, b.conv1_w);
             else rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1_16);
             if (rc) return rc;
-        } else {
+        }
+        if (d->has32()) {   // (mma = auto packs both sets)
             if ((rc = sn_pack(sd, p + "conv_0", sn, b.n_mid, b.n_in, 3, true, b.conv0))) return rc;
             if ((rc = sn_pack(sd, p + "conv_1", sn, b.n_out, b.n_mid, 3, true, b.conv1))) return rc;
             // from the 8x8 level on: Winograd F(4,3) on the fp32 matrix cores (half the MFMA work of the 27-tap kernel)
@@ -1352,7 +1370,7 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         }
         if (b.learned) {
             if ((rc = sn_pack(sd, p + "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs))) return rc;
-            if (d->cfg.mma == 1 && d->pw16 && (rc = sn_pack(sd, p + "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs16))) return rc;
+            if (d->has16() && d->pw16 && (rc = sn_pack(sd, p + "conv_s", sn, b.n_out, b.n_in, 1, false, b.convs16))) return rc;
             const float* gw = sd.f32(p + "norm_s.bn.weight", b.n_in);
             const float* gb = sd.f32(p + "norm_s.bn.bias", b.n_in);
             if (!gw || !gb) return I2V_E_MISSING;
@@ -1379,9 +1397,8 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         std::memcpy(wgb.data(), wg, (size_t)b.n_in * 128 * 9 * 4);
         std::memcpy(wgb.data() + (size_t)b.n_in * 128 * 9, wb, (size_t)b.n_in * 128 * 9 * 4);
         for (int c = 0; c < b.n_in; ++c) { bgb[c] = bg[c] + 1.0f; bgb[b.n_in + c] = bb[c]; }  // normalized*(1+gamma)+beta
-        if (d->cfg.mma == 1) rc = b.sp_gb16.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
-        else rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0);
-        if (rc) return rc;
+        if (d->has16() && (rc = b.sp_gb16.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0))) return rc;
+        if (d->has32() && (rc = b.sp_gb.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 3, 3, 1.0))) return rc;
         if (spade_w4_wanted(d, b, d->lvl[k])) {
             if ((rc = b.sp_gb_w4.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1.0, 1))) return rc;
         } else if (spade_wino_wanted(d, b, d->lvl[k]) && (rc = b.sp_gb_w.pack(wgb.data(), bgb.data(), 2 * b.n_in, 128, 1, 1.0)))
@@ -1402,9 +1419,9 @@ int i2v_dec_load(i2v_dec* d, const i2v_tensor* tensors, int32_t n_tensors) {
         if ((rc = d->conv_img_v.pack(w, b, nf))) return rc;
         // (measured: 1.3 vs 1.7 ms per B = 64 BAIR pass at nf = 64, but 0.8 ms SLOWER than the vector-ALU kernel per B = 32
         //  128x128 pass at nf = 32, where the 81 planes outweigh the 32-channel input)
-        if (d->cfg.mma == 1 && d->img16 == 2 && conv_img_mfma_supported(d->lvl[5].T, d->lvl[5].H, d->lvl[5].W, nf) &&
+        if (d->has16() && d->img16 == 2 && conv_img_mfma_supported(d->lvl[5].T, d->lvl[5].H, d->lvl[5].W, nf) &&
             (rc = d->conv_img_m.pack(w, b, nf))) return rc;
-        if (d->cfg.mma == 1 && d->img16 == 1 && nf >= 64 && nf % 4 == 0) {
+        if (d->has16() && d->img16 == 1 && nf >= 64 && nf % 4 == 0) {
             std::vector<float> w81((size_t)81 * nf);   // row tap * 3 + n = w[n][:][tap]
             for (int n = 0; n < 3; ++n)
                 for (int c = 0; c < nf; ++c)
@@ -1543,7 +1560,9 @@ int i2v_dec_forward(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, 
     return i2v_dec_forward_strided(d, img, img_h, img_w, 0, motion, out, 0, workspace, workspace_bytes, batch, stream);
 }
 
-int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, int64_t img_bstride, const float* motion, float* out,
+}  // extern "C"
+
+static int dec_forward_once(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, int64_t img_bstride, const float* motion, float* out,
                             int64_t out_bstride, void* workspace, size_t workspace_bytes, int32_t batch, void* stream) {
     // One prepare serves at most the NEXT forward on the handle: whatever happens below (range error of the previous call, bad
     // argument, workspace too small), a prepared set of SPADE maps must never survive into a later call, whose start frames can
@@ -1628,7 +1647,7 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
             BlockBufs bufs{a, dx, xs_in, xs_low, y0, y1, gb, coef, s_in + (size_t)s0 * b.n_in * 2, sums2, s_out + (size_t)s0 * b.n_out * 2,
                            F(L.splitk), L.splitk_floats, L.has_y1v ? F(L.y1v) : nullptr,
                            prepared ? F(L.gbs[k]) + (size_t)s0 * l.H * l.W * 2 * b.n_in : nullptr,
-                           d->cfg.mma == 0 && d->wino32 ? F(L.m6) : nullptr,
+                           d->has32() && d->wino32 ? F(L.m6) : nullptr,
                            forked && nsub == B && d->overlap >= 1 && !d->no_side_shortcut ? d->side : nullptr, F(L.coef_s)};
             bool ready = x_stats_ready;
             if ((rc = block_forward(d, k, d->blk[k], l, x + (size_t)s0 * Pl * b.n_in, xn + (size_t)s0 * P * b.n_out,
@@ -1642,8 +1661,8 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
     join.on = false;   // every level's maps and every shortcut have been waited for by their consumers
     {
         const Level& l = d->lvl[5];
-        if (d->conv_img_m.w.p) rc = conv_img_mfma_forward(d->conv_img_m, x, out, B, l.T, l.H, l.W, st, d->status_dev, out_bstride);
-        else if (d->conv_img16.w.p) {
+        if (d->aux16() && d->conv_img_m.w.p) rc = conv_img_mfma_forward(d->conv_img_m, x, out, B, l.T, l.H, l.W, st, d->status_dev, out_bstride);
+        else if (d->aux16() && d->conv_img16.w.p) {
             const long P = (long)l.T * l.H * l.W, tot = (long)B * P;
             I2V_REQUIRE((tot + 255) / 256 < (1L << 31), I2V_E_INVALID, "conv_img: %ld positions", tot);
             if ((rc = pointwise16_forward(d->conv_img16, x, a, nullptr, tot, P, EPI_NONE, st, nullptr, d->status_dev, true))) return rc;
@@ -1654,11 +1673,61 @@ int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t
         else rc = conv_forward(d->conv_img, x, d->nf, out, nullptr, 1, 1, B, l.T, l.H, l.W, EPI_FRAMES, st, nullptr, 1, 1, out_bstride);
         if (rc) return rc;
     }
-    if (d->cfg.mma == 1) {
+    if (d->has16()) {
         hipLaunchKernelGGL(status_finish_kernel, dim3(1), dim3(1), 0, st, d->status_dev);
         I2V_HIP_CHECK(hipGetLastError());
-        I2V_HIP_CHECK(hipMemcpyAsync(d->status_host, d->status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        I2V_HIP_CHECK(hipMemcpyAsync(d->status_host, d->status_dev, I2V_STATUS_WORDS * sizeof(int), hipMemcpyDeviceToHost, st));
     }
+    return I2V_OK;
+}
+
+// mma = auto: after a forward has been synchronised, turn what the range guard saw into per-layer decisions.  Returns true when a
+// layer (or the whole handle) was switched to the exact-fp32 kernels, i.e. the forward has to be run again.
+static bool auto_decide(i2v_dec* d) {
+    const int* h = d->status_host;
+    bool changed = false;
+    for (int layer = 0; layer < 12; ++layer) {
+        const int bits = h[I2V_STATUS_SNAP + 1 + layer];
+        if (!bits || d->fp32_layer[layer]) continue;
+        float m;
+        std::memcpy(&m, &bits, 4);
+        if (!(m >= I2V_UNDERFLOW_MAX && m <= I2V_OVERFLOW_MAX)) { d->fp32_layer[layer] = true; changed = true; }
+    }
+    if ((h[0] & 1) && !changed && !d->fp32_all) { d->fp32_all = true; changed = true; }   // an overflow no operand slot explains
+    return changed;
+}
+
+extern "C" {
+
+int i2v_dec_forward_strided(i2v_dec* d, const float* img, int32_t img_h, int32_t img_w, int64_t img_bstride, const float* motion, float* out,
+                            int64_t out_bstride, void* workspace, size_t workspace_bytes, int32_t batch, void* stream) {
+    int rc = dec_forward_once(d, img, img_h, img_w, img_bstride, motion, out, out_bstride, workspace, workspace_bytes, batch, stream);
+    if (rc || !d || d->cfg.mma != 2) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stream_is_capturing(st)) return rc;   // (a captured forward runs the layer choices made so far; it cannot look at its own flags)
+    for (int round = 0; round < 14; ++round) {
+        I2V_HIP_CHECK(hipStreamSynchronize(st));
+        if (!auto_decide(d)) {
+            // what is left in the flag word has been handled (bit 1 -- underflow -- by the per-layer switch; bit 0 cannot remain)
+            if (*d->status_host & 2) { I2V_HIP_CHECK(hipMemsetAsync(d->status_dev, 0, sizeof(int), st)); *d->status_host &= ~2; }
+            return I2V_OK;
+        }
+        I2V_HIP_CHECK(hipMemsetAsync(d->status_dev, 0, sizeof(int), st));
+        *d->status_host = 0;
+        d->auto_reruns += 1;
+        if ((rc = dec_forward_once(d, img, img_h, img_w, img_bstride, motion, out, out_bstride, workspace, workspace_bytes, batch, stream))) return rc;
+    }
+    I2V_REQUIRE(false, I2V_E_RANGE, "i2v_dec_forward (mma = auto): the range guard still fires with every layer on the exact-fp32 kernels");
+}
+
+int i2v_dec_fallback_layers(i2v_dec* d, int32_t* mask, int32_t* reruns) {
+    I2V_REQUIRE(d && mask, I2V_E_INVALID, "i2v_dec_fallback_layers: null argument");
+    int m = 0;
+    for (int layer = 0; layer < 12; ++layer)
+        if (d->fp32_layer[layer] || d->fp32_all) m |= 1 << layer;
+    if (d->fp32_all) m |= 1 << 30;
+    *mask = m;
+    if (reruns) *reruns = d->auto_reruns;
     return I2V_OK;
 }
 

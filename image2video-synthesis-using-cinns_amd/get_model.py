@@ -24,7 +24,14 @@ class Model(torch.nn.Module):
         path_stage1 = opt.First_stage_model["model_path"] + opt.First_stage_model["model_name"] + "/"
         config = i2v_config.load(path_stage1 + "config_stage1.yaml")
 
-        self.decoder = decoder.Generator(config.Decoder).cuda()
+        # Matrix-core mode: the checkpoint's activations are unknown until they have been seen, so the drop-in entry point runs the
+        # decoder in AUTO mode (split-fp16 with the per-layer fallback to the exact-fp32 kernels behind the range guard: a checkpoint
+        # inside the split format's window runs exactly the default launches, one outside it still returns valid frames -- check()
+        # says which layers were switched) unless the YAML's Decoder section or I2V_DEC_MMA pick a mode.
+        dec_cfg = dict(config.Decoder)
+        if "mma" not in dec_cfg and "I2V_DEC_MMA" not in os.environ:
+            dec_cfg["mma"] = "auto"
+        self.decoder = decoder.Generator(dec_cfg).cuda()
         self.decoder.load_state_dict(torch.load(path_stage1 + opt.First_stage_model["checkpoint_decoder"] + ".pth",
                                                 map_location="cpu")["state_dict"])
         _ = self.decoder.eval()
@@ -88,6 +95,12 @@ class Model(torch.nn.Module):
     def check(self):
         """Raises if the decoder's split-fp16 operands left the fp16 range in any call since the last check (sticky device
         flag, i2v_dec_status).  Synchronises: call it where the results are brought to the host anyway."""
+        fb = self.decoder.native().fallback_layers()
+        if fb["layers"] or fb["whole_handle"]:
+            import warnings
+            warnings.warn("decoder (mma = auto): the range guard switched " + ("the whole handle" if fb["whole_handle"] else ", ".join(fb["layers"])) +
+                          f" to the exact-fp32 kernels ({fb['reruns']} forward(s) were run again): this checkpoint's activations leave the window "
+                          "the split-fp16 operand format holds 1e-4 in (INTEGRATION.md §3); the frames are valid", RuntimeWarning)
         flags = self.decoder.native().status()
         if flags & 2 and not flags & 1:
             import warnings

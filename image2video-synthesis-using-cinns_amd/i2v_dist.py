@@ -58,8 +58,12 @@ class OverlappedCollator:
     decoder, which overlap the transfer over xGMI.  ``result()`` makes the current stream wait for the newest gather and
     returns its buffer; a buffer is reused two submits later, by which time the caller has consumed it."""
 
-    def __init__(self, total, group=None):
+    def __init__(self, total, group=None, emulate=False):
         self.total, self.group = total, group
+        # emulate (one process, measurement only): the same side stream, events and double buffers, with a device copy of the block
+        # standing in for the RCCL all-gather -- the stream configuration of an N > 1 job (main + side streams + the collation stream)
+        # on ONE GPU, to measure what the extra stream costs on HIP's four hardware queues (bench.py --emulate-collation)
+        self.emulate = bool(emulate)
         self.stream = None
         self.bufs = [None, None]
         self.events = [None, None]
@@ -67,6 +71,8 @@ class OverlappedCollator:
         self.last = None
 
     def submit(self, local):
+        if self.emulate and local.is_cuda and not (dist.is_available() and dist.is_initialized()):
+            return self._submit_emulated(local)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1 \
                 or self.total % dist.get_world_size(self.group) != 0 or not local.is_cuda:
             self.last = ("sync", collate(local, self.total, self.group))  # ragged shards / CPU tensors (gloo): plain path
@@ -87,6 +93,27 @@ class OverlappedCollator:
             self.stream.wait_event(ready)
             dist.all_gather_into_tensor(self.bufs[k], local, group=self.group)
             local.record_stream(self.stream)             # keep the block alive until the gather has read it
+            done = torch.cuda.Event()
+            done.record()
+        self.events[k] = done
+        self.last = ("async", k)
+
+    def _submit_emulated(self, local):
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=local.device)
+        k = self.i
+        self.i ^= 1
+        if self.bufs[k] is None or self.bufs[k].shape != local.shape:
+            if self.events[k] is not None:
+                self.events[k].synchronize()
+            with torch.cuda.stream(self.stream):
+                self.bufs[k] = torch.empty_like(local)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            self.bufs[k].copy_(local)                    # stands in for the all-gather kernel
+            local.record_stream(self.stream)
             done = torch.cuda.Event()
             done.record()
         self.events[k] = done

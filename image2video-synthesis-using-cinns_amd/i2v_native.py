@@ -103,6 +103,7 @@ SYMBOLS = {
     "i2v_dec_prepare_cancel": (c_int32, [c_void_p]),
     "i2v_dec_join": (c_int32, [c_void_p, c_void_p]),
     "i2v_dec_set_side_stream": (c_int32, [c_void_p, c_void_p]),
+    "i2v_dec_fallback_layers": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
     "i2v_dec_set_profile": (c_int32, [c_void_p, c_int32]),
     "i2v_dec_debug_tap": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t]),
     "i2v_dec_get_profile": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
@@ -364,6 +365,16 @@ class NativeDecoder(_Handle):
         _check(lib().i2v_dec_status(self._h, ctypes.byref(flags), int(bool(reset)), _stream()), "i2v_dec_status")
         return int(flags.value)
 
+    LAYER_NAMES = tuple(f"{b}.conv_{i}" for b in ("head_0", "g_0", "g_1", "g_2", "g_3", "g_4") for i in (0, 1))
+
+    def fallback_layers(self):
+        """mma = auto (i2v_dec_fallback_layers): the 3x3x3 convs the range guard has switched to the exact-fp32 kernels so far, as
+        ``{"layers": [names], "whole_handle": bool, "reruns": n}``.  Empty for a checkpoint inside the split format's window."""
+        mask, reruns = c_int32(), c_int32()
+        _check(lib().i2v_dec_fallback_layers(self._h, ctypes.byref(mask), ctypes.byref(reruns)), "i2v_dec_fallback_layers")
+        return {"layers": [n for i, n in enumerate(self.LAYER_NAMES) if mask.value >> i & 1], "whole_handle": bool(mask.value >> 30 & 1),
+                "reruns": int(reruns.value)}
+
     @_on_device
     def debug_tap(self, block, which, dst):
         """Test hook (i2v_dec_debug_tap): dst = float32 CUDA tensor or None."""
@@ -595,9 +606,18 @@ def default_flow_f16():
     return int(os.environ.get("I2V_FLOW_F16", "0"))
 
 
+def parse_mma(v):
+    """0 / 1 / 2 or "auto" (= 2) -> the i2v_dec_cfg.mma value."""
+    if isinstance(v, str):
+        v = v.strip().lower()
+        return 2 if v == "auto" else int(v)
+    return int(v)
+
+
 def default_mma():
-    """Matrix-core mode of the 3x3x3 convolutions: 1 = split-fp16 (default), 0 = exact fp32 MFMA; env I2V_DEC_MMA."""
-    return int(os.environ.get("I2V_DEC_MMA", "1"))
+    """Matrix-core mode of the 3x3x3 convolutions: 1 = split-fp16 (default), 0 = exact fp32 MFMA, 2 / "auto" = split-fp16 with the
+    per-layer fallback to exact fp32 behind the range guard (every forward synchronises); env I2V_DEC_MMA."""
+    return parse_mma(os.environ.get("I2V_DEC_MMA", "1"))
 
 
 class NativeGBlock(_Handle):

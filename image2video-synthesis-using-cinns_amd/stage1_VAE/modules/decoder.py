@@ -64,7 +64,7 @@ class Generator(NativeBacked):
         # matrix-core mode of the 3x3x3 convolutions: 0 = exact fp32 MFMA, 1 = split-fp16 (3 fp16 MFMAs per product,
         # fp32-class accuracy, ~5x the rate).  Not a reference key: taken from dic["mma"] or the I2V_DEC_MMA env var.
         mma = dic.get("mma", None) if hasattr(dic, "get") else None
-        self.mma = native.default_mma() if mma is None else int(mma)
+        self.mma = native.default_mma() if mma is None else native.parse_mma(mma)   # 0, 1, 2 or "auto" (= 2)
 
     def _build_native(self):
         h = native.NativeDecoder(self.channel_factor, self.z_dim, self.upsample_s, self.upsample_t, self.use_spectral,

@@ -138,7 +138,11 @@ typedef struct {
     int32_t upsample_s[2];  /* decoder.py:66 */
     int32_t upsample_t[2];  /* decoder.py:67 */
     int32_t spectral_norm;  /* decoder.py:64 */
-    int32_t mma;            /* 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = split-fp16 3-term MFMA */
+    int32_t mma;            /* 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = split-fp16 3-term MFMA; 2 = auto: split-fp16 with a
+                             * per-layer fallback to the exact-fp32 kernels behind the range guard -- both weight sets are packed, every
+                             * forward synchronises its stream, looks at the operand maxima the writers published, switches the 3x3x3 convs
+                             * whose operand left the window the split format holds 1e-4 in (for the life of the handle) and runs the call
+                             * again; a checkpoint inside the window runs exactly the launches of mma = 1 (i2v_dec_fallback_layers) */
 } i2v_dec_cfg;
 
 int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out);
@@ -201,6 +205,11 @@ int i2v_dec_join(i2v_dec* d, void* stream);
  * serialise.  `side_stream` stays the caller's (it must outlive the handle or be reset with NULL: the handle then creates its own
  * again).  Same kernels, same events, same bits.  No reference counterpart (the reference has one stream). */
 int i2v_dec_set_side_stream(i2v_dec* d, void* side_stream);
+/* mma = 2 (auto): which 3x3x3 convs the range guard has switched to the exact-fp32 kernels so far: bit 2 * block + (0: conv_0, 1: conv_1),
+ * blocks head_0, g_0 .. g_4; bit 30: the whole handle (an overflow outside the conv operands: SPADE's activation, a shortcut, conv_img).
+ * reruns (optional): forwards that were run a second time because a layer had to be switched.  Always 0 / 0 for mma = 0, 1.
+ * No reference counterpart (the reference computes in fp32 throughout: decoder.py:99-120). */
+int i2v_dec_fallback_layers(i2v_dec* d, int32_t* mask, int32_t* reruns);
 /* Roofline instrumentation.  With profiling on, every 3x3x3 Conv3d launch (the dominant kernel) is bracketed by HIP
  * events recorded on the launch stream -- no synchronisation is added to the forward.  After the caller has
  * synchronised, i2v_dec_get_profile resolves the pending pairs and returns the totals since set_profile(d, 1):

@@ -1349,6 +1349,65 @@ def test_hl16_range_guard():
     assert gu.native().status(reset=True) == 2 and gu.native().status() == 0
 
 
+def test_mma_auto_falls_back_per_layer_behind_the_range_guard():
+    """Round 6 (review item: "nothing automatic stands behind the range guard"): mma = "auto" packs both weight sets; every forward
+    synchronises, reads the operand maxima the writers published, switches the 3x3x3 convs whose operand left the window of the
+    split-fp16 format to the exact-fp32 kernels (for the life of the handle) and runs the call again.  The checkpoints of
+    test_hl16_range_guard must return VALID frames without an exception -- the 3e6 SPADE bias (overflow in g_2.conv_0's operand:
+    1e-3 vs the oracle, huge activations), the 2^-20 ADAIN (underflow in g_3.conv_1's operand: 1e-4), the 1e6 bias that only
+    conv_img's guard sees (whole-handle fallback) -- and an in-range checkpoint must run exactly the mma = 1 launches (same bits,
+    nothing switched).  get_model.Model runs the decoder in this mode by default."""
+    from oracle import decoder_ref
+    from stage1_VAE.modules.decoder import Generator
+    cfg = {"channel_factor": 8, "z_dim": 64, "upsample_s": [2, 1], "upsample_t": [2, 1], "spectral_norm": True}
+    x0, z, _ = synth.bench_inputs(2, 64, 64)
+    xc, zc = x0.cuda(), z.cuda()
+
+    def make(sd, mma, **kw):
+        g = Generator(dict(cfg, mma=mma, **kw))
+        g.load_state_dict(sd)
+        return g.cuda().eval()
+
+    base = T(synth.decoder_state_dict(seed=5, channel_factor=8))
+    ref1 = make(base, 1)(xc, zc)
+    ga = make(base, "auto")
+    assert ga.mma == 2 and torch.equal(ga(xc, zc), ref1)
+    assert ga.native().fallback_layers() == {"layers": [], "whole_handle": False, "reruns": 0} and ga.native().status() == 0
+    # overflow in ONE operand tensor
+    sd = dict(base)
+    sd["g_2.norm_0.conv_gamma.bias"] = sd["g_2.norm_0.conv_gamma.bias"] * 0 + 3.0e6
+    g1 = make(sd, "auto")
+    out = g1(xc, zc)
+    fb = g1.native().fallback_layers()
+    ref = decoder_ref.generator(sd, x0, z)
+    err = rel_l2(out.cpu(), ref)
+    print(f"mma auto, 3e6 SPADE bias: switched {fb}, rel-L2 vs oracle {err:.2e}")
+    assert bool(torch.isfinite(out).all()) and err < 1e-3 and "g_2.conv_0" in fb["layers"] and not fb["whole_handle"] and fb["reruns"] >= 1
+    assert g1.native().status() == 0
+    again = g1(xc, zc)                                   # the decision sticks: no further re-run, same frames
+    assert torch.equal(again, out) and g1.native().fallback_layers()["reruns"] == fb["reruns"]
+    out0 = make(sd, 0)(xc, zc)
+    assert rel_l2(out.cpu(), out0.cpu()) < 1e-3
+    # underflow in one operand tensor
+    sd3 = dict(base)
+    for key in ("g_3.norm_1.linear.weight", "g_3.norm_1.linear.bias"):
+        sd3[key] = sd3[key] * 2.0 ** -20
+    g3 = make(sd3, "auto")
+    out_u = g3(xc, zc)
+    fb3 = g3.native().fallback_layers()
+    err_u = rel_l2(out_u.cpu(), decoder_ref.generator(sd3, x0, z))
+    print(f"mma auto, 2^-20 ADAIN: switched {fb3}, rel-L2 vs oracle {err_u:.2e}")
+    assert err_u < TOL and fb3["layers"] == ["g_3.conv_1"] and g3.native().status() == 0
+    # an overflow no operand slot explains (only conv_img's guard sees g_4.conv_1's huge bias): the whole handle falls back
+    sd2 = T(synth.decoder_state_dict(seed=5, channel_factor=16))
+    sd2["g_4.conv_1.bias"] = sd2["g_4.conv_1.bias"] * 0 + 1.0e6
+    g2 = make(sd2, "auto", channel_factor=16)
+    out2 = g2(xc, zc)
+    fb2 = g2.native().fallback_layers()
+    assert fb2["whole_handle"] and bool(torch.isfinite(out2).all()) and g2.native().status() == 0
+    assert rel_l2(out2.cpu(), make(sd2, 0, channel_factor=16)(xc, zc).cpu()) < 1e-5
+
+
 def test_handles_are_bound_to_their_device():
     """A native handle serves the GPU its module lives on: a tensor from another device is rejected; with one GPU
     visible the check is exercised through the C ABI's own device test."""

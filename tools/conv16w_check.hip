@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "i2v_conv.h"
@@ -35,6 +36,10 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 2, T = argc > 2 ? atoi(argv[2]) : 16, H = argc > 3 ? atoi(argv[3]) : 64,
               W = argc > 4 ? atoi(argv[4]) : 64, Cin = argc > 5 ? atoi(argv[5]) : 256, Cout = argc > 6 ? atoi(argv[6]) : 128;
     const int tdup = argc > 7 ? atoi(argv[7]) : 0, use_res = argc > 8 ? atoi(argv[8]) : 0, nostats = argc > 9 ? atoi(argv[9]) : 0;
+    // gen: 1 = also run the operand-GENERATING kernel (conv_wino4g_f16x3_kernel) on the raw fp32 input + per-(b,c) coefficients
+    // (ADAIN form, conv_1 of g_4); 2 = with SPADE gamma' | beta maps and a x2 spatial up-sampling in front (conv_0 of g_4).  The
+    // activations the other kernels see are then a = lrelu(modulate(x)), formed on the host with the writer's expressions.
+    const int gen = argc > 10 ? atoi(argv[10]) : 0;
     const int Ti = tdup ? T / 2 : T, J = W / 2;
     std::vector<float> w((size_t)Cout * Cin * 27), bias(Cout);
     srand(1);
@@ -76,6 +81,35 @@ int main(int argc, char** argv) {
     for (auto& v : a) {
         v = (rand() / (float)RAND_MAX - 0.3f) * 2.f;
         if (v < 0) v *= 0.2f;  // leaky-relu-like distribution
+    }
+    // gen: raw input x (low resolution for gen = 2), coefficients, SPADE maps; a = what modulate_wino4_kernel would feed the conv
+    const int us = gen == 2 ? 2 : 1;
+    std::vector<float> xraw, coefh, gbh;
+    if (gen) {
+        if (tdup || !wino4g_supported(Cout, Cin, T, H, W, us)) { printf("gen: shape not supported by the generating kernel\n"); return 1; }
+        const int Hl = H / us, Wl = W / us;
+        xraw.resize((size_t)B * T * Hl * Wl * Cin);
+        coefh.resize((size_t)B * Cin * 2);
+        for (auto& v : xraw) v = (rand() / (float)RAND_MAX - 0.5f) * 3.f;
+        for (size_t i = 0; i < (size_t)B * Cin; ++i) { coefh[2 * i] = 0.5f + rand() / (float)RAND_MAX; coefh[2 * i + 1] = rand() / (float)RAND_MAX - 0.4f; }
+        if (gen == 2) {
+            gbh.resize((size_t)B * H * W * 2 * Cin);
+            for (size_t i = 0; i < gbh.size(); ++i) gbh[i] = ((i / Cin) & 1) ? rand() / (float)RAND_MAX - 0.5f : 0.6f + rand() / (float)RAND_MAX;
+        }
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t)
+                for (int h = 0; h < H; ++h)
+                    for (int w_ = 0; w_ < W; ++w_)
+                        for (int c = 0; c < Cin; ++c) {
+                            const float xv = xraw[((((size_t)b * T + t) * Hl + h / us) * Wl + w_ / us) * Cin + c];
+                            const float ca = coefh[((size_t)b * Cin + c) * 2], cb = coefh[((size_t)b * Cin + c) * 2 + 1];
+                            float r;
+                            if (gen == 2) {
+                                const float* gp = &gbh[(((size_t)b * H + h) * W + w_) * 2 * Cin];
+                                r = fmaf(xv, ca * gp[c], fmaf(cb, gp[c], gp[Cin + c]));
+                            } else r = fmaf(xv, ca, cb);
+                            a[((((size_t)b * T + t) * H + h) * W + w_) * Cin + c] = r < 0.f ? 0.2f * r : r;
+                        }
     }
     // power probe: I2V_CHECK_DATA=zero (all-zero activations), =pow2 (powers of two: empty lo parts)
     if (const char* e = getenv("I2V_CHECK_DATA")) {
@@ -121,8 +155,9 @@ int main(int argc, char** argv) {
                         const int wq = 4 * j - 1 + k;
                         d[k] = (wq >= 0 && wq < W) ? a[(row * W + wq) * Cin + c] : 0.f;
                     }
-                    const float v[6] = {4 * d[0] - 5 * d[2] + d[4], -4 * (d[1] + d[2]) + d[3] + d[4], 4 * (d[1] - d[2]) - d[3] + d[4],
-                                        2 * (d[3] - d[1]) + d[4] - d[2], 2 * (d[1] - d[3]) + d[4] - d[2], 4 * d[1] - 5 * d[3] + d[5]};
+                    // (the expressions of modulate_wino4_kernel, so that this operand is the production writer's bit for bit)
+                    const float v[6] = {fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4])), fmaf(-4.f, d[1] + d[2], d[3] + d[4]), fmaf(4.f, d[1] - d[2], d[4] - d[3]),
+                                        fmaf(2.f, d[3] - d[1], d[4] - d[2]), fmaf(2.f, d[1] - d[3], d[4] - d[2]), fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]))};
                     for (int x = 0; x < 6; ++x) {
                         _Float16 hi, lo;
                         split(v[x], hi, lo);
@@ -233,13 +268,46 @@ int main(int argc, char** argv) {
     if (do4)
         printf("   F(4,3) vs direct rel-L2 %.3e max|d| %.3e nonfinite %zu  stats rel %.2e | F(4,3) vs fp64 (400 samples) rel-L2 %.3e\n",
                std::sqrt(num4 / (den + 1e-30)), mx4, bad4, smx4, std::sqrt(rnum4 / (rden + 1e-30)));
+    float *dx = nullptr, *dcoef = nullptr, *dgb = nullptr, *o3 = nullptr;
+    double* s3 = nullptr;
+    int* dflag = nullptr;
+    if (gen && do4) {
+        hipMalloc(&dx, xraw.size() * 4); hipMemcpy(dx, xraw.data(), xraw.size() * 4, hipMemcpyHostToDevice);
+        hipMalloc(&dcoef, coefh.size() * 4); hipMemcpy(dcoef, coefh.data(), coefh.size() * 4, hipMemcpyHostToDevice);
+        if (gen == 2) { hipMalloc(&dgb, gbh.size() * 4); hipMemcpy(dgb, gbh.data(), gbh.size() * 4, hipMemcpyHostToDevice); }
+        hipMalloc(&o3, npo * Cout * 4); hipMemset(o3, 0xff, npo * Cout * 4);
+        hipMalloc(&s3, (size_t)B * Cout * 16); hipMemset(s3, 0, (size_t)B * Cout * 16);
+        hipMalloc(&dflag, 64 * 4); hipMemset(dflag, 0, 64 * 4);
+        if (wino4g_forward(w4, dx, dcoef, dgb, us, o3, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s3, dflag, dflag + 1)) {
+            printf("wino4g: %s\n", i2v_last_error()); return 1;
+        }
+        if (hipDeviceSynchronize() != hipSuccess) { printf("gen kernel fault: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+        std::vector<float> h3(npo * Cout);
+        std::vector<double> hs3((size_t)B * Cout * 2);
+        int hflag[2] = {0, 0};
+        hipMemcpy(h3.data(), o3, h3.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(hs3.data(), s3, hs3.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(hflag, dflag, 8, hipMemcpyDeviceToHost);
+        size_t ndiff = 0, first = (size_t)-1;
+        double mxd = 0;
+        for (size_t i = 0; i < h3.size(); ++i)
+            if (memcmp(&h3[i], &h2[i], 4)) { if (!ndiff) first = i; ++ndiff; mxd = std::max(mxd, std::fabs((double)h3[i] - h2[i])); }
+        double smx3 = 0;
+        if (!nostats) for (size_t i = 0; i < hs3.size(); ++i) smx3 = std::max(smx3, std::fabs(hs3[i] - hs2[i]) / (std::fabs(hs2[i]) + 1.0));
+        float amax = 0.f;
+        for (float v : a) amax = std::max(amax, std::fabs(v));
+        float um; memcpy(&um, &hflag[1], 4);
+        printf("   GEN (mode %d) vs F(4,3) on the writer's operand: %zu of %zu outputs differ (first at %zu, max|d| %.3e)  stats rel %.2e | range flag %d, published max|d| %.6g (host %.6g)\n",
+               gen, ndiff, h3.size(), first, mxd, smx3, hflag[0], um, amax);
+    }
     const double flops = 2.0 * npo * Cin * Cout * 27.0;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int n = 5;
-    for (int which = 0; which < (do4 ? 3 : 2); ++which) {
+    for (int which = 0; which < (do4 ? (gen ? 4 : 3) : 2); ++which) {
         auto go = [&]() {
-            if (which == 2) wino4_forward(w4, dV4, o2, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s2);
+            if (which == 3) wino4g_forward(w4, dx, dcoef, dgb, us, o3, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s3, dflag, dflag + 1);
+            else if (which == 2) wino4_forward(w4, dV4, o2, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s2);
             else if (which) wino16_forward(ww, dV, o1, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, nostats ? nullptr : s1);
             else conv16_forward(cw, dhl, o0, dres, 1, 1, B, T, H, W, EPI_NONE, nullptr, fuse ? s0 : nullptr);
         };
@@ -251,7 +319,7 @@ int main(int argc, char** argv) {
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         ms /= n;
-        printf("   %-8s %8.3f ms  %7.1f TFLOP/s algorithmic\n", which == 2 ? "F(4,3)" : which ? "F(2,3)" : "direct", ms, flops / ms / 1e9);
+        printf("   %-8s %8.3f ms  %7.1f TFLOP/s algorithmic\n", which == 3 ? "GEN" : which == 2 ? "F(4,3)" : which ? "F(2,3)" : "direct", ms, flops / ms / 1e9);
 #ifdef W4_TAPTIME
         if (which == 2) w4_taptime_report();
 #endif
