@@ -907,6 +907,8 @@ def encoder_latency(cfg, x0_d):
 KERNEL_TEXT = {
     "conv_wino4_f16x3": "conv_wino4_f16x3_kernel (3x3x3 Conv3d, Winograd F(4,3) along W on split-fp16 operands: 6 transformed planes per 4 "
                         "outputs in two passes over the K loop, 3x v_mfma_f32_32x32x16_f16 per product; i2v_conv16w4.hip)",
+    "conv_wino4g_f16x3": "conv_wino4g_f16x3_kernel (the same F(4,3) conv with the operand generated in the kernel: 8 MFMA waves + 4 producer waves "
+                         "that form lrelu(norm(x)), B^T d and the fp16 hi / lo split from the conv's fp32 input; i2v_conv16w4g.hip)",
     "conv_wino_f16x3": "conv_wino_f16x3_kernel (3x3x3 Conv3d, Winograd F(2,3) along W on split-fp16 operands: 4 planes per output pair; "
                        "i2v_conv16w.hip)",
     "conv_mfma_f16x3": "conv_mfma_f16x3_kernel (3x3x3 Conv3d, direct split-fp16 implicit GEMM; i2v_conv16.hip)",

@@ -83,7 +83,13 @@ __device__ __forceinline__ int brick_index(int row, int TH, int TW, int patch) {
 
 // TPS = taps per pipeline stage: the narrower the channel tile, the more taps share one weight buffer / barrier
 // (BN x TPS = 128 rows per buffer for every variant).
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
+// TSK (round 6): temporal tap skipping per MFMA row block.  A 3-tap temporal kernel on a TWO-frame map (g_0.conv_1: 2 x 8 x 8) meets
+// zero padding in one of its three temporal taps for EVERY output frame (frame 0: the tap at t - 1, frame 1: the tap at t + 1), but the
+// brick holds both frames, so the brick-level tap list keeps all 27 taps and a third of the MFMAs multiply zero rows.  A 32-row MFMA
+// block lies inside one frame: with TSK each tap carries its temporal offset (low bits of its LDS offset) and a row block whose frame
+// meets only padding for the tap skips its MFMAs -- 18 instead of 27 taps of matrix work, the same bits (the skipped products are
+// exact zeros).
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, bool TSK = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void conv_mfma_f16x3_kernel(Conv16Args a) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;              // 512 (2 waves per SIMD) or 1024 (4 per SIMD)
     constexpr int NSLOT = C16_SLOTS * 512 / NTHR;            // prefetched 16-byte input pieces per thread
@@ -150,12 +156,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
             const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
             if (hi < 0 || lo >= a.T) continue;  // the whole brick meets zero padding only
             taplist[1 + cnt] = a.tap_base + tap;
-            taplist[33 + cnt] = ((dt * HH + dh) * HW + dw) * C16_ROW;
+            taplist[33 + cnt] = ((dt * HH + dh) * HW + dw) * C16_ROW | (TSK ? dt : 0);   // (C16_ROW is a multiple of 16: the low bits are free)
             ++cnt;
         }
         while (cnt % TPS) {  // pad the stage with the all-zero weight slab
             taplist[1 + cnt] = a.ztap;
-            taplist[33 + cnt] = 0;
+            taplist[33 + cnt] = TSK ? 3 : 0;   // (TSK: temporal offset 3 = outside the map for every row block: skipped)
             ++cnt;
         }
         taplist[0] = cnt;
@@ -173,6 +179,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     }
 
     int aoff[WM], boff[WN];
+    int tbs[WM];   // TSK: input frame of the row block for temporal offset 0 (the launcher guarantees 32-row blocks inside one frame)
 #pragma unroll
     for (int wm = 0; wm < WM; ++wm) {
         int m = brick_index(wave_m * (32 * WM) + 32 * wm + l31, a.TH, a.TW, a.patch);
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         const int ih = m % a.TH; m /= a.TH;
         const int it = m % a.TT; m /= a.TT;
         aoff[wm] = ((((m < a.TB ? m : 0) * HT + it) * HH + ih) * HW + iw) * C16_ROW + kg * 32;
+        tbs[wm] = TSK ? __builtin_amdgcn_readfirstlane(t0 + it - pt) : 0;
     }
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) boff[wn] = (wave_n * (32 * WN) + 32 * wn + l31) * C16_ROW + kg * 32;
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
 #define C16_LOAD_OPS(o, aoffs, wbuf, koff)                                                                            \
     {                                                                                                                \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
-            const char* p_ = in_lds + aoff[wm] + (aoffs) + (koff);                                                   \
+            const char* p_ = in_lds + aoff[wm] + (TSK ? ((aoffs) & ~3) : (aoffs)) + (koff);                          \
             (o).ah[wm] = *reinterpret_cast<const half8*>(p_);                                                        \
             (o).al[wm] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
         }                                                                                                            \
@@ -237,13 +245,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         }                                                                                                            \
     }
     // three terms, tiles interleaved so that consecutive MFMAs never chain on the same accumulator
-#define C16_MFMA(o)                                                                                                  \
+#define C16_MFMA(o, tq_)                                                                                             \
     {                                                                                                                \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+        bool on_[WM];                                                                                                \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) on_[wm] = !TSK || ((onmask >> ((tq_) * WM + wm)) & 1u);     \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) if (on_[wm]) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) \
             acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) if (on_[wm]) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) \
             acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bl[wn], acc[wm][wn], 0, 0, 0);      \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn)          \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) if (on_[wm]) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) \
             acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
     }
     // split-K (tiny feature maps: few tiles, long K): this workgroup covers the chunks [ch0, ch1)
@@ -315,6 +325,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         // (s_setprio around the MFMA block and dropping the scheduling fences were measured: no effect.)
 #define C16_STAGE(st_, WR)                                                                                           \
     {                                                                                                                \
+        unsigned onmask = ~0u;   /* TSK: bit (tap of the stage) * WM + row block = the block's frame meets data for the tap */ \
+        if constexpr (TSK) {                                                                                         \
+            onmask = 0u;                                                                                             \
+            _Pragma("unroll") for (int t = 0; t < TPS; ++t) {                                                        \
+                const int dt_ = __builtin_amdgcn_readfirstlane(tcur[t] & 3);                                         \
+                _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                    \
+                    onmask |= ((unsigned)(tbs[wm] + dt_) < (unsigned)a.T ? 1u : 0u) << (t * WM + wm);                \
+            }                                                                                                        \
+        }                                                                                                            \
         const char* wb = w_lds + ((st_) & 1) * WBUF;                                                                 \
         char* wnext = w_lds + (((st_) + 1) & 1) * WBUF;                                                              \
         /* unconditional (after the last stage: a harmless re-park / re-request of the last slab): the vmcnt queue    \
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                 if ((st_) + 1 < nst) C16_LOAD_OPS(o0, tnxt[0], wnext, 0)                                             \
             }                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
-            if (q & 1) C16_MFMA(o1) else C16_MFMA(o0)                                                                \
+            if (q & 1) C16_MFMA(o1, q >> 1) else C16_MFMA(o0, q >> 1)                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
         _Pragma("unroll") for (int t = 0; t < TPS; ++t) { tcur[t] = tnxt[t]; tnxt[t] = tnn[t]; }                     \
@@ -502,9 +521,9 @@ int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
     return I2V_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, bool TSK = false>
 static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
-    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS>;
+    auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS, TSK>;
     static bool attr_set[I2V_MAX_DEV] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.tdup ? 2 * nblk : nblk, a.ksplit), dim3(64 * WAVES_M * WAVES_N), lds, st, a);
@@ -615,9 +634,15 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * a.HWp;
     // channel tile: the widest that divides CoutPad, narrowed while the launch would leave most CUs without a workgroup
     // (head_0: 64 samples x 4 x 4 positions = 4 bricks x 8 tiles of 128 channels, each streaming 9 x 1024 channels of K)
+    // split-K (decided by the layer geometry alone, see below): its slices are workgroups too -- round 5 narrowed the channel tile
+    // without counting them, so head_0 at B = 64 (4 bricks x 8 slices) ran 32-channel tiles: 1024 workgroups that each re-read the
+    // whole activation brick for 32 output channels (0.38 / 0.27 ms for 0.04 ms of matrix work).  The tile width changes the schedule
+    // only, never an output's accumulation order: same bits.
+    const bool can_split = splitk_ws && !stats && !(epi & (EPI_FRAMES | EPI_HL16)) && a.Cout % 4 == 0;
+    const int ksplit_plan = can_split ? conv16_splitk_factor((long)(a.tdup ? 2 * T : T) * H * W, a.nchunk) : 1;
     int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
     {
-        const long bricks = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.tdup ? 2 : 1);
+        const long bricks = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.tdup ? 2 : 1) * ksplit_plan;
         while (BN > 32 && bricks * (a.CoutPad / BN) < 256) BN /= 2;
     }
     const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + (size_t)npos * 4;
@@ -629,8 +654,8 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     // caller's scratch and a reduction pass (fixed order) applies bias / residual / activation.
     const long npos_out = (long)B * (a.tdup ? 2 * T : T) * H * W;
     int ksplit = 1;
-    if (splitk_ws && !stats && !(epi & (EPI_FRAMES | EPI_HL16)) && a.Cout % 4 == 0) {
-        ksplit = conv16_splitk_factor((long)(a.tdup ? 2 * T : T) * H * W, a.nchunk);
+    if (can_split) {
+        ksplit = ksplit_plan;
         I2V_REQUIRE((size_t)ksplit * npos_out * a.Cout <= splitk_ws_floats || ksplit == 1, I2V_E_WORKSPACE,
                     "conv16: split-K scratch of %zu floats is too small for %d x %ld x %d", splitk_ws_floats, ksplit, npos_out, a.Cout);
     }
@@ -641,9 +666,12 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     }
     // (a 16-wave variant <8,2,1,2,1> -- 4 waves per SIMD, wave tile 32x64, 128 VGPRs -- was measured 5 % slower)
     int rc;
-    if (BN == 128) rc = launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
-    else if (BN == 64) rc = launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);
-    else rc = launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);
+    // temporal tap skipping per row block (see the kernel): a 3-tap temporal kernel on a two-frame map whose 32-row MFMA blocks lie
+    // inside one frame (g_0.conv_1: 2 x 8 x 8)
+    const bool tsk = !a.tdup && a.KT == 3 && a.T == 2 && a.TT == 2 && (a.TH * a.TW) % 32 == 0;
+    if (BN == 128) rc = tsk ? launch16<4, 2, 2, 2, 1, true>(a, (unsigned)nblk, lds, st) : launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
+    else if (BN == 64) rc = launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);   // (its TSK instantiation spills: 256 VGPRs + scratch; the 64-wide tile keeps all 27 taps)
+    else rc = tsk ? launch16<8, 1, 1, 1, 4, true>(a, (unsigned)nblk, lds, st) : launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);
     if (rc || ksplit == 1) return rc;
     const long total4 = npos_out * (a.Cout / 4);
     hipLaunchKernelGGL(conv16_splitk_reduce_kernel, dim3((unsigned)std::min<long>((total4 + 255) / 256, 4096)), dim3(256), 0, st,

@@ -660,6 +660,9 @@ struct i2v_dec {
     int img16 = 2;  // split-fp16 mode: 2 fused matrix-core kernel (i2v_convimg.hip), 1 round 2's 81-plane GEMM + gather at nf >= 64, 0 vector-ALU kernel (env I2V_DEC_IMG16)
     int wino4 = 1; // 1: F(4,3) Winograd kernel where the shape allows and one sample gives >= 32 workgroups (env I2V_DEC_WINO4=0: F(2,3); 2: wherever the shape allows)
     int spw = 1;   // 1: SPADE's gamma|beta conv uses the Winograd kernel where the shape allows (env I2V_DEC_SPW=0: direct kernel)
+    int gen = 0;   // 1: the thin F(4,3) layers of the 128 x 128 configs (g_4: 32 output channels at 16 x 128 x 128) generate their operand in the
+                   // conv kernel's own producer waves instead of reading a V tensor an operand-writer launch wrote (i2v_conv16w4g.hip; same
+                   // bits).  env I2V_DEC_GEN.  Measured in profiles/r06_*_thin_fused_*.
     int wino32 = 1;  // exact-fp32 mode (mma = 0): 1 = 3x3x3 convs from the 8x8 level on run Winograd F(4,3) on the fp32 matrix cores (env I2V_DEC_WINO32=0: direct kernel)
     const float* prep_img = nullptr;   // i2v_dec_prepare: the start frames whose SPADE branches are in the workspace's gbs[] ...
     int prep_B = 0;                    // ... their batch, image size and the workspace they live in (consumed by the next matching forward)
@@ -959,6 +962,16 @@ int conv3_w4(i2v_dec* d, const Wino4Weights& w, const float* v_hl16, float* out,
     return wino4_forward(w, v_hl16, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats);
 }
 
+// the same conv with the operand generated in the kernel (no operand-writer launch in front): x = the conv's fp32 input before the
+// modulation, coef / gb as the writer takes them
+int conv3_w4g(i2v_dec* d, const Wino4Weights& w, const float* x, const float* coef, const float* gb, int us, float* out, const float* res, int rt,
+              int rs, int B, const Level& l, int epi, hipStream_t st, double* stats, int* flag, int* umax) {
+    if (stats) I2V_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * w.Cout * 16, st));
+    const double fl = 2.0 * B * l.T * l.H * l.W * (double)w.Cin * w.Cout * 27.0;
+    ProfScope ps(d, st, fl, 3.0 * fl * 0.5);
+    return wino4g_forward(w, x, coef, gb, us, out, res, rt, rs, B, l.T, l.H, l.W, epi, st, stats, flag, umax);
+}
+
 // which kernel conv_0 / conv_1 of a block use at this geometry (want_*: by shape; use_*: and the weights are packed for it)
 bool want_wino0(const i2v_dec* d, const Block& b, const Level& l) {
     const bool tdup = l.ut == 2;   // conv_0 behind a x2 temporal up-sampling: pair kernels on the half-rate tensor (Block::tdup0)
@@ -1105,17 +1118,22 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     int* um0 = f16_0 && flag ? flag + 1 + 2 * (k % 12) : nullptr;
     int* um1 = f16_1 && flag ? flag + 2 + 2 * (k % 12) : nullptr;
     const bool f0 = !f16_0 && w.m6 && use_wf_0(d, b, l), f1 = !f16_1 && w.m6 && use_wf_1(d, b, l);   // exact fp32: Winograd F(4,3) on the fp32 matrix cores
-    if (f0) rc = modulate_wino4_f32(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st);
+    // thin F(4,3) layers: the operand is generated by the conv kernel's producer waves (no writer launch, no V tensor)
+    const bool g0 = d->gen == 1 && q0 && !tdup && l.ut == 1 && l.us == 2 && !d->tap_dst && wino4g_supported(b.n_mid, b.n_in, l.T, l.H, l.W, 2);
+    const bool g1 = d->gen && q1 && !d->tap_dst && wino4g_supported(b.n_out, b.n_mid, l.T, l.H, l.W, 1);
+    if (g0) rc = I2V_OK;
+    else if (f0) rc = modulate_wino4_f32(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st);
     else if (q0) rc = run_modulate_wino4(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
     else if (w0) rc = run_modulate_wino(x, coef, gb, a, B, tdup ? l.T / 2 : l.T, l.H, l.W, b.n_in, tdup ? 1 : l.ut, l.us, 1, st, flag, um0);
     else if (tdup) rc = run_modulate(x, coef, gb, a, B, l.T / 2, l.H, l.W, b.n_in, 1, l.us, 1, st, true, flag, um0);
     else rc = run_modulate(x, coef, gb, a, B, l.T, l.H, l.W, b.n_in, l.ut, l.us, 1, st, f16_0, flag, um0);
     if (rc) return rc;
-    if (!f0 && (rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
+    if (!f0 && !g0 && (rc = tap(k, 1, a, (size_t)B * (tdup ? P / 2 : P) * b.n_in))) return rc;
     const bool fuse = f16_0 && conv16_can_fuse_stats(tdup ? l.T / 2 : l.T, l.H, l.W);
     d->prof_cur_layer = 2 * k;
-    d->prof_cur_kernel = q0 ? 3 : w0 ? 2 : (f16_0 ? 1 : 0);
-    if (f0) rc = conv3_wf(d, b.conv0_wf, a, w.m6, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
+    d->prof_cur_kernel = g0 ? 4 : q0 ? 3 : w0 ? 2 : (f16_0 ? 1 : 0);
+    if (g0) rc = conv3_w4g(d, b.conv0_w4, x, coef, gb, 2, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr, flag, um0);
+    else if (f0) rc = conv3_wf(d, b.conv0_wf, a, w.m6, dx, nullptr, 1, 1, B, l, EPI_NONE, st);
     else if (q0) rc = conv3_w4(d, b.conv0_w4, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else if (w0) rc = conv3_w(d, b.conv0_w, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr);
     else if (f16_0) rc = conv3_16(d, b.conv0_16, a, dx, nullptr, 1, 1, B, l, EPI_NONE, st, fuse ? sums2 : nullptr, w.splitk, w.splitk_floats);
@@ -1125,12 +1143,13 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // ADAIN (normalization_layer.py:47-51) + leaky_relu
     if (!fuse && (rc = run_stats(dx, sums2, B, P, b.n_mid, st))) return rc;
     if ((rc = run_coef(sums2, coef, B, b.n_mid, b.n_mid, (double)P, zl, zstride, b.zoff, nullptr, nullptr, st))) return rc;
-    if (f1) rc = modulate_wino4_f32(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st);
+    if (g1) rc = I2V_OK;
+    else if (f1) rc = modulate_wino4_f32(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st);
     else if (q1) rc = run_modulate_wino4(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
     else if (w1) rc = run_modulate_wino(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, flag, um1);
     else rc = run_modulate(dx, coef, nullptr, a, B, l.T, l.H, l.W, b.n_mid, 1, 1, 1, st, f16_1, flag, um1);
     if (rc) return rc;
-    if (!f1 && (rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
+    if (!f1 && !g1 && (rc = tap(k, 3, a, (size_t)B * P * b.n_mid))) return rc;
     // shortcut (decoder.py:44-49) at low resolution
     const float* res = x;
     if (b.learned && !side_shortcut) {
@@ -1152,8 +1171,9 @@ int block_forward(i2v_dec* d, int k, Block& b, const Level& l, const float* x, f
     // statistics of the block OUTPUT = the next block's input)
     const bool fuse_out = f16_1 && conv16_can_fuse_stats(l.T, l.H, l.W) && !last;
     d->prof_cur_layer = 2 * k + 1;
-    d->prof_cur_kernel = q1 ? 3 : w1 ? 2 : (f16_1 ? 1 : 0);
-    if (f1) rc = conv3_wf(d, b.conv1_wf, a, w.m6, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
+    d->prof_cur_kernel = g1 ? 4 : q1 ? 3 : w1 ? 2 : (f16_1 ? 1 : 0);
+    if (g1) rc = conv3_w4g(d, b.conv1_w4, dx, coef, nullptr, 1, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr, flag, um1);
+    else if (f1) rc = conv3_wf(d, b.conv1_wf, a, w.m6, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st);
     else if (q1) rc = conv3_w4(d, b.conv1_w4, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
     else if (w1) rc = conv3_w(d, b.conv1_w, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr);
     else if (f16_1) rc = conv3_16(d, b.conv1_16, a, xn, res, l.ut, l.us, B, l, last ? EPI_LRELU : EPI_NONE, st, fuse_out ? sums_out : nullptr,
@@ -1291,6 +1311,7 @@ int i2v_dec_create(const i2v_dec_cfg* cfg, i2v_dec** out) {
     if (const char* e = std::getenv("I2V_DEC_IMG16")) d->img16 = std::atoi(e);
     if (const char* e = std::getenv("I2V_DEC_SPW")) d->spw = std::atoi(e) != 0;
     if (const char* e = std::getenv("I2V_DEC_WINO32")) d->wino32 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("I2V_DEC_GEN")) d->gen = std::atoi(e);   // 1: conv_0 and conv_1 of the thin level, 2: conv_1 only
     if (const char* e = std::getenv("I2V_DEC_OVERLAP")) { d->overlap = std::atoi(e) != 0; d->no_side_shortcut = std::atoi(e) == 2; }
     if (const char* e = std::getenv("I2V_DEC_SUB")) d->sub = std::max(0, std::atoi(e));
     if (int rc = init_status(d.get())) return rc;

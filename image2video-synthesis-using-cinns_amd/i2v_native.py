@@ -353,7 +353,7 @@ class NativeDecoder(_Handle):
             _check(lib().i2v_dec_get_layer_profile(self._h, layer, name, 48, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ex),
                                                    ctypes.byref(n), ctypes.byref(k)), "i2v_dec_get_layer_profile")
             if n.value:
-                rows.append({"layer": name.value.decode(), "kernel": ("conv_mfma_f32", "conv_mfma_f16x3", "conv_wino_f16x3", "conv_wino4_f16x3")[k.value],
+                rows.append({"layer": name.value.decode(), "kernel": ("conv_mfma_f32", "conv_mfma_f16x3", "conv_wino_f16x3", "conv_wino4_f16x3", "conv_wino4g_f16x3")[k.value],
                              "launches": int(n.value), "ms": ms.value, "flops": fl.value, "mfma_flops": ex.value})
         return rows
 

@@ -370,6 +370,57 @@ def test_f43_structure_switches_keep_the_bits(golden, monkeypatch, tmp_path):
     assert res["checked"] >= 14 and res["bad"] == [], res
 
 
+def test_generated_operand_kernel_keeps_the_bits(monkeypatch):
+    """Round 6: the thin F(4,3) layers of the 128x128 configs (g_4: 64 -> 32 behind SPADE and a x2 spatial up-sampling, 32 -> 32 behind
+    ADAIN) can generate their operand in the conv kernel itself -- 8 MFMA waves + 4 producer waves that form lrelu(norm(x)), B^T d
+    and the fp16 hi / lo split from the conv's fp32 input (csrc/i2v_conv16w4g.hip, I2V_DEC_GEN; opt-in: measured -6 % on layer + writer,
+    profiles/r06_d_thin_fused_no_go.md) -- instead of reading the V tensor modulate_wino4_kernel wrote.  Same expressions in the same
+    order: the frames must agree with the writer path to 1e-6 at the golden's batch and on a 5-sample batch (bricks at every border of
+    the tensor, several samples), the range guard must see the same things (in range: nothing; the underflow slot of g_4.conv_1 when
+    its ADAIN is scaled to 2^-20), and the golden holds."""
+    from stage1_VAE.modules.decoder import Generator
+    g, meta = load_golden("dec_nf32_128")
+    img, z = cu(g["img"]), cu(g["z"])
+    x5, z5, _ = synth.bench_inputs(5, 128, 64)
+    x5, z5 = x5.cuda(), z5.cuda()
+    monkeypatch.setenv("I2V_DEC_GEN", "0")
+    ref_gen = _gen(meta)
+    ref, ref5 = ref_gen(img, z), ref_gen(x5, z5)
+    monkeypatch.setenv("I2V_DEC_GEN", "1")
+    gen = _gen(meta)
+    gen.native().set_profile(True)
+    out, out5 = gen(img, z), gen(x5, z5)
+    torch.cuda.synchronize()
+    kernels = {L["layer"]: L["kernel"] for L in gen.native().get_layer_profile()}
+    gen.native().set_profile(False)
+    assert kernels["g_4.conv_0"] == kernels["g_4.conv_1"] == "conv_wino4g_f16x3" and kernels["g_3.conv_1"] == "conv_wino4_f16x3", kernels
+    assert rel_l2(out[..., ::2, ::2].cpu(), g["out_s2"]) < TOL
+    d1, d5 = float((out - ref).abs().max()), float((out5 - ref5).abs().max())
+    e1, e5 = rel_l2(out.cpu(), ref.cpu()), rel_l2(out5.cpu(), ref5.cpu())
+    print(f"generated operand vs writer path: max |diff| {d1:.3e} / rel-L2 {e1:.2e} (golden batch), {d5:.3e} / {e5:.2e} (5 samples)")
+    # Same source expressions, but NOT the same bits: hipcc picks v_cvt_f16_f32, v_cvt_pk_f16_f32 or v_fma_mix{lo,hi}_f16 for the
+    # fp16 hi / lo parts element by element, differently in the two kernels (tools/cvt_tie_test: how each of them rounds); the (hi, lo)
+    # pairs still represent the same value to 2^-22, and ~0.5 % of the conv outputs move by one fp32 ulp.  Gate: two orders of
+    # magnitude inside the 1e-4 of the path, and the generating kernel is bit-identical to ITSELF across batches (below).
+    assert e1 < 1e-6 and e5 < 1e-6 and d1 < 1e-5 and d5 < 1e-5, (d1, d5, e1, e5)
+    assert torch.equal(gen(x5[1:3].contiguous(), z5[1:3].contiguous()), out5[1:3])      # rows of a batch == the shard's own run
+    assert gen.native().status() == 0
+    # the producer waves publish the same range information as the writer: an operand tensor below the format's floor raises bit 1
+    sd = T(synth.decoder_state_dict(**meta["synth"]))
+    for key in ("g_4.norm_1.linear.weight", "g_4.norm_1.linear.bias"):
+        sd[key] = sd[key] * 2.0 ** -20
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("I2V_DEC_GEN", flag)
+        gu = Generator({"channel_factor": meta["synth"]["channel_factor"], "z_dim": 64, "upsample_s": meta["upsample_s"],
+                        "upsample_t": meta["upsample_t"], "spectral_norm": True, "mma": 1})
+        gu.load_state_dict(sd)
+        gu = gu.cuda().eval()
+        outs[flag] = gu(img, z)
+        assert gu.native().status(reset=True) == 2, flag
+    assert rel_l2(outs["1"].cpu(), outs["0"].cpu()) < 1e-3   # (an operand tensor at 2^-20 is below the format's floor in BOTH paths)
+
+
 def test_f43_tile_width_switch_across_batches():
     """The F(4,3) launcher narrows its workgroups to 32 channels when 64-channel ones would leave CUs idle -- a decision that
     depends on batch x bricks (round-4 advisor finding: only tested through I2V_W4_BN at one batch).  nf = 8 BAIR: g_1's convs have 4

@@ -401,6 +401,45 @@ def test_f43_kernel_keeps_its_hand_counted_waits_valid(tmp_path, measure):
     assert caw.check_scalar_operands(text, "conv_wino4_f16x3_kernel") == []
 
 
+def test_generating_f43_kernel_static_checks(tmp_path):
+    """csrc/i2v_conv16w4g.hip (round 6): the 12-wave workgroup whose four producer waves generate the operand.  Its MFMA role is the
+    tap loop of the 512-thread 32-channel kernel WITHOUT V requests: both compiled loops must hold exactly the weight loads (no LDS-DMA),
+    the hand-counted waits must replay clean and tight, the kernel must fit 768 threads (<= 168 VGPRs, no scratch), and the producer
+    role must not contain packed fp32 arithmetic (-fno-slp-vectorize: MI355X_MICROARCH.md prices v_pk_* above the scalar pair next to
+    MFMAs)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(PKG, "csrc", "i2v_conv16w4g.hip")
+    asm = tmp_path / "w4g.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-I" + os.path.join(PKG, "csrc"), "-S",
+                    "--cuda-device-only", src, "-o", str(asm)], check=True, capture_output=True, timeout=900)
+    text = asm.read_text()
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_asm_waits as caw
+    kernels = re.findall(r"^(_ZN3i2v24conv_wino4g_f16x3_kernelILi9ELi(\d+)ELb([01])EEEvNS_6W4ArgsENS_9W4GenArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+                         flags=re.S | re.M)
+    assert sorted((k[1], k[2]) for k in kernels) == [("32", "0"), ("32", "1"), ("64", "0"), ("64", "1")], [k[0] for k in kernels]
+    for name, cin, spade, whole in kernels:
+        assert "scratch_" not in whole and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", whole), name
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", whole).group(1)) <= 168, name      # 12 waves per CU = 3 per SIMD
+        assert not re.search(r"\bv_pk_(fma|mul|add)_f32", whole), name
+        loops = [mm.group(2) for mm in re.finditer(r"^(\.LBB\d+_\d+):[^\n]*\n((?:(?!^\.LBB).)*?)s_cbranch_\w+ \1\n", whole, flags=re.S | re.M)
+                 if "v_mfma" in mm.group(2)]
+        assert len(loops) == 2, (name, len(loops))
+        for loop, wm in zip(loops, (2, 1)):
+            assert loop.count("v_mfma_f32_32x32x16_f16") == 18 * 3 * wm, name
+            assert loop.count("global_load_lds_dwordx4") == 0 and not re.findall(r"buffer_load_dwordx4 [^\n]* lds", loop), name
+            assert len(re.findall(r"global_load_dwordx4", loop)) == 18 * 2 and loop.count("s_barrier") == 2, name
+            assert caw.check_loop(loop) == [], name
+            b_wait = max(waits_of(loop))
+            mutated = re.sub(r"s_waitcnt vmcnt\(%d\)" % b_wait, "s_waitcnt vmcnt(%d)" % (b_wait + 1), loop)
+            assert caw.check_loop(mutated) != [], (name, b_wait)
+    assert caw.check_loop_entries(text, "conv_wino4g_f16x3_kernel") == []
+    assert caw.check_scalar_operands(text, "conv_wino4g_f16x3_kernel") == []
+
+
 def test_f43_virtual_workgroup_map_is_a_bijection(tmp_path):
     """The F(4,3) kernel turns a (virtual) workgroup index into (sample, brick, channel tile, frame parity) -- per XCD, in one of
     three orders, also when the persistent variants loop over it.  A wrong map would skip or double bricks silently for the

@@ -13,23 +13,23 @@ CS=image2video-synthesis-using-cinns_amd/csrc
 mkdir -p tools/_tl
 make -C $CS -j4 measure
 if [ "$1" != "conv" ]; then
-  ALL="$CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_wino32.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip"
+  ALL="$CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_wino32.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_conv16w4g.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip"
   # the shipped library WITHOUT kernarg preload (A/B of that flag: FLOWTIME_LIB=tools/_tl/libi2v_hip_nopreload.so python tools/flowtime.py)
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -shared -I$CS -Iinclude $ALL -o tools/_tl/libi2v_hip_nopreload.so &
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DFLOW_TIMELINE -mllvm -amdgpu-kernarg-preload-count=16 -Wno-unused-function -shared -I$CS -Iinclude \
     $CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_wino32.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip \
-    $CS/i2v_conv16w4.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip -o tools/_tl/libi2v_hip_flowtl.so &
+    $CS/i2v_conv16w4.hip $CS/i2v_conv16w4g.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip -o tools/_tl/libi2v_hip_flowtl.so &
 fi
 if [ "$1" = "nt" ]; then
   # cache-policy experiments: V stream non-temporal / output stores non-temporal / operand writer non-temporal
-  ALL="$CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_wino32.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip"
+  ALL="$CS/i2v_common.hip $CS/i2v_flow.hip $CS/i2v_flow_tile.hip $CS/i2v_conv.hip $CS/i2v_wino32.hip $CS/i2v_pointwise.hip $CS/i2v_conv16.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_conv16w4g.hip $CS/i2v_convimg.hip $CS/i2v_dec.hip $CS/i2v_embed.hip $CS/i2v_encoder.hip $CS/i2v_ops.hip"
   for v in "vnt:-DW4_V_NT" "outnt:-DW4_OUT_NT" "modnt:-DMOD_NT" "allnt:-DW4_V_NT -DW4_OUT_NT -DMOD_NT"; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 ${v#*:} -mllvm -amdgpu-kernarg-preload-count=16 -Wno-unused-function -shared -I$CS -Iinclude $ALL -o tools/_tl/libi2v_hip_${v%%:*}.so &
   done
   wait; ls -la tools/_tl; exit 0
 fi
 if [ "$1" != "flow" ]; then
-  SRC="tools/conv16w_check.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_conv16.hip $CS/i2v_common.hip"
+  SRC="tools/conv16w_check.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_conv16w4g.hip $CS/i2v_conv16.hip $CS/i2v_common.hip"
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -I$CS -Iinclude $SRC -o tools/conv16w_check &
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -DW4_TIMELINE -I$CS -Iinclude $SRC -o tools/conv16w_check_tl &
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -DW4_TAPTIME -I$CS -Iinclude $SRC -o tools/conv16w_check_tt &

@@ -292,6 +292,22 @@ int main(int argc, char** argv) {
         double mxd = 0;
         for (size_t i = 0; i < h3.size(); ++i)
             if (memcmp(&h3[i], &h2[i], 4)) { if (!ndiff) first = i; ++ndiff; mxd = std::max(mxd, std::fabs((double)h3[i] - h2[i])); }
+        if (ndiff) {   // where do the differing outputs sit?  (brick = 4 frames x 8 rows x 16 columns; channel quads of the producer lanes)
+            long hw[16] = {}, hh[8] = {}, ht[4] = {}, hc[32] = {};
+            for (size_t i = 0; i < h3.size(); ++i)
+                if (memcmp(&h3[i], &h2[i], 4)) {
+                    const int c = (int)(i % Cout); size_t p_ = i / Cout;
+                    const int w_ = (int)(p_ % W); p_ /= W;
+                    const int h_ = (int)(p_ % H); p_ /= H;
+                    const int t_ = (int)(p_ % T);
+                    ++hw[w_ % 16]; ++hh[h_ % 8]; ++ht[t_ % 4]; ++hc[c % 32];
+                }
+            printf("      differing outputs by w %% 16:"); for (long v : hw) printf(" %ld", v);
+            printf("\n      by h %% 8:"); for (long v : hh) printf(" %ld", v);
+            printf("\n      by t %% 4:"); for (long v : ht) printf(" %ld", v);
+            printf("\n      by output channel:"); for (long v : hc) printf(" %ld", v);
+            printf("\n");
+        }
         double smx3 = 0;
         if (!nostats) for (size_t i = 0; i < hs3.size(); ++i) smx3 = std::max(smx3, std::fabs(hs3[i] - hs2[i]) / (std::fabs(hs2[i]) + 1.0));
         float amax = 0.f;
