@@ -87,6 +87,13 @@ class Model(torch.nn.Module):
         import i2v_pipeline
         if self._prefetch is None or self._prefetch.stream.device != x_0.device:
             self._prefetch = i2v_pipeline.LatentPrefetcher(lambda a, b, c, d: self.sample_latent(a, b, c, d), device=x_0.device)
+            # A rank of a multi-GPU job (torch.distributed up, world > 1) also runs a collation stream and RCCL's: the decoder's side
+            # work then shares the cINN stream instead of a stream of its own -- HIP multiplexes streams onto four hardware queues,
+            # and with a fourth side stream the own-stream form measured +7 % (B = 64) / +46 % (B = 8) per step
+            # (profiles/r06_c_stream_configurations.txt).  One GPU: the handle's own stream (the faster form there).
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            self.decoder.share_side_stream(self._prefetch.stream if multi else None)
         x_0 = x_0.contiguous()
         ticket = self._prefetch.submit(x_0, cond, residual, embed)
         self.decoder.prepare(x_0)

@@ -29,10 +29,26 @@ if [ "$1" = "nt" ]; then
   wait; ls -la tools/_tl; exit 0
 fi
 if [ "$1" != "flow" ]; then
-  SRC="tools/conv16w_check.hip $CS/i2v_conv16w.hip $CS/i2v_conv16w4.hip $CS/i2v_conv16w4g.hip $CS/i2v_conv16.hip $CS/i2v_common.hip"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -I$CS -Iinclude $SRC -o tools/conv16w_check &
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -DW4_TIMELINE -I$CS -Iinclude $SRC -o tools/conv16w_check_tl &
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DI2V_MEASURE -DW4_TAPTIME -I$CS -Iinclude $SRC -o tools/conv16w_check_tt &
+  # tools/conv16w_check*: the check tool linked against the library's own objects (csrc/build: `make` + `make measure`), so that every
+  # translation unit keeps its flags (i2v_conv16w4g.o: -fno-slp-vectorize); only the F(4,3) unit is recompiled for the instrumented variants
+  make -C $CS -j4
+  B=$CS/build
+  HC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DI2V_MEASURE -I$CS -Iinclude"
+  $HC -c tools/conv16w_check.hip -o tools/_tl/conv16w_check.o &
+  $HC -DW4_TIMELINE -c tools/conv16w_check.hip -o tools/_tl/conv16w_check_tl.o &
+  $HC -DW4_TAPTIME -c tools/conv16w_check.hip -o tools/_tl/conv16w_check_tt.o &
+  $HC -DW4_TIMELINE -c $CS/i2v_conv16w4.hip -o tools/_tl/i2v_conv16w4_tl.o &
+  $HC -DW4_TAPTIME -c $CS/i2v_conv16w4.hip -o tools/_tl/i2v_conv16w4_tt.o &
+  # ablations of the operand-generating kernel's producer role (results wrong, timing only): 1 nothing generated, 2 no global loads,
+  # 3 no LDS stores, 4 loads only
+  for v in 1 2 3 4; do $HC -fno-slp-vectorize -DW4G_ABLATE=$v -c $CS/i2v_conv16w4g.hip -o tools/_tl/i2v_conv16w4g_abl$v.o & done
+  wait
+  REST="$B/i2v_conv16w.o $B/i2v_conv16.o $B/i2v_common.o"
+  L="/opt/rocm/bin/hipcc --offload-arch=gfx950"
+  $L tools/_tl/conv16w_check.o $B/i2v_conv16w4.m.o $B/i2v_conv16w4g.o $REST -o tools/conv16w_check &
+  $L tools/_tl/conv16w_check_tl.o tools/_tl/i2v_conv16w4_tl.o $B/i2v_conv16w4g.o $REST -o tools/conv16w_check_tl &
+  $L tools/_tl/conv16w_check_tt.o tools/_tl/i2v_conv16w4_tt.o $B/i2v_conv16w4g.o $REST -o tools/conv16w_check_tt &
+  for v in 1 2 3 4; do $L tools/_tl/conv16w_check.o $B/i2v_conv16w4.m.o tools/_tl/i2v_conv16w4g_abl$v.o $REST -o tools/conv16w_check_abg$v & done
 fi
 wait
 ls -la tools/_tl tools/conv16w_check*
