@@ -157,9 +157,15 @@ static int launch_wino4_thin(W4Args& a, unsigned nblk, hipStream_t st) {
 // the brick -> XCD order (I2V_W4_ORDER) and the launch trace (I2V_W4_TRACE) -- exist in the measurement build only
 // (tools/build_measurement_libs.sh measure -> tools/_tl/libi2v_hip_measure.so, loaded through I2V_LIB_PATH; tools/conv16w_check*
 // are built with the flag too), where they are read per launch so that tests and A/B runs can flip them inside one process.
-struct W4Switches { int pipe, bn, order, nth, skew, trace; };
+// 32-channel 3x3x3 layers with the V requests issued by four extra waves (i2v_conv16w4g.hip, MODE 2; I2V_W4_LOADER=1 in the measurement
+// build).  Measured neutral to negative (profiles/r06_e_thin_loader_ab.txt: 32 -> 32 0.380 vs 0.384 ms, 64 -> 32 0.561 vs 0.545 ms at B = 8;
+// 1.33 vs 1.31-1.33 and 2.05 vs 1.93-1.97 ms at B = 32): what the thin layers' tap loops gain without ANY operand traffic (-21 % / -34 %) is
+// not the issue cost of the requests but the traffic itself -- 92 KB of V per chunk into an LDS that the operand reads already keep
+// 65 % busy.  Off.
+constexpr int W4_DEFAULT_LOADER = 0;
+struct W4Switches { int pipe, bn, order, nth, skew, trace, loader; };
 static W4Switches w4_switches() {
-    W4Switches w{W4_DEFAULT_PIPE, 0, W4_DEFAULT_ORDER, 0, 0, 0};
+    W4Switches w{W4_DEFAULT_PIPE, 0, W4_DEFAULT_ORDER, 0, 0, 0, W4_DEFAULT_LOADER};
 #ifdef I2V_MEASURE
     if (const char* e = getenv("I2V_W4_PIPE")) w.pipe = atoi(e);
     if (const char* e = getenv("I2V_W4_BN")) w.bn = atoi(e);
@@ -167,6 +173,7 @@ static W4Switches w4_switches() {
     if (const char* e = getenv("I2V_W4_NTH")) w.nth = atoi(e);
     if (const char* e = getenv("I2V_W4_SKEW")) w.skew = atoi(e);
     w.trace = getenv("I2V_W4_TRACE") != nullptr;
+    if (const char* e = getenv("I2V_W4_LOADER")) w.loader = atoi(e);
 #endif
     return w;
 }
@@ -232,6 +239,17 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
     // 32-channel layers: two 256-thread workgroups of 64 tiles per CU instead of one 512-thread workgroup of 128 (W4Geo; same
     // bits: neither the brick shape nor the workgroup size enters the accumulation order of an output).  I2V_W4_NTH=512 restores
     // round 4's geometry for A/B runs.
+    // 32-channel 3x3x3 layers whose map tiles into the 512-thread brick: the loader form (12 waves: the tap loops issue no V request)
+    if (sw.loader && BN == 32 && a.CoutPad == 32 && wts.KT == 3 && !wts.tdup && sw.pipe == 0 && env_nth == 0 && TT == 4 && TH == 8) {
+        a.TT = TT; a.TH = TH; a.TJ = 4; a.nbT = T / TT; a.nbH = H / TH; a.nbJ = a.J / 4;
+        a.th_shift = 3;
+        a.hh_magic = ((1 << 20) + TH + 1) / (TH + 2);
+        a.order = env_order;
+        const long nb = (long)B * a.nbT * a.nbH * a.nbJ;
+        if (wino4_loader_supported(a, wts.KT) && nb > 0 && nb < (1L << 30) && (long)T * a.nchunk * 6 * H * a.J * 64 < (1L << 31) &&
+            (long)B * T * H * W < (1L << 31) && (!stats || (long)TT * TH * 4 <= (long)T * H * a.J))
+            return wino4_loader_launch(a, (unsigned)nb, st);
+    }
     bool thin = false;
     {
         int TT2 = 1, TH2 = 1;

@@ -240,8 +240,16 @@ __device__ __forceinline__ void w4g_chunk(const W4GenLane<SPADE>& L, const char*
     w4g_frame<CIN, SPADE, PASS>(L, 3, ca, cb, gc, inb, vbuf, vmaxd, vmaxv);
 }
 
-template <int NT, int CIN, bool SPADE>
+// MODE 0 / 1: the producer waves GENERATE the operand (ADAIN / SPADE form, above).  MODE 2 (LOADER): the operand is the V tensor
+// modulate_wino4_kernel wrote, as for conv_wino4_f16x3_kernel, but it is REQUESTED by the four extra waves: the ablation of the
+// generating kernel showed that the thin layers' tap loops run 21 % / 34 % faster when they issue no V request themselves (an LDS-DMA
+// piece costs an MFMA wave 100-185 cycles of issue inside a phase that already carries its operand reads, MI355X_MICROARCH.md; a
+// 32-channel wave has half the MFMAs per chunk of a 64-channel one to hide the same eight pieces under).  The loader waves do
+// nothing else: 16 (pass A) / 8 (pass B) buffer_load ... lds per chunk from per-lane row offsets computed once per brick, one
+// s_waitcnt, the chunk barrier.  Same V, same tap loops, same bits as the kernels of i2v_conv16w4.hip.
+template <int NT, int CIN, int MODE>
 __global__ __launch_bounds__(W4G_THREADS, 1) void conv_wino4g_f16x3_kernel(W4Args a, W4GenArgs g) {
+    constexpr bool SPADE = MODE == 1, LOADER = MODE == 2;
     static_assert(NT == 9, "the generating kernel exists for the 3x3x3 convs of the last level (no temporal up-sampling in front)");
     using Geo = W4Geo<512>;
     constexpr int NTH = 512, WMA = 2, WMB = 1, KT = NT / 3, NW = 8;
@@ -259,8 +267,72 @@ __global__ __launch_bounds__(W4G_THREADS, 1) void conv_wino4g_f16x3_kernel(W4Arg
     (void)w4_tlv_;
 
     if (wave >= NW) {
-        // ------------------------------------------------------------------------------------------------ producer role
         const int ptid = tid - NTH;
+        if constexpr (LOADER) {
+            // -------------------------------------------------------------------------------------------- loader role
+            const int pw = wave - NW;                         // loader wave 0..3: rows [16 pw, 16 pw + 16) of every 64-row instruction group
+            const int lrow = ptid >> 2;
+            const unsigned vpiece = (unsigned)(((ptid & 3) ^ ((ptid >> 4) & 3)) * 16);   // 16-byte piece of the row (XOR swizzle: w4_pass)
+            auto rowoff = [&](int r, int nplanes, int plane0) -> unsigned {   // byte offset of staged row r inside the sample's V (chunk 0)
+                const int x = (r >= plane) + (r >= 2 * plane) + (r >= 3 * plane) + (r >= 4 * plane);
+                int q = r - x * plane;
+                const int ij = q & 3; q >>= 2;
+                const int it = (int)(((unsigned)q * (unsigned)a.hh_magic) >> 20);   // q / HH
+                const int ih = q - it * HH;
+                const int t = bk.t0 + it - 1, h = bk.h0 + ih - 1, j = bk.j0 + ij;
+                const bool ok = x < nplanes && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H;
+                const int row = ((t * a.nchunk * 6 + plane0 + x) * a.H + h) * a.J + j;
+                return (ok ? (unsigned)row << 6 : 0x80000000u) | vpiece;            // (out of range -> the load writes zeros: W4_PAD_ROW)
+            };
+            unsigned offA[16], offB[8];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) offA[u] = rowoff(u * 64 + lrow, 4, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) offB[u] = rowoff(u * 64 + lrow, 2, 4);
+            const long vsample = (long)a.T * a.nchunk * 6 * a.H * a.J * 64;
+            const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.in) + (long)bk.b0 * vsample, 0, (int)vsample, 0x00020000);
+            const unsigned vchunk = (unsigned)__builtin_amdgcn_readfirstlane((int)(6u * (unsigned)a.H * (unsigned)a.J * 64u));
+            const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+            const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)pw * 1024u));
+#define W4L_LOAD(off_, soff_, dst_)                                                                                  \
+    {                                                                                                                \
+        unsigned keep_;                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(off_), "s"(vr), "s"(dst_), "s"(soff_) : "memory");                          \
+    }
+            auto request = [&](bool passB, int ch, int rbuf) {   // one chunk's brick into the buffer that starts at LDS row rbuf
+                const unsigned so = (unsigned)ch * vchunk, db = dst0 + (unsigned)rbuf * 64u;
+                if (!passB) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) W4L_LOAD(offA[u], so, db + (unsigned)(u * 4096))
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) W4L_LOAD(offB[u], so, db + (unsigned)(u * 4096))
+                }
+            };
+            auto landed = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+            request(false, 0, rA0);
+            landed();
+            __syncthreads();
+            for (int c = 0; c < a.nchunk; ++c) {
+                if (c + 1 < a.nchunk) request(false, c + 1, ((c + 1) & 1) ? rA1 : rA0);
+                else request(true, 0, rB0);
+                landed();
+                __syncthreads();
+            }
+            __syncthreads();
+            for (int c = 0; c < a.nchunk; ++c) {
+                if (c + 1 < a.nchunk) request(true, c + 1, ((c + 1) & 1) ? rB1 : rB0);
+                landed();
+                __syncthreads();
+            }
+#undef W4L_LOAD
+            __syncthreads();
+            __syncthreads();
+            if (a.stats) __syncthreads();
+            return;
+        }
+        // ------------------------------------------------------------------------------------------------ producer role
         W4GenLane<SPADE> L;
         w4g_lane_init<CIN, SPADE>(a, bk, ptid, L);
         // the sample's tensors (uniform bases; the lane's byte offsets are 32-bit): input, (A, B) pairs of the lane's quad, SPADE maps
@@ -499,9 +571,28 @@ int wino4g_forward(const Wino4Weights& wts, const float* x, const float* coef, c
         return I2V_OK;
     };
     int rcl;
-    if (gb) rcl = wts.Cin == 64 ? launch(conv_wino4g_f16x3_kernel<9, 64, true>, attr_set[0]) : launch(conv_wino4g_f16x3_kernel<9, 32, true>, attr_set[1]);
-    else rcl = wts.Cin == 64 ? launch(conv_wino4g_f16x3_kernel<9, 64, false>, attr_set[2]) : launch(conv_wino4g_f16x3_kernel<9, 32, false>, attr_set[3]);
+    if (gb) rcl = wts.Cin == 64 ? launch(conv_wino4g_f16x3_kernel<9, 64, 1>, attr_set[0]) : launch(conv_wino4g_f16x3_kernel<9, 32, 1>, attr_set[1]);
+    else rcl = wts.Cin == 64 ? launch(conv_wino4g_f16x3_kernel<9, 64, 0>, attr_set[2]) : launch(conv_wino4g_f16x3_kernel<9, 32, 0>, attr_set[3]);
     if (rcl) return rcl;
+    I2V_HIP_CHECK(hipGetLastError());
+    return I2V_OK;
+}
+
+// The LOADER form for the kernels of i2v_conv16w4.hip: `a` as wino4_forward fills it for the 512-thread geometry of a 32-channel 3x3x3
+// layer (TT = 4, TH = 8, no temporal duplication); same V, same bits.
+bool wino4_loader_supported(const W4Args& a, int KT) {
+    return KT == 3 && !a.tdup && a.CoutPad == 32 && a.TT == W4G_TT && a.TH == W4G_TH && a.th_shift == 3;
+}
+
+int wino4_loader_launch(W4Args& a, unsigned nblk, hipStream_t st) {
+    a.nvirt = (int)nblk;
+    a.tofs = 2 * W4_ROWS_A * 64;
+    const size_t lds = (size_t)a.tofs + 5 * W4Geo<512>::TILES * 4;
+    auto kern = conv_wino4g_f16x3_kernel<9, 32, 2>;
+    static bool attr_set[I2V_MAX_DEV] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
+    W4GenArgs g{};
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(W4G_THREADS), lds, st, a, g);
     I2V_HIP_CHECK(hipGetLastError());
     return I2V_OK;
 }

@@ -35,7 +35,7 @@ if not torch.equal(gen()(x0, z), ref):      # the measurement build at its defau
     bad.append(["defaults", ""])
 SWITCHES = (("I2V_W4_PIPE", "1"), ("I2V_W4_PIPE", "2"), ("I2V_W4_ORDER", "0"), ("I2V_W4_ORDER", "1"), ("I2V_W4_BN", "32"),
             ("I2V_W4_NTH", "512"), ("I2V_W4_NTH", "256"), ("I2V_CONVIMG_TCH", "1"), ("I2V_CONVIMG_TCH", "2"), ("I2V_CONVIMG_TCH", "16"),
-            ("I2V_W4_SKEW", "1"))
+            ("I2V_W4_SKEW", "1"), ("I2V_W4_LOADER", "1"))
 for env, val in SWITCHES:
     os.environ[env] = val
     if env == "I2V_W4_SKEW":

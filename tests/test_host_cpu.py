@@ -38,7 +38,7 @@ def test_production_library_has_no_launch_path_environment_switches():
     if not os.path.exists(i2v_native.LIB_PATH):
         i2v_native.build()
     blob = open(i2v_native.LIB_PATH, "rb").read()
-    for name in (b"I2V_W4_PIPE", b"I2V_W4_BN", b"I2V_W4_ORDER", b"I2V_W4_NTH", b"I2V_W4_SKEW", b"I2V_W4_TRACE", b"I2V_CONVIMG_TCH"):
+    for name in (b"I2V_W4_PIPE", b"I2V_W4_BN", b"I2V_W4_ORDER", b"I2V_W4_NTH", b"I2V_W4_SKEW", b"I2V_W4_TRACE", b"I2V_W4_LOADER", b"I2V_CONVIMG_TCH"):
         assert name not in blob, name
     assert b"conv_wino4_f16x3_kernelILi9ELi64ELi0ELi512E" in blob
     for pipe in (1, 2):
@@ -418,9 +418,10 @@ def test_generating_f43_kernel_static_checks(tmp_path):
     text = asm.read_text()
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import check_asm_waits as caw
-    kernels = re.findall(r"^(_ZN3i2v24conv_wino4g_f16x3_kernelILi9ELi(\d+)ELb([01])EEEvNS_6W4ArgsENS_9W4GenArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+    kernels = re.findall(r"^(_ZN3i2v24conv_wino4g_f16x3_kernelILi9ELi(\d+)ELi([012])EEEvNS_6W4ArgsENS_9W4GenArgsE):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
                          flags=re.S | re.M)
-    assert sorted((k[1], k[2]) for k in kernels) == [("32", "0"), ("32", "1"), ("64", "0"), ("64", "1")], [k[0] for k in kernels]
+    # (channels, mode): 0 / 1 generate the operand (ADAIN / SPADE form), 2 = the LOADER form (four extra waves issue the V requests)
+    assert sorted((k[1], k[2]) for k in kernels) == [("32", "0"), ("32", "1"), ("32", "2"), ("64", "0"), ("64", "1")], [k[0] for k in kernels]
     for name, cin, spade, whole in kernels:
         assert "scratch_" not in whole and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", whole), name
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", whole).group(1)) <= 168, name      # 12 waves per CU = 3 per SIMD
@@ -430,12 +431,15 @@ def test_generating_f43_kernel_static_checks(tmp_path):
         assert len(loops) == 2, (name, len(loops))
         for loop, wm in zip(loops, (2, 1)):
             assert loop.count("v_mfma_f32_32x32x16_f16") == 18 * 3 * wm, name
-            assert loop.count("global_load_lds_dwordx4") == 0 and not re.findall(r"buffer_load_dwordx4 [^\n]* lds", loop), name
+            assert loop.count("global_load_lds_dwordx4") == 0 and not re.findall(r"buffer_load_dwordx4 [^\n]* lds", loop), name   # (no V request in a tap loop)
             assert len(re.findall(r"global_load_dwordx4", loop)) == 18 * 2 and loop.count("s_barrier") == 2, name
             assert caw.check_loop(loop) == [], name
             b_wait = max(waits_of(loop))
             mutated = re.sub(r"s_waitcnt vmcnt\(%d\)" % b_wait, "s_waitcnt vmcnt(%d)" % (b_wait + 1), loop)
             assert caw.check_loop(mutated) != [], (name, b_wait)
+        if spade == "2":   # the loader role: 16 + 8 LDS-DMA requests per chunk, each behind its own m0, all waited for before the barrier
+            dma = re.findall(r"buffer_load_dwordx4 [^\n]* lds", whole)
+            assert len(dma) >= 24 and whole.count("s_waitcnt vmcnt(0)") >= 4, (name, len(dma))
     assert caw.check_loop_entries(text, "conv_wino4g_f16x3_kernel") == []
     assert caw.check_scalar_operands(text, "conv_wino4g_f16x3_kernel") == []
 
