@@ -347,7 +347,7 @@ def main():
                                 {"single_call": {"ms": single_ms}, "ms_per_step": dt / args.steps * 1e3}, prefetch)
     # the un-emulated number: the same step on the exact-fp32 MFMA kernels (mma = 0), N = 1 only
     exact = None
-    if not args.no_extras and world == 1 and gen.mma == 1 and not args.no_exact:
+    if not args.no_extras and world == 1 and gen.mma != 0 and not args.no_exact:
         gen0 = Generator({"channel_factor": cfg["nf"], "z_dim": 64, "upsample_s": cfg["ups"], "upsample_t": cfg["upt"],
                           "spectral_norm": True, "mma": 0})
         gen0.load_state_dict(dsd)
@@ -401,7 +401,8 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32" if gen.mma == 0 else "f32 (split-fp16 MFMA: fp16 hi/lo operand pairs, 3 MFMAs per product, fp32 accumulate)",
+            "dtype": "f32" if gen.mma == 0 else "f32 (split-fp16 MFMA: fp16 hi/lo operand pairs, 3 MFMAs per product, fp32 accumulate)" +
+                     ("; auto mode: per-layer fallback to exact fp32 behind the range guard, switched so far: %s" % gen.native().fallback_layers() if gen.mma == 2 else ""),
             "data": "synthetic (seeded start frames / latents / embeddings, deterministic synthetic weights)",
             "config": {"workload": f"{cfg['name']}, batch {nb}/GPU (global {total}), vid_length {vid_length}: "
                                    "20-block cINN inverse + decoder pass(es)" + (" + RCCL all-gather (overlapped)" if world > 1 else ""),
@@ -444,9 +445,9 @@ def main():
                 **cinn_latency_floor(flow, nb, cinn["inv_us"]),
                 "measured_hbm_bytes_per_pass": measured, "measured_hbm_bytes_source": msrc,
             }
-        if gen.mma == 1 and result.get("roofline") and not args.no_extras and world == 1 and not args.lean:
+        if gen.mma != 0 and result.get("roofline") and not args.no_extras and world == 1 and not args.lean:
             result["roofline"]["undisturbed"] = undisturbed_roofline(cfg, dsd, dev, x0_d, last_z["z"], vid_length, result["roofline"])
-        if gen.mma == 1 and result.get("roofline") and not args.no_extras and not args.lean:
+        if gen.mma != 0 and result.get("roofline") and not args.no_extras and not args.lean:
             # the data-sheet peak assumes 2.4 GHz; with live operands the matrix cores sustain less (power management).
             # An MFMA-only loop of the conv kernel's shape, measured here on this box, gives the sustained rate.
             sustained = i2v_native.probe_mfma_f16(dev)
@@ -478,7 +479,7 @@ def main():
             live_traffic(result, args)
         if args.per_layer:
             write_per_layer(args.per_layer, layers, args.steps, gen.mma)
-        validate_line(result, full=world == 1 and gen.mma == 1 and not (args.no_extras or args.no_cpu_baseline or args.no_exact or args.sustain < 10))
+        validate_line(result, full=world == 1 and gen.mma != 0 and not (args.no_extras or args.no_cpu_baseline or args.no_exact or args.sustain < 10))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -924,7 +925,7 @@ def roofline(prof, dt, mma, default_workload=False, layers=None, steps=1):
     taps: what the matrix cores actually issue is mfma_issue_frac.  `roofline_all_conv3`: the same over all 3x3x3 launches."""
     if prof["conv3_ms"] <= 0 or not layers:
         return {"roofline": None, "roofline_all_conv3": None}
-    peak = PEAK_F16_MFMA_TFLOPS if mma == 1 else PEAK_FP32_MFMA_TFLOPS
+    peak = PEAK_F16_MFMA_TFLOPS if mma != 0 else PEAK_FP32_MFMA_TFLOPS   # (mma 2 = auto runs the split-fp16 kernels unless the range guard switched a layer)
     by_kernel = {}
     for L in layers:
         k = by_kernel.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "mfma_flops": 0.0, "launches": 0, "layers": []})
@@ -936,7 +937,7 @@ def roofline(prof, dt, mma, default_workload=False, layers=None, steps=1):
     # rocprofv3 --pmc passes and corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot read PMCs itself: STATIC
     # figure from the newest committed summary (tools/pmc_hbm_traffic.py), valid for the default workload only.
     traffic, tsrc = None, None
-    if mma == 1 and default_workload:
+    if mma != 0 and default_workload:
         path = _latest_traffic_file()
         try:
             with open(path) as f:
@@ -971,7 +972,7 @@ def write_per_layer(path, layers, steps, mma):
     with open(path, "w") as f:
         f.write("layer,kernel,launches_per_step,ms_per_launch,algorithmic_gflop_per_launch,tflops_algorithmic,tflops_mfma_issued,"
                 "frac_of_peak_algorithmic\n")
-        peak = PEAK_F16_MFMA_TFLOPS if mma == 1 else PEAK_FP32_MFMA_TFLOPS
+        peak = PEAK_F16_MFMA_TFLOPS if mma != 0 else PEAK_FP32_MFMA_TFLOPS
         for L in layers:
             ms = L["ms"] / L["launches"]
             ta = L["flops"] / (L["ms"] * 1e-3) / 1e12

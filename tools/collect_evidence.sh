@@ -22,11 +22,13 @@ I2V_DEC_OVERLAP=0 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-bas
 I2V_DEC_OVERLAP=0 timeout 300 python bench.py --config land128 --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_land128_overlap0.json
 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact --small-batch 0 2>/dev/null | tail -1 > $out/bench_bair64_overlap1.json
 timeout 300 python bench.py --config land128 --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_land128_overlap1.json
-# same box, the library built from the sources one commit before the buffer-descriptor V requests (tools/_tl/libi2v_hip_prebuf.so, if present)
-if [ -f tools/_tl/libi2v_hip_prebuf.so ]; then
-  I2V_LIB_PATH=tools/_tl/libi2v_hip_prebuf.so timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact --small-batch 0 2>/dev/null | tail -1 > $out/bench_bair64_prebuf.json
-  I2V_LIB_PATH=tools/_tl/libi2v_hip_prebuf.so timeout 300 python bench.py --config land128 --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --sustain 0 --no-exact 2>/dev/null | tail -1 > $out/bench_land128_prebuf.json
-fi
+# round 6: the decoder in auto mode (per-layer fallback behind the range guard: a stream synchronisation per forward), and the stream
+# configuration of an N > 1 rank emulated on this GPU (one shared side stream + the collation stream)
+I2V_DEC_MMA=auto timeout 300 python bench.py --steps 20 --warmup 3 --lean 2>/dev/null | tail -1 > $out/bench_bair64_mma_auto.json
+I2V_DEC_MMA=auto timeout 300 python bench.py --batch 8 --steps 40 --warmup 5 --lean 2>/dev/null | tail -1 > $out/bench_bair8_mma_auto.json
+timeout 300 python bench.py --batch 8 --steps 40 --warmup 5 --lean 2>/dev/null | tail -1 > $out/bench_bair8_lean.json
+timeout 300 python bench.py --steps 20 --warmup 3 --lean --emulate-collation 2>/dev/null | tail -1 > $out/bench_bair64_multi_gpu_streams.json
+timeout 300 python bench.py --batch 8 --steps 40 --warmup 5 --lean --emulate-collation 2>/dev/null | tail -1 > $out/bench_bair8_multi_gpu_streams.json
 I2V_DEC_WINO32=0 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --sustain 0 --small-batch 0 2>/dev/null | tail -1 > $out/bench_bair64_exact_direct.json
 I2V_FLOW_FOLD=0 timeout 300 python tools/flowtime.py 2>&1 | grep -v amdgpu.ids > $out/flowtime_unfolded.txt
 # cINN chain: latencies (fp32 and fp16-operand mode), per-kernel stats
