@@ -199,15 +199,15 @@ __device__ __forceinline__ void w4g_frame(const W4GenLane<SPADE>& L, int fi, con
             else if (xq == 3) v = fmaf(2.f, d[3][c] - d[1][c], d[4][c] - d[2][c]);
             else if (xq == 4) v = fmaf(2.f, d[1][c] - d[3][c], d[4][c] - d[2][c]);
             else v = fmaf(4.f, d[1][c], fmaf(-5.f, d[3][c], d[5][c]));
+            // The fp32 value goes through a register the compiler cannot see into.  Otherwise hipcc (-ffp-contract=fast) fuses the
+            // transform's last fma with the conversion into ONE v_fma_mixlo_f16: hi = fp16(4 d0 + t) rounded ONCE, where the writer
+            // (and the source) round twice, fp16(fp32(4 d0 + t)).  Both are valid splits -- lo = v - hi absorbs the difference -- but
+            // the hi parts then differ in 1 of ~10^4 values and ~0.5 % of the conv outputs move by one ulp against the writer path.
+            asm volatile("" : "+v"(v));
             vmaxv = fmaxf(vmaxv, fabsf(v));
             const _Float16 hh = (_Float16)v;
             ph[c] = hh;
-            // (the difference goes through a register the compiler cannot see into: fused into v_fma_mixlo_f16 -- one instruction for
-            //  subtract + convert -- the lo parts came out different from the writer's v_sub_f32 + v_cvt_f16_f32 in ~0.5 % of the
-            //  outputs' last bit: fp16 subnormal results, which most lo parts of values below 2^-3 are)
-            float dl = v - (float)hh;
-            asm volatile("" : "+v"(dl));
-            pl[c] = (_Float16)dl;
+            pl[c] = (_Float16)(v - (float)hh);
         }
         char* o = rp + (xq - (PASS ? 4 : 0)) * (W4G_PLANE * 64);
         if constexpr (W4G_ABLATE == 3) { asm volatile("" ::"v"(ph), "v"(pl), "v"(o)); continue; }

@@ -92,6 +92,15 @@ int main(int argc, char** argv) {
         coefh.resize((size_t)B * Cin * 2);
         for (auto& v : xraw) v = (rand() / (float)RAND_MAX - 0.5f) * 3.f;
         for (size_t i = 0; i < (size_t)B * Cin; ++i) { coefh[2 * i] = 0.5f + rand() / (float)RAND_MAX; coefh[2 * i + 1] = rand() / (float)RAND_MAX - 0.4f; }
+        // I2V_CHECK_GEN (diagnosis of the last-bit differences between the generating kernel and the writer path): 1 = identity
+        // coefficients (d = lrelu(x)), 2 = identity coefficients and x >= 0 (d = x: no modulation arithmetic at all), 3 = x small integers,
+        // identity coefficients (every V exact: hi exact, lo = 0)
+        if (const char* e = getenv("I2V_CHECK_GEN")) {
+            const int m = atoi(e);
+            if (m >= 1) for (size_t i = 0; i < (size_t)B * Cin; ++i) { coefh[2 * i] = 1.f; coefh[2 * i + 1] = 0.f; }
+            if (m == 2) for (auto& v : xraw) v = std::fabs(v);
+            if (m == 3) for (auto& v : xraw) v = (float)(rand() % 4);
+        }
         if (gen == 2) {
             gbh.resize((size_t)B * H * W * 2 * Cin);
             for (size_t i = 0; i < gbh.size(); ++i) gbh[i] = ((i / Cin) & 1) ? rand() / (float)RAND_MAX - 0.5f : 0.6f + rand() / (float)RAND_MAX;
