@@ -99,15 +99,22 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="1 (default): the cINN pass of step k+1 runs on a side stream underneath the decoder of step k "
                          "(i2v_pipeline.LatentPrefetcher; every step still has its own pass, the first one is exposed); 0: serial")
+    ap.add_argument("--collation-stream", default="auto", choices=["auto", "own", "prefetch"],
+                    help="N > 1 (or --emulate-collation): which stream the all-gather of a step is issued on -- a stream of the collator's own "
+                         "(a FOURTH stream next to main, cINN prefetch and the decoder's side stream: HIP's four hardware queues then cost the "
+                         "own-side-stream form 7 % / 46 % per step at B = 64 / 8) or the cINN prefetch stream (the gather of step k and the "
+                         "pass of step k + 2 serialise there with a step of slack; three streams).  auto = prefetch")
     ap.add_argument("--side-stream", default="auto", choices=["auto", "shared", "own"],
                     help="own: the decoder handle runs its side work (SPADE branches, learned shortcuts) on a stream of its own next to the "
                          "cINN prefetch stream (best on ONE GPU: 3 streams); shared: on the SAME stream as the cINN prefetch, so that a job "
                          "with a collation stream still has three side streams at most -- HIP multiplexes streams onto four hardware queues, "
                          "and with the collation stream as the FOURTH the `own` form loses 7 % at B = 64 and 46 % at B = 8 "
                          "(profiles/r06_c_stream_configurations.txt); auto (default): own for N = 1, shared for N > 1 / --emulate-collation")
-    ap.add_argument("--emulate-collation", action="store_true",
-                    help="N = 1 measurement: run the collation side stream with a device copy standing in for the RCCL all-gather -- the "
-                         "stream count of an N > 1 job on one GPU (what does the extra stream cost on HIP's four hardware queues?)")
+    ap.add_argument("--emulate-collation", nargs="?", const="copy", default=None, choices=["copy", "rccl"],
+                    help="N = 1 measurement: run the collation of an N > 1 rank on one GPU -- the same stream, events and double buffers; "
+                         "copy (default): a device copy stands in for the RCCL all-gather; rccl: a ONE-rank RCCL process group is brought up "
+                         "in this process and every step's all-gather goes through torch.distributed / RCCL itself (whatever streams and "
+                         "events ProcessGroupNCCL adds are then part of the measurement)")
     ap.add_argument("--lean", action="store_true",
                     help="timed steps, checksums, single_call and the per-layer roofline only (no sustained / exact-fp32 / cINN / probe / "
                          "embedder legs): what the default run's `config_128` child leg uses")
@@ -157,6 +164,10 @@ def main():
         dist.all_gather_object(rank_devices, (rank, torch.cuda.current_device(), uuid))
     else:
         rank_devices = [(0, torch.cuda.current_device(), None)]
+        if args.emulate_collation == "rccl":
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     torch.set_grad_enabled(False)
 
     if args.scaling == "weak":
@@ -180,11 +191,13 @@ def main():
     x0, residual, embed = synth.bench_inputs(total, cfg["img"], cfg["emb"])
     lo, hi = i2v_dist.shard_bounds(total, world, rank)
     x0_d, res_d, emb_d = x0[lo:hi].to(dev), residual[lo:hi].to(dev), embed[lo:hi].to(dev)
-    collator = i2v_dist.OverlappedCollator(total, emulate=args.emulate_collation and world == 1)
-
     import i2v_pipeline
     prefetch = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True), device=dev, enabled=bool(args.pipeline))
-    side_mode = args.side_stream if args.side_stream != "auto" else ("shared" if (world > 1 or args.emulate_collation) else "own")
+    coll_mode = "prefetch" if args.collation_stream == "auto" else args.collation_stream
+    coll_on_prefetch = coll_mode == "prefetch" and prefetch.enabled and (world > 1 or args.emulate_collation)
+    collator = i2v_dist.OverlappedCollator(total, emulate=args.emulate_collation if world == 1 else None, stream=prefetch.stream if coll_on_prefetch else None)
+    # the decoder's side work: its handle's own stream, unless the collation has a stream of its own too (then the fourth stream must go)
+    side_mode = args.side_stream if args.side_stream != "auto" else ("shared" if ((world > 1 or args.emulate_collation) and not coll_on_prefetch) else "own")
     shared = side_mode == "shared" and prefetch.enabled
     if shared:
         gen.share_side_stream(prefetch.stream)
@@ -216,16 +229,8 @@ def main():
         ticket = prefetch.submit(res_d, emb_d)
         for k in range(n):
             z = prefetch.get(ticket)
-            if shared:
-                # ONE side stream, in order: the SPADE branches of step k (an explicit prepare), the cINN pass of step k + 1 behind
-                # them (its inputs are complete at `ev`: it does not wait for anything of step k), then the learned shortcuts the
-                # decoder of step k enqueues as it goes -- the first of which is only needed by conv_1 of g_1
-                ev = prefetch.mark()
-                gen.prepare(x0_d)
-                if k + 1 < n:
-                    ticket = prefetch.submit(res_d, emb_d, _ready=ev)
-                decode(z)
-                continue
+            # (shared side stream: the pass of step k + 1 is enqueued FIRST, the decoder's side work of step k behind it -- the handle
+            #  runs the two tiny first SPADE levels inline then, so that the main chain does not wait for the pass: i2v_dec.hip fork_spade)
             if k + 1 < n:
                 ticket = prefetch.submit(res_d, emb_d)
             decode(z)
@@ -468,8 +473,11 @@ def main():
                              "what": ("main + ONE side stream: the cINN prefetch and the decoder handle's side work (SPADE branches, learned "
                                       "shortcuts) share it" if shared else "main + the cINN prefetch stream + the decoder handle's own side stream") +
                                      ("; + the collation stream and RCCL's" if world > 1 else ""),
-                             "dec_overlap_env": os.environ.get("I2V_DEC_OVERLAP"), "collation_stream_emulated": bool(args.emulate_collation and world == 1),
-                             "rule": "own for N = 1, shared for N > 1 (--side-stream auto); `small_batch` is measured in BOTH and projects from the N > 1 one"}
+                             "dec_overlap_env": os.environ.get("I2V_DEC_OVERLAP"), "collation_stream_emulated": (args.emulate_collation or False) if world == 1 else False,
+                             "collation_stream": ("the cINN prefetch stream" if coll_on_prefetch else "its own") if (world > 1 or args.emulate_collation) else None,
+                             "rule": "three streams at every N: main + the decoder handle's side stream + the cINN prefetch stream, which for N > 1 also "
+                                     "carries the all-gathers (--collation-stream auto); `small_batch` is measured in the one-GPU and in the N > 1 form and "
+                                     "projects from the second"}
         if small is not None:
             result["small_batch"] = small
         if world == 1 and default_workload and not args.no_extras and not args.no_config_128:
@@ -483,6 +491,7 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -635,9 +644,8 @@ def undisturbed_roofline(cfg, dsd, dev, x0_d, z, vid_length, ro):
 def small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, nb, result, pf):
     """The per-GPU share of the default job on 8 GPUs (BASELINE north_star: >= 6x at 8 GPUs for BAIR 64x64x16): the same step at
     batch `nb` on THIS GPU -- one serial call (median of 5) and the pipelined stream rate (30 steps) -- in TWO stream configurations:
-    `n1` = what a one-GPU job runs (the decoder's side work on the handle's own stream), and `multi_gpu` = what every rank of an
-    N > 1 job runs (ONE shared side stream + the collation stream, here with a device copy of the rank's block standing in for the
-    RCCL all-gather).  The strong-scaling figure is PROJECTED from the second: T(64 on one GPU) / T(nb in the N > 1 configuration),
+    `n1` = what a one-GPU job runs, and `multi_gpu` = what every rank of an N > 1 job runs (the same three streams, the all-gather of
+    every step issued on the cINN prefetch stream -- here a device copy of the rank's block standing in for the RCCL kernel).  The strong-scaling figure is PROJECTED from the second: T(64 on one GPU) / T(nb in the N > 1 configuration),
     with an explicit all-gather term.  A projection from one GPU, labelled so; no multi-GPU claim."""
     import i2v_dist
     x, r, e = x0_d[:nb].contiguous(), res_d[:nb].contiguous(), emb_d[:nb].contiguous()
@@ -662,14 +670,8 @@ def small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, nb, result, pf):
             tk = pf.submit(r, e)
             for k in range(n):
                 z = pf.get(tk)
-                if shared:   # (one side stream: branches of step k, the pass of step k + 1, then step k's shortcuts -- as run_steps does)
-                    ev = pf.mark()
-                    gen.prepare(x)
-                    if k + 1 < n:
-                        tk = pf.submit(r, e, _ready=ev)
-                else:
-                    if k + 1 < n:
-                        tk = pf.submit(r, e)
+                if k + 1 < n:
+                    tk = pf.submit(r, e)
                 seq = gen.decode_sequence(x, z.view(nb, -1), vid_length)
                 if collator is not None:
                     collator.submit(seq)
@@ -697,13 +699,13 @@ def small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, nb, result, pf):
 
     try:
         n1 = measure(False, None)
-        multi = measure(True, i2v_dist.OverlappedCollator(nb, emulate=True))
+        multi = measure(False, i2v_dist.OverlappedCollator(nb, emulate="rccl" if dist.is_initialized() else "copy", stream=pf.stream))   # the N > 1 form: gathers on the cINN stream
     finally:
         gen.share_side_stream(was_shared)
     big_single = (result.get("single_call") or {}).get("ms")
     out = {"what": f"the same step at batch {nb} = the per-GPU share of the B = 64 job on {64 // nb} GPUs, measured on this one GPU in the "
-                   "stream configuration of a one-GPU job (`n1`) and in the one every rank of an N > 1 job runs (`multi_gpu`: one shared side "
-                   "stream + the collation stream, the all-gather replaced by a device copy of the block)",
+                   "stream configuration of a one-GPU job (`n1`) and in the one every rank of an N > 1 job runs (`multi_gpu`: the same streams, "
+                   "every step's all-gather -- here a device copy of the block -- issued on the cINN prefetch stream)",
            "batch": nb, "n1": n1, "multi_gpu": multi,
            "projected_strong_scaling": projected_scaling(64 // nb, nb, frames // nb, big_single, multi["single_call_ms"], result["ms_per_step"],
                                                          multi["pipelined_ms_per_step"])}

@@ -53,6 +53,10 @@ struct Conv16Args {
     long part_stride; // floats per split slice
     int B, T, H, W, Cin, Cout, CoutPad, nchunk;  // T,H,W: geometry of the INPUT tensor
     int tdup;            // 1: temporal-duplication mode -- the output has 2T frames, two tiles (frame parities) per brick
+    int tskperm;         // TSK: 1 = the permuted wave -> row slab order (always, except in measurement A/Bs)
+    int tclip;           // 1: the brick spans the map's whole time extent and only its TT real frames are staged (no temporal halo:
+                         //    those frames are zero padding); every (row block, tap) pair that would read them is skipped -- by the
+                         //    brick-level tap list (TT == 1) or by the TSK masks, which then also gate the operand reads
     long wset_stride;    // bytes between the two parity weight sets (tdup)
     int KT, KH, KW, tap_base, ztap;  // ztap: index of the all-zero weight slab (stage padding)
     int TB, TT, TH, TW, nbB, nbT, nbH, nbW;
@@ -100,7 +104,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    // TSK: a workgroup's waves w and w + 4 share a SIMD (waves go to the SIMDs in a cyclic order), and a 64-row slab of the two-frame
+    // brick lies in ONE frame -- in the plain order the two waves of a SIMD hold the same frame, so a tap that only one frame meets
+    // leaves two SIMDs idle and the other two with both their waves busy: the stage takes as long as an unmasked one.  The permuted
+    // order gives every SIMD one wave of each frame (which rows a wave owns changes, no output's arithmetic does).
+    const int wm_idx = wave / WAVES_N;
+    const int wave_m = !(TSK && a.tskperm) ? wm_idx : WAVES_M == 4 ? ((0x2130 >> (4 * wm_idx)) & 3) : WAVES_M == 8 ? ((0x76325410 >> (4 * wm_idx)) & 7) : wm_idx;
+    const int wave_n = wave % WAVES_N;
     const int kg = lane >> 5, l31 = lane & 31;
 
     // Temporal-duplication mode (conv_0 behind a x2 nearest up-sampling in time): the virtual input satisfies
@@ -118,7 +128,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     const int tile_id = !a.tdup ? (int)blockIdx.x
                         : pair_ ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)(blockIdx.x % (nb_ >> 1));
     const int pt = a.tdup ? 1 - par : a.KT / 2, ph = a.KH / 2, pw = a.KW / 2;
-    const int HT = a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.HWp;
+    const int HT = a.tclip ? a.TT : a.TT + a.KT - 1, HH = a.TH + a.KH - 1, HW = a.HWp;
+    const int tsh = a.tclip ? 0 : pt;   // staged frame 0 = input frame t0 - tsh
     const int NPOS = a.TB * HT * HH * HW;
     const int ntaps = a.KT * a.KH * a.KW;
 
@@ -156,7 +167,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
             const int lo = t0 + dt - pt, hi = lo + a.TT - 1;
             if (hi < 0 || lo >= a.T) continue;  // the whole brick meets zero padding only
             taplist[1 + cnt] = a.tap_base + tap;
-            taplist[33 + cnt] = ((dt * HH + dh) * HW + dw) * C16_ROW | (TSK ? dt : 0);   // (C16_ROW is a multiple of 16: the low bits are free)
+            // (C16_ROW is a multiple of 16: the low bits are free -- also of a negative offset, which tclip produces for dt < pt)
+            taplist[33 + cnt] = (((dt - (pt - tsh)) * HH + dh) * HW + dw) * C16_ROW | (TSK ? dt : 0);
             ++cnt;
         }
         while (cnt % TPS) {  // pad the stage with the all-zero weight slab
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         const int iw = p % HW; p /= HW;
         const int ih = p % HH; p /= HH;
         const int it = p % HT; p /= HT;
-        const int b = b0 + p, t = t0 + it - pt, h = h0 + ih - ph, w = w0 + iw - pw;
+        const int b = b0 + p, t = t0 + it - tsh, h = h0 + ih - ph, w = w0 + iw - pw;
         const bool ok = b < a.B && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W &&
                         iw < a.TW + a.KW - 1;
         gpos[p0] = ok ? ((b * a.T + t) * a.H + h) * a.W + w : -1;
@@ -231,22 +243,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     }
     struct Ops { half8 ah[WM], al[WM], bh[WN], bl[WN]; };
     Ops o0, o1;
-#define C16_LOAD_OPS(o, aoffs, wbuf, koff)                                                                            \
-    {                                                                                                                \
-        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) {                                                          \
+    // TSK: WM-bit mask of the row blocks whose frame meets data for the tap with table value tapv_ (wave-uniform); a masked row
+    // block neither reads its A operands nor multiplies, and a wave whose row blocks are all masked skips the tap's B reads too
+    // (with tclip the masked A address would lie outside the staged frames)
+#define C16_TAPMASK(tapv_) ([&]() -> unsigned {                                                                      \
+        if constexpr (!TSK) return ~0u;                                                                              \
+        const int dt_ = __builtin_amdgcn_readfirstlane((tapv_) & 3);                                                 \
+        unsigned m_ = 0u;                                                                                            \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) m_ |= ((unsigned)(tbs[wm] + dt_) < (unsigned)a.T ? 1u : 0u) << wm; \
+        return m_; }())
+#define C16_LOAD_OPS(o, aoffs, wbuf, koff, msk_)                                                                      \
+    if (!(C16_ABL & 2)) {                                                                                            \
+        _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) if (!TSK || (((msk_) >> wm) & 1u)) {                        \
             const char* p_ = in_lds + aoff[wm] + (TSK ? ((aoffs) & ~3) : (aoffs)) + (koff);                          \
             (o).ah[wm] = *reinterpret_cast<const half8*>(p_);                                                        \
             (o).al[wm] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
         }                                                                                                            \
-        _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) {                                                          \
-            const char* p_ = (wbuf) + boff[wn] + (koff);                                                             \
-            (o).bh[wn] = *reinterpret_cast<const half8*>(p_);                                                        \
-            (o).bl[wn] = *reinterpret_cast<const half8*>(p_ + 16);                                                   \
+        if (!TSK || ((msk_) & ((1u << WM) - 1u))) {                                                                  \
+            _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) {                                                      \
+                const char* p_ = (wbuf) + boff[wn] + (koff);                                                         \
+                (o).bh[wn] = *reinterpret_cast<const half8*>(p_);                                                    \
+                (o).bl[wn] = *reinterpret_cast<const half8*>(p_ + 16);                                               \
+            }                                                                                                        \
         }                                                                                                            \
     }
     // three terms, tiles interleaved so that consecutive MFMAs never chain on the same accumulator
 #define C16_MFMA(o, tq_)                                                                                             \
-    {                                                                                                                \
+    if (!(C16_ABL & 1)) {                                                                                            \
         bool on_[WM];                                                                                                \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) on_[wm] = !TSK || ((onmask >> ((tq_) * WM + wm)) & 1u);     \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) if (on_[wm]) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) \
@@ -270,98 +293,125 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
 #pragma unroll
     for (int u = 0; u < WLD; ++u) {
         const int f = tid + u * NTHR;
-        const int tis = f / (C16_BN * 8), fr = f % (C16_BN * 8);
+        const int tis = TPS == 1 ? 0 : f / (C16_BN * 8), fr = f % (C16_BN * 8);   // (TPS == 1: a compile-time 0 keeps the slab address scalar)
         wtis[u] = tis;
         wsrc[u] = fr * 16;
         wdst[u] = tis * (C16_BN * C16_ROW) + (fr >> 3) * C16_ROW + (fr & 7) * 16;
     }
     const long wtap_stride = (long)a.nchunk * slab;
 
-    for (int ch = ch0; ch < ch1; ++ch) {
-        __syncthreads();
+#ifndef C16_ABL
+#define C16_ABL 0      // measurement builds only (tools/conv16_bench_abl*): bit 0 no MFMAs, 1 no operand reads, 2 no weight park / request, 3 no per-stage barrier
+#endif
+#ifndef C16_XCHUNK
+#define C16_XCHUNK 1   // 0 (measurement builds): round 5's per-chunk weight pipeline, which restarts -- two exposed fetches -- at every chunk
+#endif
+    // The weight pipeline runs over VIRTUAL stages v = (chunk, stage) of the workgroup's whole K range (round 6): the slab of virtual
+    // stage v + 3 is requested at stage v, also across a chunk boundary, so that a new chunk finds its first slab parked in LDS and its
+    // second one in registers.  Before, every chunk fetched its stage-0 slab straight into LDS and waited for the stage-1 slab at the
+    // top of stage 0 -- two exposed L2 / MALL round trips per chunk, ~8 us of the 17 us a 9-tap chunk of g_0.conv_0 took.  The LDS
+    // buffer and the register set of a stage follow the parity of v (a chunk may have an odd number of stages).
+    const char* wbase0 = a.wp + (long)par * a.wset_stride + (long)n0 * 128;
+    float4 wra[WLD], wrb[WLD];
 #pragma unroll
-        for (int u = 0; u < NSLOT; ++u) {
-            const int idx = tid + u * NTHR;
-            if (idx < NPOS * 8) *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + (idx & 7) * 16) = vin[u];
-        }
-        for (int idx = tid + NSLOT * NTHR; idx < NPOS * 8; idx += NTHR) {  // oversized halo bricks only
-            const int q = idx & 7;
-            const int gp = gpos[idx >> 3];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gp >= 0 && ch * 4 + (q >> 1) < ngrp)
-                v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)ch * 128 + q * 16);
-            *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;
-        }
-        // weights: stage 0 straight to LDS, stages 1 and 2 into the two register sets (branch-free, always in registers)
-        const char* wbase = a.wp + (long)par * a.wset_stride + (long)ch * slab + (long)n0 * 128;
-        float4 wra[WLD], wrb[WLD];
-#pragma unroll
-        for (int u = 0; u < WLD; ++u) wra[u] = wrb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#define C16_REQUEST_W(WR, stg)                                                                                       \
+    for (int u = 0; u < WLD; ++u) wra[u] = wrb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define C16_REQUEST_W(WR, c_, s_)                                                                                    \
     _Pragma("unroll") for (int u = 0; u < WLD; ++u)                                                                  \
-        WR[u] = *reinterpret_cast<const float4*>(wbase + (long)tapw[(stg) * TPS + wtis[u]] * wtap_stride + wsrc[u]);
-        if (nst > 0) {
-#pragma unroll
-            for (int u = 0; u < WLD; ++u)
-                *reinterpret_cast<float4*>(w_lds + wdst[u]) =
-                    *reinterpret_cast<const float4*>(wbase + (long)tapw[wtis[u]] * wtap_stride + wsrc[u]);
-        }
-        { const int r1_ = nst > 1 ? 1 : 0, r2_ = nst > 2 ? 2 : nst - 1; C16_REQUEST_W(wra, r1_) C16_REQUEST_W(wrb, r2_) }
-        __syncthreads();
-        // LDS byte offsets of the taps of the current and of the next stage, fetched from the table a stage AHEAD: a
-        // ds_read_b32 right in front of the operand reads it addresses exposes one LDS round trip per k-step
-        int tcur[TPS], tnxt[TPS];
-#pragma unroll
-        for (int t = 0; t < TPS; ++t) {
-            tcur[t] = tapo[t];
-            tnxt[t] = tapo[(nst > 1 ? TPS : 0) + t];
-        }
-        if (nst > 0) C16_LOAD_OPS(o0, tcur[0], w_lds, 0)  // first k-step of the chunk: the only exposed LDS read
-        // One pipeline stage = TPS taps.  WR holds the weights of stage st_+1, requested TWO stages ago (an L2/MALL miss on
-        // a slab that every workgroup wants at the same moment costs more than one stage): park them in the other LDS buffer
-        // -- its last readers finished before the previous barrier -- and request stage st_+3 into the same registers.
-        // Then 2*TPS k-steps: the operands of k-step q+1 are read from LDS while k-step q's MFMAs run; the stage's single
-        // barrier sits in front of the last k-step and publishes the next stage's weights.
-        // (s_setprio around the MFMA block and dropping the scheduling fences were measured: no effect.)
-#define C16_STAGE(st_, WR)                                                                                           \
+        WR[u] = *reinterpret_cast<const float4*>(wbase0 + (long)(c_) * slab + (long)tapw[(s_) * TPS + wtis[u]] * wtap_stride + wsrc[u]);
+    int rq_c = ch0, rq_s = 0;   // the next virtual stage to request: chunk, stage (past the end: the last slab again, harmless)
+#define C16_RQ_NEXT(WR)                                                                                              \
     {                                                                                                                \
+        const bool in_ = rq_c < ch1 && (C16_XCHUNK || rq_c == ch);                                                   \
+        const int c_ = in_ ? rq_c : (C16_XCHUNK ? ch1 - 1 : ch), s_ = in_ ? rq_s : nst - 1;                          \
+        C16_REQUEST_W(WR, c_, s_)                                                                                    \
+        if (++rq_s == nst) { rq_s = 0; ++rq_c; }                                                                     \
+    }
+    int ch = ch0, sidx = 0;     // the current virtual stage: chunk, stage inside the chunk
+    const int nv = nst > 0 ? (ch1 - ch0) * nst : 0;
+    // LDS byte offsets of the taps of the current and of the next stage, fetched from the table a stage AHEAD: a
+    // ds_read_b32 right in front of the operand reads it addresses exposes one LDS round trip per k-step
+    int tcur[TPS], tnxt[TPS];
+#pragma unroll
+    for (int t = 0; t < TPS; ++t) tcur[t] = tnxt[t] = 0;
+    // Start of a chunk (stage 0): the previous brick's readers are done (first barrier), the prefetched input rows go to LDS, and the
+    // chunk's first operands are read -- the only exposed LDS read.  Only the workgroup's FIRST chunk (or every chunk with
+    // C16_XCHUNK = 0) also fetches its stage-0 slab straight into LDS and starts the request queue.
+#define C16_CHUNK_START(vpar_)                                                                                       \
+    {                                                                                                                \
+        __syncthreads();                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < NSLOT; ++u) {                                                          \
+            const int idx = tid + u * NTHR;                                                                          \
+            if (idx < NPOS * 8) *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + (idx & 7) * 16) = vin[u]; \
+        }                                                                                                            \
+        for (int idx = tid + NSLOT * NTHR; idx < NPOS * 8; idx += NTHR) {  /* oversized halo bricks only */          \
+            const int q = idx & 7;                                                                                   \
+            const int gp = gpos[idx >> 3];                                                                           \
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+            if (gp >= 0 && ch * 4 + (q >> 1) < ngrp)                                                                 \
+                v = *reinterpret_cast<const float4*>(a.in + (long)gp * in_row + (long)ch * 128 + q * 16);            \
+            *reinterpret_cast<float4*>(in_lds + (idx >> 3) * C16_ROW + q * 16) = v;                                  \
+        }                                                                                                            \
+        if (ch == ch0 || !C16_XCHUNK) {                                                                              \
+            rq_c = ch; rq_s = 0;                                                                                     \
+            _Pragma("unroll") for (int u = 0; u < WLD; ++u)                                                          \
+                *reinterpret_cast<float4*>(w_lds + (vpar_) * WBUF + wdst[u]) =                                       \
+                    *reinterpret_cast<const float4*>(wbase0 + (long)ch * slab + (long)tapw[wtis[u]] * wtap_stride + wsrc[u]); \
+            if (++rq_s == nst) { rq_s = 0; ++rq_c; }                                                                 \
+            if ((vpar_) == 0) { C16_RQ_NEXT(wra) C16_RQ_NEXT(wrb) } else { C16_RQ_NEXT(wrb) C16_RQ_NEXT(wra) }       \
+        }                                                                                                            \
+        __syncthreads();                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < TPS; ++t) {                                                            \
+            tcur[t] = tapo[t];                                                                                       \
+            tnxt[t] = tapo[(nst > 1 ? TPS : 0) + t];                                                                 \
+        }                                                                                                            \
+        C16_LOAD_OPS(o0, tcur[0], w_lds + (vpar_) * WBUF, 0, C16_TAPMASK(tcur[0]))                                   \
+    }
+    // One pipeline stage = TPS taps.  WR holds the weights of virtual stage v + 1, requested TWO stages ago (an L2/MALL miss on
+    // a slab that every workgroup wants at the same moment costs more than one stage): park them in the other LDS buffer
+    // -- its last readers finished before the previous barrier -- and request stage v + 3 into the same registers.
+    // Then 2*TPS k-steps: the operands of k-step q+1 are read from LDS while k-step q's MFMAs run; the stage's single
+    // barrier sits in front of the last k-step and publishes the next stage's weights.
+    // (s_setprio around the MFMA block and dropping the scheduling fences were measured: no effect.)
+#define C16_STAGE(vpar_, WR)                                                                                         \
+    {                                                                                                                \
+        if (sidx == 0) C16_CHUNK_START(vpar_)                                                                        \
         unsigned onmask = ~0u;   /* TSK: bit (tap of the stage) * WM + row block = the block's frame meets data for the tap */ \
+        unsigned onnext = ~0u;   /* the same for tap 0 of the NEXT stage (its first operands are read behind this stage's barrier) */ \
         if constexpr (TSK) {                                                                                         \
             onmask = 0u;                                                                                             \
-            _Pragma("unroll") for (int t = 0; t < TPS; ++t) {                                                        \
-                const int dt_ = __builtin_amdgcn_readfirstlane(tcur[t] & 3);                                         \
-                _Pragma("unroll") for (int wm = 0; wm < WM; ++wm)                                                    \
-                    onmask |= ((unsigned)(tbs[wm] + dt_) < (unsigned)a.T ? 1u : 0u) << (t * WM + wm);                \
-            }                                                                                                        \
+            _Pragma("unroll") for (int t = 0; t < TPS; ++t) onmask |= C16_TAPMASK(tcur[t]) << (t * WM);              \
+            onnext = C16_TAPMASK(tnxt[0]);                                                                           \
         }                                                                                                            \
-        const char* wb = w_lds + ((st_) & 1) * WBUF;                                                                 \
-        char* wnext = w_lds + (((st_) + 1) & 1) * WBUF;                                                              \
+        const char* wb = w_lds + (vpar_) * WBUF;                                                                     \
+        char* wnext = w_lds + (1 - (vpar_)) * WBUF;                                                                  \
         /* unconditional (after the last stage: a harmless re-park / re-request of the last slab): the vmcnt queue    \
            retires in order, and behind a conditional load the compiler must assume the shortest queue */           \
+        if (!(C16_ABL & 4)) {                                                                                        \
         _Pragma("unroll") for (int u = 0; u < WLD; ++u) *reinterpret_cast<float4*>(wnext + wdst[u]) = WR[u];         \
-        { const int rq_ = (st_) + 3 < nst ? (st_) + 3 : nst - 1; C16_REQUEST_W(WR, rq_) }                            \
-        if ((st_) == pf_stage && ch + 1 < ch1) C16_REQUEST_INPUT(ch + 1)                                             \
-        int tnn[TPS]; /* tap offsets of stage st_ + 2 (clamped), needed one stage from now */                        \
-        _Pragma("unroll") for (int t = 0; t < TPS; ++t) tnn[t] = tapo[((st_) + 2 < nst ? (st_) + 2 : nst - 1) * TPS + t]; \
+        C16_RQ_NEXT(WR)                                                                                              \
+        }                                                                                                            \
+        if (sidx == pf_stage && ch + 1 < ch1) C16_REQUEST_INPUT(ch + 1)                                              \
+        int tnn[TPS]; /* tap offsets of stage sidx + 2 (clamped), needed one stage from now */                       \
+        _Pragma("unroll") for (int t = 0; t < TPS; ++t) tnn[t] = tapo[(sidx + 2 < nst ? sidx + 2 : nst - 1) * TPS + t]; \
         _Pragma("unroll") for (int q = 0; q < 2 * TPS; ++q) {                                                        \
             if (q + 1 < 2 * TPS) {                                                                                   \
                 const int tq = (q + 1) >> 1, sq = (q + 1) & 1;                                                       \
-                if ((q + 1) & 1) C16_LOAD_OPS(o1, tcur[tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)                   \
-                else C16_LOAD_OPS(o0, tcur[tq], wb + tq * (C16_BN * C16_ROW), 64 * sq)                               \
+                if ((q + 1) & 1) C16_LOAD_OPS(o1, tcur[tq], wb + tq * (C16_BN * C16_ROW), 64 * sq, onmask >> (tq * WM)) \
+                else C16_LOAD_OPS(o0, tcur[tq], wb + tq * (C16_BN * C16_ROW), 64 * sq, onmask >> (tq * WM))           \
             } else {                                                                                                 \
-                __syncthreads();                                                                                     \
-                if ((st_) + 1 < nst) C16_LOAD_OPS(o0, tnxt[0], wnext, 0)                                             \
+                if (!(C16_ABL & 8)) __syncthreads();                                                                 \
+                if (sidx + 1 < nst) C16_LOAD_OPS(o0, tnxt[0], wnext, 0, onnext)                                      \
             }                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             if (q & 1) C16_MFMA(o1, q >> 1) else C16_MFMA(o0, q >> 1)                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
         _Pragma("unroll") for (int t = 0; t < TPS; ++t) { tcur[t] = tnxt[t]; tnxt[t] = tnn[t]; }                     \
+        if (++sidx == nst) { sidx = 0; ++ch; }                                                                       \
     }
-        for (int st = 0; st < nst; st += 2) {
-            C16_STAGE(st, wra)
-            if (st + 1 < nst) C16_STAGE(st + 1, wrb)
-        }
+    for (int v = 0; v < nv; v += 2) {
+        C16_STAGE(0, wra)
+        if (v + 1 < nv) C16_STAGE(1, wrb)
     }
 
     const int HWo = a.H * a.W;
@@ -521,6 +571,18 @@ int Conv16Weights::pack_tdup(const float* w_src, const float* bias_src, int cout
     return I2V_OK;
 }
 
+// measurement builds (-DC16_TUNE) can switch the clipped staging off (I2V_C16_CLIP=0) for same-box A/Bs; the production build cannot
+static bool c16_switch(const char* name) {
+#ifdef C16_TUNE
+    const char* e = getenv(name);
+    return !(e && e[0] == '0');
+#else
+    (void)name;
+    return true;
+#endif
+}
+static bool c16_clip_enabled() { return c16_switch("I2V_C16_CLIP"); }
+
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, bool TSK = false>
 static int launch16(const Conv16Args& a, unsigned nblk, size_t lds, hipStream_t st) {
     auto kern = conv_mfma_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, TPS, TSK>;
@@ -608,43 +670,59 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     rem /= TT;
     while (rem > 1 && W >= TW * 2) { TW *= 2; rem /= 2; }
     while (rem > 1 && H >= TH * 2) { TH *= 2; rem /= 2; }
-    int TB = rem;
-    I2V_REQUIRE(TB * TT * TH * TW == C16_BM && T % TT == 0 && H % TH == 0 && W % TW == 0, I2V_E_INVALID,
+    const int TB_full = rem;
+    I2V_REQUIRE(TB_full * TT * TH * TW == C16_BM && T % TT == 0 && H % TH == 0 && W % TW == 0, I2V_E_INVALID,
                 "conv16: cannot tile [T=%d,H=%d,W=%d] into bricks of %d positions", T, H, W, C16_BM);
-    {   // tiny feature maps x many samples: the halo tile of a full brick may not fit LDS -- take fewer samples per brick
-        // (the tile's unused rows are masked)
-        auto lds_of = [&](int tb) {
-            const size_t rows = (size_t)tb * (TT + a.KT - 1) * (TH + a.KH - 1) * (TW + a.KW - 1);
-            return rows * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + rows * 4;
-        };
-        while (TB > 1 && lds_of(TB) > 160 * 1024) TB /= 2;
-    }
-    I2V_REQUIRE(!stats || TB == 1, I2V_E_INVALID, "conv16: fused statistics need bricks inside one sample");
-    a.TB = TB; a.TT = TT; a.TH = TH; a.TW = TW;
-    a.nbB = (B + TB - 1) / TB; a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;
-    a.HWp = TW + a.KW - 1;
+    a.TT = TT; a.TH = TH; a.TW = TW;
+    a.nbT = T / TT; a.nbH = H / TH; a.nbW = W / TW;
     a.patch = (TW % 4 == 0 && TH % 4 == 0) ? 1 : 0;
-    if (a.patch) {  // a halo row pitch = 4 or 12 (mod 16) makes the 4x4 patches conflict-free; keep it if LDS allows
-        int hp = a.HWp;
-        while (hp % 16 != 4 && hp % 16 != 12) ++hp;
-        const size_t rows = (size_t)TB * (TT + a.KT - 1) * (TH + a.KH - 1) * hp;
-        const size_t need = rows * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + rows * 4;
-        if (need <= 160 * 1024) a.HWp = hp;
-    }
-    const int npos = TB * (TT + a.KT - 1) * (TH + a.KH - 1) * a.HWp;
-    // channel tile: the widest that divides CoutPad, narrowed while the launch would leave most CUs without a workgroup
-    // (head_0: 64 samples x 4 x 4 positions = 4 bricks x 8 tiles of 128 channels, each streaming 9 x 1024 channels of K)
-    // split-K (decided by the layer geometry alone, see below): its slices are workgroups too -- round 5 narrowed the channel tile
-    // without counting them, so head_0 at B = 64 (4 bricks x 8 slices) ran 32-channel tiles: 1024 workgroups that each re-read the
-    // whole activation brick for 32 output channels (0.38 / 0.27 ms for 0.04 ms of matrix work).  The tile width changes the schedule
-    // only, never an output's accumulation order: same bits.
     const bool can_split = splitk_ws && !stats && !(epi & (EPI_FRAMES | EPI_HL16)) && a.Cout % 4 == 0;
     const int ksplit_plan = can_split ? conv16_splitk_factor((long)(a.tdup ? 2 * T : T) * H * W, a.nchunk) : 1;
-    int BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
-    {
+    // temporal tap skipping per row block (see the kernel): a 3-tap temporal kernel on a two-frame map whose 32-row MFMA blocks lie
+    // inside one frame (g_0.conv_1: 2 x 8 x 8)
+    const bool tsk_geo = !a.tdup && a.KT == 3 && a.T == 2 && TT == 2 && (TH * TW) % 32 == 0;
+    // Brick plan for a given staging form.  clip (round 6): a brick that spans the map's whole time extent stages only its real frames --
+    // the temporal halo of such a brick is zero padding, which a one-frame brick's tap list and the TSK masks skip anyway.  Without the
+    // halo frames (half of g_0.conv_1's staged rows, half of g_0.conv_0's) the brick fits LDS with the conflict-free row pitch.
+    // Nothing an output sums, and no order, changes: same bits.
+    int TB = 1, BN = 32, npos = 0;
+    auto plan = [&](bool clip) {
+        const int ht = clip ? TT : TT + a.KT - 1;
+        auto lds_of = [&](int tb, int hp) {
+            const size_t rows = (size_t)tb * ht * (TH + a.KH - 1) * hp;
+            return rows * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + rows * 4;
+        };
+        // tiny feature maps x many samples: the halo tile of a full brick may not fit LDS -- take fewer samples per brick
+        // (the tile's unused rows are masked)
+        TB = TB_full;
+        while (TB > 1 && lds_of(TB, TW + a.KW - 1) > 160 * 1024) TB /= 2;
+        a.HWp = TW + a.KW - 1;
+        if (a.patch) {  // a halo row pitch = 4 or 12 (mod 16) makes the 4x4 patches conflict-free; keep it if LDS allows
+            int hp = a.HWp;
+            while (hp % 16 != 4 && hp % 16 != 12) ++hp;
+            if (lds_of(TB, hp) <= 160 * 1024) a.HWp = hp;
+        }
+        a.TB = TB;
+        a.nbB = (B + TB - 1) / TB;
+        npos = TB * ht * (TH + a.KH - 1) * a.HWp;
+        // channel tile: the widest that divides CoutPad, narrowed while the launch would leave most CUs without a workgroup
+        // (head_0: 64 samples x 4 x 4 positions = 4 bricks x 8 tiles of 128 channels, each streaming 9 x 1024 channels of K)
+        // split-K (decided by the layer geometry alone, see below): its slices are workgroups too -- round 5 narrowed the channel tile
+        // without counting them, so head_0 at B = 64 (4 bricks x 8 slices) ran 32-channel tiles: 1024 workgroups that each re-read the
+        // whole activation brick for 32 output channels (0.38 / 0.27 ms for 0.04 ms of matrix work).  The tile width changes the schedule
+        // only, never an output's accumulation order: same bits.
+        BN = a.CoutPad % 128 == 0 ? 128 : (a.CoutPad % 64 == 0 ? 64 : 32);
         const long bricks = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.tdup ? 2 : 1) * ksplit_plan;
         while (BN > 32 && bricks * (a.CoutPad / BN) < 256) BN /= 2;
+    };
+    a.tskperm = c16_switch("I2V_C16_PERM") ? 1 : 0;
+    a.tclip = 0;
+    if (a.nbT == 1 && a.KT > 1 && (TT == 1 || tsk_geo) && c16_clip_enabled()) {
+        plan(true);
+        a.tclip = (TT == 1 || BN != 64) ? 1 : 0;   // (the 64-channel tile has no TSK instantiation: it needs the staged padding frames)
     }
+    if (!a.tclip) plan(false);
+    I2V_REQUIRE(!stats || TB == 1, I2V_E_INVALID, "conv16: fused statistics need bricks inside one sample");
     const size_t lds = (size_t)npos * C16_ROW + 2 * (size_t)128 * C16_ROW + (2 * C16_BM + 72) * 4 + (size_t)npos * 4;
     I2V_REQUIRE(lds <= 160 * 1024, I2V_E_INVALID, "conv16: LDS %zu bytes exceeds 160 KiB", lds);
     const long nblk = (long)a.nbB * a.nbT * a.nbH * a.nbW * (a.CoutPad / BN);
@@ -666,9 +744,7 @@ int conv16_forward(const Conv16Weights& wts, const void* in_hl16, float* out, co
     }
     // (a 16-wave variant <8,2,1,2,1> -- 4 waves per SIMD, wave tile 32x64, 128 VGPRs -- was measured 5 % slower)
     int rc;
-    // temporal tap skipping per row block (see the kernel): a 3-tap temporal kernel on a two-frame map whose 32-row MFMA blocks lie
-    // inside one frame (g_0.conv_1: 2 x 8 x 8)
-    const bool tsk = !a.tdup && a.KT == 3 && a.T == 2 && a.TT == 2 && (a.TH * a.TW) % 32 == 0;
+    const bool tsk = tsk_geo;
     if (BN == 128) rc = tsk ? launch16<4, 2, 2, 2, 1, true>(a, (unsigned)nblk, lds, st) : launch16<4, 2, 2, 2, 1>(a, (unsigned)nblk, lds, st);
     else if (BN == 64) rc = launch16<4, 2, 2, 1, 2>(a, (unsigned)nblk, lds, st);   // (its TSK instantiation spills: 256 VGPRs + scratch; the 64-wide tile keeps all 27 taps)
     else rc = tsk ? launch16<8, 1, 1, 1, 4, true>(a, (unsigned)nblk, lds, st) : launch16<8, 1, 1, 1, 4>(a, (unsigned)nblk, lds, st);

@@ -1563,7 +1563,16 @@ static int fork_spade(i2v_dec* d, const DecWs& L, char* ws, const float* img, in
     I2V_HIP_CHECK(hipEventRecord(d->ev_fork, st));
     I2V_HIP_CHECK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
     int rc = I2V_OK;
-    for (int k = 0; k < 6 && !rc; ++k) {
+    // A SHARED side stream (i2v_dec_set_side_stream: the caller's cINN prefetch runs on it) typically has the NEXT batch's cINN pass
+    // queued in front of these branches: the two tiny first levels (4x4, 8x8 maps: the maps head_0 and g_0 wait for) then run inline on
+    // the caller's stream -- with their own scratch -- so that the main chain does not stall behind that pass; the branches of the
+    // later levels have the first two blocks' time to get through.  (Own side stream: everything on it, as before.)
+    const int k0 = d->side_owned ? 0 : 2;
+    for (int k = 0; k < k0 && !rc; ++k) {
+        rc = spade_branch(d, d->blk[k], d->lvl[k], img, img_h, img_w, B, F(L.y0), F(L.y1), L.has_y1v ? F(L.y1v) : nullptr, F(L.gbs[k]), st);
+        if (!rc && hipEventRecord(d->ev_lvl[k], st) != hipSuccess) rc = I2V_E_HIP;
+    }
+    for (int k = k0; k < 6 && !rc; ++k) {
         rc = spade_branch(d, d->blk[k], d->lvl[k], img, img_h, img_w, B, F(L.py0), F(L.py1), L.has_y1v ? F(L.py1v) : nullptr, F(L.gbs[k]), d->side);
         if (!rc && hipEventRecord(d->ev_lvl[k], d->side) != hipSuccess) rc = I2V_E_HIP;
     }

@@ -87,17 +87,27 @@ class Model(torch.nn.Module):
         import i2v_pipeline
         if self._prefetch is None or self._prefetch.stream.device != x_0.device:
             self._prefetch = i2v_pipeline.LatentPrefetcher(lambda a, b, c, d: self.sample_latent(a, b, c, d), device=x_0.device)
-            # A rank of a multi-GPU job (torch.distributed up, world > 1) also runs a collation stream and RCCL's: the decoder's side
-            # work then shares the cINN stream instead of a stream of its own -- HIP multiplexes streams onto four hardware queues,
-            # and with a fourth side stream the own-stream form measured +7 % (B = 64) / +46 % (B = 8) per step
-            # (profiles/r06_c_stream_configurations.txt).  One GPU: the handle's own stream (the faster form there).
-            import torch.distributed as dist
-            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-            self.decoder.share_side_stream(self._prefetch.stream if multi else None)
+            # Three streams at every N: the caller's, this prefetch stream, the decoder handle's own side stream.  A rank of a multi-GPU
+            # job that collates a STREAM of calls off the compute stream issues its all-gathers on the prefetch stream too
+            # (``self.collator(total)``), not on a fourth stream: HIP multiplexes streams onto four hardware queues, and a collation
+            # stream of its own cost +7 % (B = 64) / +46 % (B = 8) per step, the shared-side-stream remedy +2 % / +9 %, the gathers on
+            # the prefetch stream nothing (profiles/r06_c_stream_configurations.txt, r06_o_collation_on_prefetch_stream.txt).
+            self.decoder.share_side_stream(None)
         x_0 = x_0.contiguous()
         ticket = self._prefetch.submit(x_0, cond, residual, embed)
         self.decoder.prepare(x_0)
         return self.decode(x_0, self._prefetch.get(ticket))
+
+    def collator(self, total, group=None, device=None):
+        """``i2v_dist.OverlappedCollator`` for a stream of ``synthesize`` calls on this rank's shard of a ``total``-sample job: every
+        call's all-gather is issued on the stream the cINN prefetch runs on (see ``synthesize``), overlapping the next call."""
+        import i2v_dist
+        import i2v_pipeline
+        if self._prefetch is None:
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            self._prefetch = i2v_pipeline.LatentPrefetcher(lambda a, b, c, d: self.sample_latent(a, b, c, d), device=dev)
+            self.decoder.share_side_stream(None)
+        return i2v_dist.OverlappedCollator(total, group=group, stream=self._prefetch.stream)
 
     def check(self):
         """Raises if the decoder's split-fp16 operands left the fp16 range in any call since the last check (sticky device

@@ -58,12 +58,18 @@ class OverlappedCollator:
     decoder, which overlap the transfer over xGMI.  ``result()`` makes the current stream wait for the newest gather and
     returns its buffer; a buffer is reused two submits later, by which time the caller has consumed it."""
 
-    def __init__(self, total, group=None, emulate=False):
+    def __init__(self, total, group=None, emulate=False, stream=None):
         self.total, self.group = total, group
+        # stream (optional): issue the gathers on THIS side stream instead of one of the collator's own -- e.g. the stream the cINN
+        # prefetch of the NEXT step runs on (i2v_pipeline.LatentPrefetcher.stream): a rank then runs main + the decoder handle's side
+        # stream + ONE more stream, the count that fits HIP's four hardware queues (DESIGN.md §3.6).  The gather of step k and the pass
+        # of step k + 2 serialise on it with a whole step of slack.
+        self._ext_stream = stream
         # emulate (one process, measurement only): the same side stream, events and double buffers, with a device copy of the block
         # standing in for the RCCL all-gather -- the stream configuration of an N > 1 job (main + side streams + the collation stream)
-        # on ONE GPU, to measure what the extra stream costs on HIP's four hardware queues (bench.py --emulate-collation)
-        self.emulate = bool(emulate)
+        # on ONE GPU, to measure what the extra stream costs on HIP's four hardware queues (bench.py --emulate-collation).
+        # emulate = "rccl": the REAL path below on a one-rank RCCL process group (torch.distributed / RCCL issue the gather themselves)
+        self.emulate = emulate or False
         self.stream = None
         self.bufs = [None, None]
         self.events = [None, None]
@@ -73,12 +79,12 @@ class OverlappedCollator:
     def submit(self, local):
         if self.emulate and local.is_cuda and not (dist.is_available() and dist.is_initialized()):
             return self._submit_emulated(local)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1 \
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and self.emulate != "rccl") \
                 or self.total % dist.get_world_size(self.group) != 0 or not local.is_cuda:
             self.last = ("sync", collate(local, self.total, self.group))  # ragged shards / CPU tensors (gloo): plain path
             return
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=local.device)
+            self.stream = self._ext_stream if self._ext_stream is not None else torch.cuda.Stream(device=local.device)
         k = self.i
         self.i ^= 1
         if self.bufs[k] is None or self.bufs[k].shape[1:] != local.shape[1:] or self.bufs[k].dtype != local.dtype:
@@ -100,7 +106,7 @@ class OverlappedCollator:
 
     def _submit_emulated(self, local):
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=local.device)
+            self.stream = self._ext_stream if self._ext_stream is not None else torch.cuda.Stream(device=local.device)
         k = self.i
         self.i ^= 1
         if self.bufs[k] is None or self.bufs[k].shape != local.shape:

@@ -40,10 +40,10 @@ class LatentPrefetcher:
         the arguments are complete; or after the event ``_ready`` of an earlier ``mark()``).  Returns a ticket for ``get``.
 
         When the decoder shares this stream for its own side work (``Generator.share_side_stream(pf.stream)``: ONE side stream per
-        job), enqueue the decoder of batch k FIRST and the pass of batch k+1 behind it -- the side stream runs in order, and a pass
-        enqueued in front would delay the decoder's first SPADE maps by its 0.45 ms:
-
-            ev = pf.mark(); frames_k = decoder(x0_k, z_k); t = pf.submit(res_{k+1}, emb_{k+1}, _ready=ev)"""
+        job, what a rank of a multi-GPU job should run) the usual order -- submit batch k + 1, then the decoder of batch k -- stays:
+        the decoder handle then runs its two tiny first SPADE levels inline, so the main chain does not wait for the pass queued in
+        front of its side work.  ``_ready`` lets a caller enqueue the pass BEHIND the decoder's launches without making it wait for
+        them (``ev = pf.mark(); frames = decoder(...); t = pf.submit(..., _ready=ev)``)."""
         if not self.enabled:
             return (self.latent_fn(*args, **kwargs), None)
         ready = _ready

@@ -42,6 +42,20 @@ for _ in range(3):   # a short stream of steps: the gather of step k overlaps st
 out = col.result()
 torch.cuda.synchronize()
 assert out.shape == full.shape and torch.equal(out, full), (rank, float((out - full).abs().max()))
+# the bench's N > 1 form: the gathers issued on the stream the cINN prefetch of the NEXT step runs on (three streams per rank)
+import i2v_pipeline  # noqa: E402
+pf = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True), device=dev)
+col3 = i2v_dist.OverlappedCollator(total, stream=pf.stream)
+xs, rs, es = x0[lo:hi].to(dev).contiguous(), residual[lo:hi].to(dev).contiguous(), embed[lo:hi].to(dev).contiguous()
+tk = pf.submit(rs, es)
+for k in range(4):
+    z = pf.get(tk)
+    if k + 1 < 4:
+        tk = pf.submit(rs, es)
+    col3.submit(gen(xs, z.view(xs.size(0), -1)))
+out3 = col3.result()
+torch.cuda.synchronize()
+assert torch.equal(out3, full), (rank, "collation on the prefetch stream")
 out2 = i2v_dist.synthesize_sharded(model, x0.to(dev), residual.to(dev), embed.to(dev))
 assert torch.equal(out2, full)
 dist.barrier()

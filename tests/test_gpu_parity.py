@@ -504,6 +504,14 @@ def test_decoder_shared_side_stream_keeps_the_bits():
                 tk = pf.submit(rs[k + 1], es[k + 1], _ready=ev)
         for k in range(4):
             assert torch.equal(outs[k], refs[k]), (rep, k)
+    outs, tk = [], pf.submit(rs[0], es[0])       # the usual order on the shared stream: the pass of batch k + 1 in FRONT of decoder k's side work
+    for k in range(4):
+        z = pf.get(tk)
+        if k + 1 < 4:
+            tk = pf.submit(rs[k + 1], es[k + 1])
+        outs.append(gen(xs[k], z.view(3, -1)))
+    for k in range(4):
+        assert torch.equal(outs[k], refs[k]), k
     # single calls: pass on the side stream, prepare behind it on the same stream, then the decoder
     for k in (2, 0):
         tk = pf.submit(rs[k], es[k])
@@ -512,6 +520,44 @@ def test_decoder_shared_side_stream_keeps_the_bits():
     gen.prepare(xs[1])                       # a prepare is pending on the shared stream when the handle gets its own stream back
     gen.share_side_stream(None)
     assert torch.equal(gen(xs[1], flow(rs[1], es[1], reverse=True).view(3, -1)), refs[1])
+    assert gen.native().status() == 0
+
+
+def test_collation_on_the_prefetch_stream_keeps_the_bits():
+    """Round 6: a rank of an N > 1 job issues every step's all-gather on the stream its cINN prefetch runs on
+    (OverlappedCollator(stream = LatentPrefetcher.stream): three streams at every N).  One GPU, the gather emulated by a device
+    copy: on that stream the pass of step k + 1, the gather of step k and the pass of step k + 2 follow each other; every collated
+    step must equal the serial call bit for bit, also when result() is only taken every other step (double buffers)."""
+    import i2v_dist
+    import i2v_pipeline
+    from stage2_cINN.modules.flow_blocks import ConditionalFlow
+    g, meta = load_golden("dec_nf8_bair")
+    gen = _gen(meta)
+    flow = ConditionalFlow(64, 64, 512, 2, 20, conditioning_option="None")
+    flow.load_state_dict(T(synth.flow_state_dict(seed=7, embedding_dim=64)))
+    flow = flow.cuda().eval()
+    xs, rs, es = [], [], []
+    for k in range(5):
+        x0, r, e = synth.bench_inputs(3, 64, 64)
+        xs.append((x0 * (1.0 - 0.15 * k)).cuda().contiguous()); rs.append((r - 0.1 * k).cuda().contiguous()); es.append(e.cuda().contiguous())
+    refs = [gen(xs[k], flow(rs[k], es[k], reverse=True).view(3, -1)).clone() for k in range(5)]
+    torch.cuda.synchronize()
+    pf = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True))
+    col = i2v_dist.OverlappedCollator(3, emulate="copy", stream=pf.stream)
+    for every in (1, 2):
+        got = {}
+        tk = pf.submit(rs[0], es[0])
+        for k in range(5):
+            z = pf.get(tk)
+            if k + 1 < 5:
+                tk = pf.submit(rs[k + 1], es[k + 1])
+            col.submit(gen(xs[k], z.view(3, -1)))
+            if k % every == every - 1 or k == 4:
+                got[k] = col.result().clone()
+        torch.cuda.synchronize()
+        assert col.stream is pf.stream
+        for k, v in got.items():
+            assert torch.equal(v, refs[k]), (every, k)
     assert gen.native().status() == 0
 
 

@@ -38,7 +38,7 @@ def test_production_library_has_no_launch_path_environment_switches():
     if not os.path.exists(i2v_native.LIB_PATH):
         i2v_native.build()
     blob = open(i2v_native.LIB_PATH, "rb").read()
-    for name in (b"I2V_W4_PIPE", b"I2V_W4_BN", b"I2V_W4_ORDER", b"I2V_W4_NTH", b"I2V_W4_SKEW", b"I2V_W4_TRACE", b"I2V_W4_LOADER", b"I2V_CONVIMG_TCH"):
+    for name in (b"I2V_W4_PIPE", b"I2V_W4_BN", b"I2V_W4_ORDER", b"I2V_W4_NTH", b"I2V_W4_SKEW", b"I2V_W4_TRACE", b"I2V_W4_LOADER", b"I2V_CONVIMG_TCH", b"I2V_C16_"):
         assert name not in blob, name
     assert b"conv_wino4_f16x3_kernelILi9ELi64ELi0ELi512E" in blob
     for pipe in (1, 2):
@@ -48,7 +48,8 @@ def test_production_library_has_no_launch_path_environment_switches():
         assert b"I2V_W4_PIPE" in mblob and b"conv_wino4_f16x3_kernelILi9ELi64ELi1ELi512E" in mblob
     # source level: getenv only at creation / pack time (functions named below) or under I2V_MEASURE
     allowed = {"i2v_dec.hip": ("i2v_dec_create", "i2v_gblock_create"), "i2v_flow.hip": ("i2v_flow_create",),
-               "i2v_flow_tile.hip": ("env_int",), "i2v_conv16w4.hip": ("w4_switches",), "i2v_convimg.hip": ("conv_img_mfma_forward",)}
+               "i2v_flow_tile.hip": ("env_int",), "i2v_conv16w4.hip": ("w4_switches",), "i2v_convimg.hip": ("conv_img_mfma_forward",),
+               "i2v_conv16.hip": ("c16_switch",)}     # (under -DC16_TUNE only: the stand-alone tools/conv16_bench build)
     import glob
     for f in glob.glob(os.path.join(PKG, "csrc", "*.hip")):
         text = open(f).read()
@@ -59,6 +60,8 @@ def test_production_library_has_no_launch_path_environment_switches():
     body = w4[w4.index("static W4Switches w4_switches()"):]
     body = body[:body.index("\n}\n")]
     assert w4.count("getenv(") == body.count("getenv(") and body.index("#ifdef I2V_MEASURE") < body.index("getenv(") < body.index("#endif")
+    c16 = open(os.path.join(PKG, "csrc", "i2v_conv16.hip")).read()
+    assert c16.count("getenv(") == 1 and c16.index("#ifdef C16_TUNE") < c16.index("getenv(") < c16.index("#else", c16.index("#ifdef C16_TUNE"))
     ci = open(os.path.join(PKG, "csrc", "i2v_convimg.hip")).read()
     assert ci.count("getenv(") == 1 and ci.index("#ifdef I2V_MEASURE") < ci.index("getenv(")
     ft = open(os.path.join(PKG, "csrc", "i2v_flow_tile.hip")).read()
