@@ -18,9 +18,12 @@
 // output channels (128/64/32), wave tile up to 64 x 64.  Per 32-channel K chunk the input halo brick is staged once in
 // LDS (rows padded 128 -> 144 B, MFMA rows assigned to 4x4 (h,w) patches: conflict-free ds_read_b128) and reused by all
 // taps; the next chunk's rows are requested from HBM a few taps ahead.  The [BN][32] weight slab of each tap is
-// double-buffered in LDS and requested one full tap ahead.  The tap loop is software-pipelined: the operands of the
-// next k-step (second half of this tap / first half of the next tap) are read from LDS while the current k-step's 12
-// MFMAs per wave run, with ONE barrier per tap placed between the two k-steps (it publishes the next tap's weights).
+// double-buffered in LDS and requested three stages ahead, over VIRTUAL stages that run across chunk boundaries (round 6).
+// The tap loop is software-pipelined: the operands of the next k-step (second half of this tap / first half of the next
+// tap) are read from LDS while the current k-step's 12 MFMAs per wave run -- one ds_read_b128 per gap between two MFMAs
+// (round 6: sched_group_barrier) -- with ONE barrier per tap placed between the two k-steps (it publishes the next tap's
+// weights).  A brick that spans the map's whole time extent stages no temporal halo frames (round 6, `tclip`).
+// Round-6 A/Bs and ablations of the stage loop: profiles/r06_q_conv16_direct_ab.txt.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) m_ |= ((unsigned)(tbs[wm] + dt_) < (unsigned)a.T ? 1u : 0u) << wm; \
         return m_; }())
 #define C16_LOAD_OPS(o, aoffs, wbuf, koff, msk_)                                                                      \
-    if (!(C16_ABL & 2)) {                                                                                            \
+    { if (!(C16_ABL & 2)) {                                                                                          \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) if (!TSK || (((msk_) >> wm) & 1u)) {                        \
             const char* p_ = in_lds + aoff[wm] + (TSK ? ((aoffs) & ~3) : (aoffs)) + (koff);                          \
             (o).ah[wm] = *reinterpret_cast<const half8*>(p_);                                                        \
@@ -266,10 +269,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                 (o).bl[wn] = *reinterpret_cast<const half8*>(p_ + 16);                                               \
             }                                                                                                        \
         }                                                                                                            \
-    }
+    } }
     // three terms, tiles interleaved so that consecutive MFMAs never chain on the same accumulator
 #define C16_MFMA(o, tq_)                                                                                             \
-    if (!(C16_ABL & 1)) {                                                                                            \
+    { if (!(C16_ABL & 1)) {                                                                                          \
         bool on_[WM];                                                                                                \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) on_[wm] = !TSK || ((onmask >> ((tq_) * WM + wm)) & 1u);     \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) if (on_[wm]) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) \
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
             acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).ah[wm], (o).bl[wn], acc[wm][wn], 0, 0, 0);      \
         _Pragma("unroll") for (int wm = 0; wm < WM; ++wm) if (on_[wm]) _Pragma("unroll") for (int wn = 0; wn < WN; ++wn) \
             acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16((o).al[wm], (o).bh[wn], acc[wm][wn], 0, 0, 0);      \
-    }
+    } }
     // split-K (tiny feature maps: few tiles, long K): this workgroup covers the chunks [ch0, ch1)
     const int ch0 = (int)((long)a.nchunk * blockIdx.y / a.ksplit), ch1 = (int)((long)a.nchunk * (blockIdx.y + 1) / a.ksplit);
     C16_REQUEST_INPUT(ch0)
@@ -303,6 +306,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
 #ifndef C16_ABL
 #define C16_ABL 0      // measurement builds only (tools/conv16_bench_abl*): bit 0 no MFMAs, 1 no operand reads, 2 no weight park / request, 3 no per-stage barrier
 #endif
+#ifndef C16_ILV
+#define C16_ILV 1      // 0 (measurement builds): the operand reads of the next k-step as one burst in front of the k-step's MFMAs (round 5)
+#endif
+    // The 2 (WM + WN) ds_read_b128 of the next k-step go ONE PER GAP between this k-step's MFMAs (sched_group_barrier: MFMA, DS read,
+    // MFMA, DS read, ...).  As a burst in front of the MFMAs -- all eight waves leave the stage barrier together -- 64 reads queue up at
+    // the LDS and every wave's first MFMA waits behind its own eight (in-order issue): the ablations (profiles/r06_q) put the burst at
+    // 0.22 of the 0.50 ms of g_0.conv_0.  (TSK instantiations branch around masked row blocks: their k-steps are not one basic block.)
+#define C16_INTERLEAVE                                                                                               \
+    {                                                                                                                \
+        constexpr int NR_ = 2 * (WM + WN), NM_ = 3 * WM * WN, NI_ = NR_ < NM_ ? NR_ : NM_;                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI_; ++i_) {                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                       \
+        }                                                                                                            \
+        if constexpr (NM_ > NI_) __builtin_amdgcn_sched_group_barrier(0x008, NM_ - NI_, 0);                          \
+        if constexpr (NR_ > NI_) __builtin_amdgcn_sched_group_barrier(0x100, NR_ - NI_, 0);                          \
+    }
 #ifndef C16_XCHUNK
 #define C16_XCHUNK 1   // 0 (measurement builds): round 5's per-chunk weight pipeline, which restarts -- two exposed fetches -- at every chunk
 #endif
@@ -400,10 +420,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                 else C16_LOAD_OPS(o0, tcur[tq], wb + tq * (C16_BN * C16_ROW), 64 * sq, onmask >> (tq * WM))           \
             } else {                                                                                                 \
                 if (!(C16_ABL & 8)) __syncthreads();                                                                 \
-                if (sidx + 1 < nst) C16_LOAD_OPS(o0, tnxt[0], wnext, 0, onnext)                                      \
+                /* (interleaved form: unconditional -- behind a chunk's last stage a harmless read of valid addresses --  \
+                   so that the k-step stays one basic block) */                                                      \
+                if ((C16_ILV && !TSK) || sidx + 1 < nst) C16_LOAD_OPS(o0, tnxt[0], wnext, 0, onnext)                 \
             }                                                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            if (!C16_ILV || TSK) __builtin_amdgcn_sched_barrier(0);                                                  \
             if (q & 1) C16_MFMA(o1, q >> 1) else C16_MFMA(o0, q >> 1)                                                \
+            if (C16_ILV && !TSK) C16_INTERLEAVE                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
         _Pragma("unroll") for (int t = 0; t < TPS; ++t) { tcur[t] = tnxt[t]; tnxt[t] = tnn[t]; }                     \

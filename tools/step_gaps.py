@@ -20,7 +20,7 @@ def short(n):
     return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace("i2v::", "")[:60]
 
 
-ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[qkey], short(r["Kernel_Name"])) for r in rows), key=lambda k: k[0])
+ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[qkey], short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows), key=lambda k: k[0])
 ci = [k for k in ks if "conv_img" in k[3]]
 if len(ci) < 2:
     raise SystemExit("fewer than two conv_img launches in the trace")
@@ -29,7 +29,7 @@ win = [k for k in ks if k[1] > w0 and k[0] < w1]
 print(f"step window {(w1 - w0) / 1e6:.3f} ms, {len(win)} launches, queues by {qkey}; main queue {mainq}")
 busy = defaultdict(float)
 cnt = defaultdict(int)
-for s, e, q, n in win:
+for s, e, q, n, _ in win:
     busy[q] += (min(e, w1) - max(s, w0)) / 1e3
     cnt[q] += 1
 for q in sorted(busy, key=lambda q: -busy[q]):
@@ -51,3 +51,16 @@ for g, a, b, t in sorted(big, reverse=True)[:5]:
     hi = lo + g * 1e3
     oth = [k for k in win if k[2] != mainq and k[1] > lo and k[0] < hi]
     print(f"  during the {g:.0f} us gap at {t:.3f} ms: " + (", ".join(sorted({k[3][:40] for k in oth})) or "nothing on any queue"))
+
+qmap = defaultdict(set)
+for k in ks:
+    qmap[k[2]].add(k[4])
+print("stream -> hardware queue ids: " + "; ".join(f"{a} -> {sorted(b)}" for a, b in sorted(qmap.items())))
+# optional dump of every launch in [t0, t1] ms of the window: python tools/step_gaps.py <dir> <min_gap> <t0> <t1>
+if len(sys.argv) > 4:
+    t0, t1 = float(sys.argv[3]), float(sys.argv[4])
+    print(f"launches between {t0} and {t1} ms of the window (start ms, duration us, stream, queue, kernel):")
+    for k in win:
+        a = (k[0] - w0) / 1e6
+        if t0 <= a <= t1 or t0 <= (k[1] - w0) / 1e6 <= t1:
+            print(f"  {a:8.3f}  {(k[1] - k[0]) / 1e3:8.1f}  s{k[2]:>2s} q{k[4]:>2s}  {k[3]}")
