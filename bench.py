@@ -488,11 +488,27 @@ def main():
         if args.per_layer:
             write_per_layer(args.per_layer, layers, args.steps, gen.mma)
         validate_line(result, full=world == 1 and gen.mma != 0 and not (args.no_extras or args.no_cpu_baseline or args.no_exact or args.sustain < 10))
-        print(json.dumps(result), flush=True)
+        line = json.dumps(result)
     if world > 1:
         dist.barrier()
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE line, and the last thing on stdout: RCCL prints its version banner through C stdio (block-buffered on a pipe, flushed
+        # at exit -- behind a line printed earlier), so the group is torn down and C stdio flushed first
+        flush_c_stdio()
+        print(line, flush=True)
+
+
+def flush_c_stdio():
+    """RCCL (and the HIP runtime) write to the C-level stdout, which is block-buffered on a pipe and would otherwise be flushed at
+    exit -- BEHIND the one JSON line the caller parses (seen with a one-rank RCCL group: five banner lines after the line)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
 
 
 CONTRACT_KEYS = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
@@ -594,6 +610,7 @@ def dry_run(args):
         dt = float(tmax.item())
     ok = bool(torch.equal(out, x0[:, None].expand(-1, 16, -1, -1, -1)))
     if rank == 0:
+        flush_c_stdio()
         print(json.dumps({"metric": "DRY RUN (CPU / gloo stand-in step, no kernels): launch path only", "value": out.shape[0] * 16 * args.steps / dt,
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
