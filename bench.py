@@ -146,28 +146,43 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} inside a {world}-process job (WORLD_SIZE): the two must agree")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        # N > 1 adds RCCL's own streams and the collation stream to the main and the cINN stream; HIP multiplexes streams onto four
-        # hardware queues and streams sharing a queue serialise.  Round 5 switched the decoder's in-call side stream off here (and
-        # thereby measured `small_batch` in a configuration the N > 1 job did not run); since round 6 the decoder's side work shares
-        # the cINN prefetch stream (--side-stream shared: main + one side + collation), the SAME configuration at every N.
+    # multi: this process takes every N > 1 code path.  I2V_BENCH_FORCE_MULTI=1 (measurement / test) does so with ONE rank -- a one-rank RCCL
+    # group on this GPU -- so that the lines only a multi-GPU job reaches (collectives around the timing, the rank lists, the line's N > 1
+    # keys) run on a one-GPU box too
+    forced = world == 1 and os.environ.get("I2V_BENCH_FORCE_MULTI") == "1"
+    multi = world > 1 or forced
+    if forced:
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        args.emulate_collation = "rccl"
+    if multi:
+        # Every N runs the same three streams (main, the cINN prefetch stream, the decoder handle's side stream); for N > 1 the prefetch
+        # stream also carries each step's all-gather (--collation-stream auto).  Round 5 switched the in-call side stream
+        # off here and thereby projected scaling from a configuration the N > 1 job did not run.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        # the job must really be N ranks over RCCL on N distinct GPUs -- not N replicas that never met
-        if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl" or not torch.cuda.nccl.version():
-            raise SystemExit(f"bench.py: expected {args.gpus} ranks over RCCL, got world {dist.get_world_size()} / backend {dist.get_backend()}")
-        rank_devices = [None] * world    # (recorded in the line; RCCL itself refuses two ranks on one GPU)
-        try:
-            uuid = str(torch.cuda.get_device_properties(dev).uuid)
-        except Exception:
-            uuid = None
-        dist.all_gather_object(rank_devices, (rank, torch.cuda.current_device(), uuid))
+        with c_stdout_to_stderr():   # (RCCL's start-up banner goes to stderr)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # the job must really be N ranks over RCCL on N distinct GPUs -- not N replicas that never met
+            if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl" or not torch.cuda.nccl.version():
+                raise SystemExit(f"bench.py: expected {args.gpus} ranks over RCCL, got world {dist.get_world_size()} / backend {dist.get_backend()}")
+            rank_devices = [None] * world    # (recorded in the line; RCCL itself refuses two ranks on one GPU)
+            try:
+                uuid = str(torch.cuda.get_device_properties(dev).uuid)
+            except Exception:
+                uuid = None
+            dist.all_gather_object(rank_devices, (rank, torch.cuda.current_device(), uuid))
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)            # the first device collective brings the communicator up (inside the redirection)
+            torch.cuda.synchronize()
     else:
         rank_devices = [(0, torch.cuda.current_device(), None)]
         if args.emulate_collation == "rccl":
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            with c_stdout_to_stderr():
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                warm = torch.zeros(1, device=dev)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
     torch.set_grad_enabled(False)
 
     if args.scaling == "weak":
@@ -194,10 +209,10 @@ def main():
     import i2v_pipeline
     prefetch = i2v_pipeline.LatentPrefetcher(lambda r, e: flow(r, e, reverse=True), device=dev, enabled=bool(args.pipeline))
     coll_mode = "prefetch" if args.collation_stream == "auto" else args.collation_stream
-    coll_on_prefetch = coll_mode == "prefetch" and prefetch.enabled and (world > 1 or args.emulate_collation)
-    collator = i2v_dist.OverlappedCollator(total, emulate=args.emulate_collation if world == 1 else None, stream=prefetch.stream if coll_on_prefetch else None)
+    coll_on_prefetch = coll_mode == "prefetch" and prefetch.enabled and (multi or args.emulate_collation)
+    collator = i2v_dist.OverlappedCollator(total, emulate=args.emulate_collation if (not multi or forced) else None, stream=prefetch.stream if coll_on_prefetch else None)
     # the decoder's side work: its handle's own stream, unless the collation has a stream of its own too (then the fourth stream must go)
-    side_mode = args.side_stream if args.side_stream != "auto" else ("shared" if ((world > 1 or args.emulate_collation) and not coll_on_prefetch) else "own")
+    side_mode = args.side_stream if args.side_stream != "auto" else ("shared" if ((multi or args.emulate_collation) and not coll_on_prefetch) else "own")
     shared = side_mode == "shared" and prefetch.enabled
     if shared:
         gen.share_side_stream(prefetch.stream)
@@ -253,7 +268,7 @@ def main():
         return float(np.median(ts))
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -274,7 +289,7 @@ def main():
     timed_sums = list(step_sums)
     dt_rank = dt
     rank_ms = [dt / max(args.steps, 1) * 1e3]
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # the timing scalar (max over ranks)
         dt = float(tmax.item())
@@ -331,7 +346,7 @@ def main():
         ts0 = time.perf_counter()
         # six chunks = 1.2x the span at the timed rate: the SAME count on every rank (dt is the max over ranks), so that the
         # collectives inside stay matched; a single process may add chunks until the span is really covered
-        while len(chunks) < 6 or (world == 1 and time.perf_counter() - ts0 < args.sustain + 0.05):
+        while len(chunks) < 6 or (not multi and time.perf_counter() - ts0 < args.sustain + 0.05):
             tc = time.perf_counter()
             run_steps(n_c)
             collator.result()
@@ -347,12 +362,12 @@ def main():
             raise SystemExit(f"bench.py: sustained-load steps {bad[:8]} differ from the serial reference")
     # second first-class workload of the default line (before the exact-fp32 leg creates another handle with its own side stream)
     small = None
-    if rank == 0 and world == 1 and not args.no_extras and args.small_batch > 0 and args.config == "bair64" and nb == 64 and vid_length == 16:
+    if rank == 0 and not multi and not args.no_extras and args.small_batch > 0 and args.config == "bair64" and nb == 64 and vid_length == 16:
         small = small_batch_leg(flow, gen, x0_d, res_d, emb_d, vid_length, args.small_batch,
                                 {"single_call": {"ms": single_ms}, "ms_per_step": dt / args.steps * 1e3}, prefetch)
     # the un-emulated number: the same step on the exact-fp32 MFMA kernels (mma = 0), N = 1 only
     exact = None
-    if not args.no_extras and world == 1 and gen.mma != 0 and not args.no_exact:
+    if not args.no_extras and not multi and gen.mma != 0 and not args.no_exact:
         gen0 = Generator({"channel_factor": cfg["nf"], "z_dim": 64, "upsample_s": cfg["ups"], "upsample_t": cfg["upt"],
                           "spectral_norm": True, "mma": 0})
         gen0.load_state_dict(dsd)
@@ -410,7 +425,7 @@ def main():
                      ("; auto mode: per-layer fallback to exact fp32 behind the range guard, switched so far: %s" % gen.native().fallback_layers() if gen.mma == 2 else ""),
             "data": "synthetic (seeded start frames / latents / embeddings, deterministic synthetic weights)",
             "config": {"workload": f"{cfg['name']}, batch {nb}/GPU (global {total}), vid_length {vid_length}: "
-                                   "20-block cINN inverse + decoder pass(es)" + (" + RCCL all-gather (overlapped)" if world > 1 else ""),
+                                   "20-block cINN inverse + decoder pass(es)" + (" + RCCL all-gather (overlapped)" if multi else ""),
                        "global_batch": total, "per_gpu_batch": nb, "frames_per_step": frames_per_step,
                        "parallelism": f"batch-shard x{world}"},
             "value_is": ("THE METRIC (BASELINE.json: synthesized frames/sec, whole-job throughput over `steps` steps): " +
@@ -430,8 +445,8 @@ def main():
                          "note": "value counts `steps` cINN passes + `steps` decoder runs inside the timed region; with pipelining "
                                  "the pass of step k+1 overlaps the decoder of step k (first pass exposed); single_call_ms = one "
                                  "serial call (median of 3)"},
-            "ranks_seen": dist.get_world_size() if world > 1 else 1,
-            "rccl_version": list(torch.cuda.nccl.version()) if world > 1 else None,
+            "ranks_seen": dist.get_world_size() if multi else 1,
+            "rccl_version": list(torch.cuda.nccl.version()) if multi else None,
             "output_check": output_check,
         }
         result.update(roofline(prof, dt, gen.mma, default_workload, layers, args.steps))
@@ -450,7 +465,7 @@ def main():
                 **cinn_latency_floor(flow, nb, cinn["inv_us"]),
                 "measured_hbm_bytes_per_pass": measured, "measured_hbm_bytes_source": msrc,
             }
-        if gen.mma != 0 and result.get("roofline") and not args.no_extras and world == 1 and not args.lean:
+        if gen.mma != 0 and result.get("roofline") and not args.no_extras and not multi and not args.lean:
             result["roofline"]["undisturbed"] = undisturbed_roofline(cfg, dsd, dev, x0_d, last_z["z"], vid_length, result["roofline"])
         if gen.mma != 0 and result.get("roofline") and not args.no_extras and not args.lean:
             # the data-sheet peak assumes 2.4 GHz; with live operands the matrix cores sustain less (power management).
@@ -467,29 +482,29 @@ def main():
         if not args.no_extras and not args.lean:
             result["embedder"] = embedder_latency(cfg, x0_d)
             result["encoder"] = encoder_latency(cfg, x0_d)
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         result["streams"] = {"side_stream": side_mode if prefetch.enabled else "none",
                              "what": ("main + ONE side stream: the cINN prefetch and the decoder handle's side work (SPADE branches, learned "
                                       "shortcuts) share it" if shared else "main + the cINN prefetch stream + the decoder handle's own side stream") +
-                                     ("; + the collation stream and RCCL's" if world > 1 else ""),
-                             "dec_overlap_env": os.environ.get("I2V_DEC_OVERLAP"), "collation_stream_emulated": (args.emulate_collation or False) if world == 1 else False,
-                             "collation_stream": ("the cINN prefetch stream" if coll_on_prefetch else "its own") if (world > 1 or args.emulate_collation) else None,
+                                     ("; + the collation stream and RCCL's" if multi else ""),
+                             "dec_overlap_env": os.environ.get("I2V_DEC_OVERLAP"), "collation_stream_emulated": (args.emulate_collation or False) if not multi else False,
+                             "collation_stream": ("the cINN prefetch stream" if coll_on_prefetch else "its own") if (multi or args.emulate_collation) else None,
                              "rule": "three streams at every N: main + the decoder handle's side stream + the cINN prefetch stream, which for N > 1 also "
                                      "carries the all-gathers (--collation-stream auto); `small_batch` is measured in the one-GPU and in the N > 1 form and "
                                      "projects from the second"}
         if small is not None:
             result["small_batch"] = small
-        if world == 1 and default_workload and not args.no_extras and not args.no_config_128:
+        if not multi and default_workload and not args.no_extras and not args.no_config_128:
             result["config_128"] = config_128_leg(args)
         live = args.live_traffic if args.live_traffic is not None else (not args.no_extras)
-        if live and world == 1:
+        if live and not multi:
             live_traffic(result, args)
         if args.per_layer:
             write_per_layer(args.per_layer, layers, args.steps, gen.mma)
-        validate_line(result, full=world == 1 and gen.mma != 0 and not (args.no_extras or args.no_cpu_baseline or args.no_exact or args.sustain < 10))
+        validate_line(result, full=not multi and gen.mma != 0 and not (args.no_extras or args.no_cpu_baseline or args.no_exact or args.sustain < 10))
         line = json.dumps(result)
-    if world > 1:
+    if multi:
         dist.barrier()
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
@@ -498,6 +513,23 @@ def main():
         # at exit -- behind a line printed earlier), so the group is torn down and C stdio flushed first
         flush_c_stdio()
         print(line, flush=True)
+
+
+class c_stdout_to_stderr:
+    """RCCL prints a five-line version banner through C stdio when its first communicator comes up.  While the process group is brought
+    up, file descriptor 1 points at stderr (and C stdio is flushed before it is restored), so that stdout carries the ONE JSON line only."""
+
+    def __enter__(self):
+        flush_c_stdio()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        flush_c_stdio()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def flush_c_stdio():
