@@ -1542,6 +1542,27 @@ def test_two_process_rccl_collation(tmp_path):
         assert p.returncode == 0, o
 
 
+def test_bench_multi_gpu_code_paths_on_one_gpu():
+    """Round 6: the lines of bench.py that only an N > 1 job reaches -- RCCL group start-up, the collectives around the timing, the rank
+    lists, every step's all-gather on the cINN prefetch stream, the N > 1 keys of the line -- on ONE GPU over a one-rank RCCL group
+    (I2V_BENCH_FORCE_MULTI=1).  stdout must carry exactly the one JSON line (RCCL's start-up banner goes to stderr); the timed steps are
+    checked against a serial reference call by the bench itself."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    port = str(29500 + (os.getpid() * 7) % 2000)
+    env = dict(os.environ, I2V_BENCH_FORCE_MULTI="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--batch", "4", "--steps", "3", "--warmup", "1", "--lean"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:6]
+    line = json.loads(lines[0])
+    assert line["ranks_seen"] == 1 and line["rccl_version"] and len(line["rank_ms_per_step"]) == 1
+    assert line["streams"]["collation_stream"] == "the cINN prefetch stream" and line["steps_check"]["all_bit_identical_to_serial_reference"]
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
