@@ -248,7 +248,7 @@ int wino4_forward(const Wino4Weights& wts, const void* v_hl16, float* out, const
         const long nb = (long)B * a.nbT * a.nbH * a.nbJ;
         if (wino4_loader_supported(a, wts.KT) && nb > 0 && nb < (1L << 30) && (long)T * a.nchunk * 6 * H * a.J * 64 < (1L << 31) &&
             (long)B * T * H * W < (1L << 31) && (!stats || (long)TT * TH * 4 <= (long)T * H * a.J))
-            return wino4_loader_launch(a, (unsigned)nb, st);
+            return wino4_loader_launch(a, (unsigned)nb, st, sw.loader);
     }
     bool thin = false;
     {

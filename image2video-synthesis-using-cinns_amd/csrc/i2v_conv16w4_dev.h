@@ -867,6 +867,6 @@ inline bool wino4_tiling(int T, int H, int W, int KT, int* TT_, int* TH_, int ti
 
 // the LOADER form of the 32-channel 3x3x3 kernel (i2v_conv16w4g.hip): four extra waves issue the V requests
 bool wino4_loader_supported(const W4Args& a, int KT);
-int wino4_loader_launch(W4Args& a, unsigned nblk, hipStream_t st);
+int wino4_loader_launch(W4Args& a, unsigned nblk, hipStream_t st, int form = 1);
 
 }  // namespace i2v

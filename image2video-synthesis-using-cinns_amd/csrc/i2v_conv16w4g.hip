@@ -249,7 +249,7 @@ __device__ __forceinline__ void w4g_chunk(const W4GenLane<SPADE>& L, const char*
 // s_waitcnt, the chunk barrier.  Same V, same tap loops, same bits as the kernels of i2v_conv16w4.hip.
 template <int NT, int CIN, int MODE>
 __global__ __launch_bounds__(W4G_THREADS, 1) void conv_wino4g_f16x3_kernel(W4Args a, W4GenArgs g) {
-    constexpr bool SPADE = MODE == 1, LOADER = MODE == 2;
+    constexpr bool SPADE = MODE == 1, LOADER = MODE >= 2, VLOADER = MODE == 3;   // (MODE 3: the loader's requests go through VGPRs + ds_write_b128 instead of LDS-DMA)
     static_assert(NT == 9, "the generating kernel exists for the 3x3x3 convs of the last level (no temporal up-sampling in front)");
     using Geo = W4Geo<512>;
     constexpr int NTH = 512, WMA = 2, WMB = 1, KT = NT / 3, NW = 8;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(W4G_THREADS, 1) void conv_wino4g_f16x3_kernel(W4Arg
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "v"(off_), "s"(vr), "s"(dst_), "s"(soff_) : "memory");                          \
     }
-            auto request = [&](bool passB, int ch, int rbuf) {   // one chunk's brick into the buffer that starts at LDS row rbuf
+            auto request_dma = [&](bool passB, int ch, int rbuf) {   // one chunk's brick into the buffer that starts at LDS row rbuf
                 const unsigned so = (unsigned)ch * vchunk, db = dst0 + (unsigned)rbuf * 64u;
                 if (!passB) {
 #pragma unroll
@@ -310,7 +310,30 @@ __global__ __launch_bounds__(W4G_THREADS, 1) void conv_wino4g_f16x3_kernel(W4Arg
                     for (int u = 0; u < 8; ++u) W4L_LOAD(offB[u], so, db + (unsigned)(u * 4096))
                 }
             };
-            auto landed = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+            auto landed_dma = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+            // MODE 3: the same rows through the vector registers -- 16 / 8 buffer_load_dwordx4 in flight per loader lane, then one
+            // ds_write_b128 each to the address the LDS-DMA form writes (buffer base + 16 x lane).  Is the thin layers' operand stream
+            // bound by the LDS-DMA path (6-7 TB/s over the chip) or by what feeds it?
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 vbuf[16];
+            int vcount = 0;
+            unsigned vdst = 0;
+            auto request_v = [&](bool passB, int ch, int rbuf) {
+                const unsigned so = (unsigned)ch * vchunk;
+                vdst = dst0 + (unsigned)rbuf * 64u + (unsigned)(tid & 63) * 16u;
+                vcount = passB ? 8 : 16;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (u < 8 || !passB) vbuf[u] = __builtin_amdgcn_raw_buffer_load_b128(vr, passB ? offB[u & 7] : offA[u], so, 0);
+            };
+            auto landed_v = [&] {
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (u < vcount)
+                        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((unsigned long)(vdst + (unsigned)(u * 4096))) = vbuf[u];
+            };
+            auto request = [&](bool passB, int ch, int rbuf) { if constexpr (VLOADER) request_v(passB, ch, rbuf); else request_dma(passB, ch, rbuf); };
+            auto landed = [&] { if constexpr (VLOADER) landed_v(); else landed_dma(); };
             request(false, 0, rA0);
             landed();
             __syncthreads();
@@ -584,13 +607,13 @@ bool wino4_loader_supported(const W4Args& a, int KT) {
     return KT == 3 && !a.tdup && a.CoutPad == 32 && a.TT == W4G_TT && a.TH == W4G_TH && a.th_shift == 3;
 }
 
-int wino4_loader_launch(W4Args& a, unsigned nblk, hipStream_t st) {
+int wino4_loader_launch(W4Args& a, unsigned nblk, hipStream_t st, int form) {
     a.nvirt = (int)nblk;
     a.tofs = 2 * W4_ROWS_A * 64;
     const size_t lds = (size_t)a.tofs + 5 * W4Geo<512>::TILES * 4;
-    auto kern = conv_wino4g_f16x3_kernel<9, 32, 2>;
-    static bool attr_set[I2V_MAX_DEV] = {};
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set)) return rc;
+    auto kern = form == 2 ? conv_wino4g_f16x3_kernel<9, 32, 3> : conv_wino4g_f16x3_kernel<9, 32, 2>;
+    static bool attr_set[2][I2V_MAX_DEV] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set[form == 2])) return rc;
     W4GenArgs g{};
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(W4G_THREADS), lds, st, a, g);
     I2V_HIP_CHECK(hipGetLastError());
